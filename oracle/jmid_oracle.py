@@ -1,0 +1,265 @@
+"""CPU ORACLE for the JMID / iMID predictor hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU (functional, no nn.Module) restatement of the
+reference algorithm.  It is the *checker*: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+The product (``safe-interactive-crowdnav_amd/``) never imports, calls or falls back to it.
+
+PARITY PIN: this restatement is checked against outputs of the reference itself
+(imported in the build container by ``tests/golden/make_golden.py``) through the
+fixtures committed under ``tests/golden/*.npz``  --  see ``tests/test_oracle_golden.py``.
+The reference has no tests of its own, so those generated
+vectors are the pin.
+
+Each function cites the reference lines it follows (paths relative to
+``/root/reference/sicnav_diffusion/JMID/``).
+
+All functions are dtype-generic: pass float64 tensors to get an fp64 "truth".
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+NODE_HIST = "PEDESTRIAN/node_history_encoder"
+EDGE_PED = "PEDESTRIAN->PEDESTRIAN/edge_encoder"
+EDGE_ROBOT = "PEDESTRIAN->JRDB_ROBOT/edge_encoder"
+EDGE_INFL = "PEDESTRIAN/edge_influence_encoder"
+
+
+# --------------------------------------------------------------------------- schedule
+def variance_schedule(num_steps: int = 100, beta_1: float = 1e-4, beta_T: float = 5e-2) -> Dict[str, Tensor]:
+    """MID/models/diffusion.py:12-55 (linear mode), built as in MID/mid.py:1281-1283."""
+    betas = torch.linspace(beta_1, beta_T, steps=num_steps)
+    betas = torch.cat([torch.zeros([1]), betas], dim=0)
+    alphas = 1 - betas
+    log_alphas = torch.log(alphas)
+    for i in range(1, log_alphas.size(0)):  # fp32 sequential accumulation, diffusion.py:36-39
+        log_alphas[i] += log_alphas[i - 1]
+    alpha_bars = log_alphas.exp()
+    sigmas_flex = torch.sqrt(betas)
+    sigmas_inflex = torch.zeros_like(sigmas_flex)
+    for i in range(1, sigmas_flex.size(0)):
+        sigmas_inflex[i] = ((1 - alpha_bars[i - 1]) / (1 - alpha_bars[i])) * betas[i]
+    sigmas_inflex = torch.sqrt(sigmas_inflex)
+    return dict(betas=betas, alphas=alphas, alpha_bars=alpha_bars,
+                sigmas_flex=sigmas_flex, sigmas_inflex=sigmas_inflex)
+
+
+# --------------------------------------------------------------------------- building blocks
+def positional_encoding(max_len: int, d_model: int, dtype=torch.float32) -> Tensor:
+    """MID/models/common.py:37-51 -> pe [max_len, 1, d_model]."""
+    pe = torch.zeros(max_len, d_model)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.unsqueeze(0).transpose(0, 1).to(dtype)
+
+
+def concat_squash_linear(w: Mapping[str, Tensor], prefix: str, ctx_emb: Tensor, x: Tensor) -> Tensor:
+    """MID/models/common.py:58-72: (W x + b) * sigmoid(Wg c + bg) + Wb c."""
+    gate = torch.sigmoid(F.linear(ctx_emb, w[f"{prefix}._hyper_gate.weight"], w[f"{prefix}._hyper_gate.bias"]))
+    bias = F.linear(ctx_emb, w[f"{prefix}._hyper_bias.weight"])
+    return F.linear(x, w[f"{prefix}._layer.weight"], w[f"{prefix}._layer.bias"]) * gate + bias
+
+
+def encoder_layer(w: Mapping[str, Tensor], prefix: str, x: Tensor, nhead: int) -> Tensor:
+    """Stock post-norm nn.TransformerEncoderLayer in eval mode (ReLU, eps 1e-5), as built at
+    MID/models/diffusion.py:120-125 / 161-166.  x: [S, Bt, d] (sequence-first)."""
+    S, Bt, d = x.shape
+    hd = d // nhead
+    qkv = F.linear(x, w[f"{prefix}.self_attn.in_proj_weight"], w[f"{prefix}.self_attn.in_proj_bias"])
+    q, k, v = qkv.chunk(3, dim=-1)
+    # [S, Bt, d] -> [Bt, nhead, S, hd]  (torch.nn.functional.multi_head_attention_forward layout)
+    q = q.reshape(S, Bt * nhead, hd).transpose(0, 1).reshape(Bt, nhead, S, hd)
+    k = k.reshape(S, Bt * nhead, hd).transpose(0, 1).reshape(Bt, nhead, S, hd)
+    v = v.reshape(S, Bt * nhead, hd).transpose(0, 1).reshape(Bt, nhead, S, hd)
+    a = F.scaled_dot_product_attention(q, k, v)
+    a = a.permute(2, 0, 1, 3).reshape(S * Bt, d)
+    a = F.linear(a, w[f"{prefix}.self_attn.out_proj.weight"], w[f"{prefix}.self_attn.out_proj.bias"])
+    a = a.view(S, Bt, d)
+    x = F.layer_norm(x + a, (d,), w[f"{prefix}.norm1.weight"], w[f"{prefix}.norm1.bias"], 1e-5)
+    f = F.linear(F.relu(F.linear(x, w[f"{prefix}.linear1.weight"], w[f"{prefix}.linear1.bias"])),
+                 w[f"{prefix}.linear2.weight"], w[f"{prefix}.linear2.bias"])
+    x = F.layer_norm(x + f, (d,), w[f"{prefix}.norm2.weight"], w[f"{prefix}.norm2.bias"], 1e-5)
+    return x
+
+
+def net_forward(w: Mapping[str, Tensor], x: Tensor, context: Tensor, beta: Tensor, *, joint: bool,
+                tf_layer: int = 3, nhead: int = 4, seq_groups: int = 1) -> Tensor:
+    """One evaluation of the denoising net e_theta([x, ctx], beta).
+
+    joint=True : JointPredictionTransformerConcatLinear.forward, mask=None branch
+                 (MID/models/diffusion.py:173-209): ONE attention sequence over all (t, row) tokens.
+    joint=False: TransformerConcatLinear.forward (diffusion.py:133-150): rows are independent
+                 sequences of length T.
+
+    x [B,T,2], context [B,ctx], beta [B].  ``seq_groups`` > 1 is the multi-episode extension the
+    build needs (not in the reference, which only ever sees one scene): rows are split into
+    ``seq_groups`` equal consecutive groups (episodes) and the joint sequence is formed per group,
+    i.e. attention is block-diagonal across episodes.
+    """
+    B, T, _ = x.shape
+    d = w["concat1._layer.weight"].shape[0]
+    beta = beta.view(B, 1, 1)
+    context = context.view(B, 1, -1)
+    time_emb = torch.cat([beta, torch.sin(beta), torch.cos(beta)], dim=-1)
+    ctx_emb = torch.cat([time_emb, context], dim=-1)
+    h = concat_squash_linear(w, "concat1", ctx_emb, x)          # [B,T,d]
+    final_emb = h.permute(1, 0, 2)                               # [T,B,d]
+    pe = positional_encoding(24, d, dtype=x.dtype)               # max_len=24, diffusion.py:116-118
+    final_emb = final_emb + pe[:T, :]
+    if joint:
+        G = seq_groups
+        Bg = B // G
+        # [T, G, Bg, d] -> per group one sequence ordered (t, row): index t*Bg + b  (diffusion.py:197-199)
+        seq = final_emb.reshape(T, G, Bg, d).permute(0, 2, 1, 3).reshape(T * Bg, G, d)
+        for l in range(tf_layer):
+            seq = encoder_layer(w, f"transformer_encoder.layers.{l}", seq, nhead)
+        trans = seq.reshape(T, Bg, G, d).permute(0, 2, 1, 3).reshape(T, B, d).permute(1, 0, 2)
+    else:
+        seq = final_emb
+        for l in range(tf_layer):
+            seq = encoder_layer(w, f"transformer_encoder.layers.{l}", seq, nhead)
+        trans = seq.permute(1, 0, 2)
+    trans = concat_squash_linear(w, "concat3", ctx_emb, trans)
+    trans = concat_squash_linear(w, "concat4", ctx_emb, trans)
+    return concat_squash_linear(w, "linear", ctx_emb, trans)
+
+
+# --------------------------------------------------------------------------- sampler
+def denoise(w: Mapping[str, Tensor], context: Tensor, x_T: Tensor, *, sample: int, step: int, joint: bool,
+            tf_layer: int = 3, nhead: int = 4, sched: Optional[Dict[str, Tensor]] = None,
+            episodes: int = 1) -> Tensor:
+    """DiffusionTraj.sample_sicnav_inference, sampling="ddim" (MID/models/diffusion.py:478-541).
+
+    context [A, ctx] (A = agents, or episodes*A_per_episode rows episode-major), x_T [sample*A, T, 2]
+    with row r = s*A + a (``context.repeat(sample, 1)``, diffusion.py:496).
+    Returns velocities [sample, A, T, 2].
+
+    For ``episodes`` > 1 the caller passes per-episode tensors stacked on a leading axis instead:
+    context [E, A, ctx], x_T [E, sample*A, T, 2]; returns [E, sample, A, T, 2].
+    """
+    if sched is None:
+        sched = variance_schedule()
+    dt = context.dtype
+    betas, alpha_bars = sched["betas"].to(dt), sched["alpha_bars"].to(dt)
+    num_steps = betas.numel() - 1
+    multi = context.dim() == 3
+    if multi:
+        E, A, C = context.shape
+        sample_context = context.repeat(1, sample, 1).reshape(E * sample * A, C)
+        x_t = x_T.reshape(E * sample * A, x_T.shape[-2], 2)
+        groups = E
+    else:
+        A = context.shape[0]
+        sample_context = context.repeat(sample, 1)
+        x_t = x_T
+        groups = 1
+    batch_size = sample_context.shape[0]
+    stride = int(100 / step)
+    for t in range(num_steps, 0, -stride):
+        alpha_bar = alpha_bars[t]
+        alpha_bar_next = alpha_bars[t - stride]
+        beta = betas[[t] * batch_size]
+        e_theta = net_forward(w, x_t, sample_context, beta, joint=joint, tf_layer=tf_layer, nhead=nhead,
+                              seq_groups=groups)
+        x0_t = (x_t - e_theta * (1 - alpha_bar).sqrt()) / alpha_bar.sqrt()
+        x_t = alpha_bar_next.sqrt() * x0_t + (1 - alpha_bar_next).sqrt() * e_theta
+    if multi:
+        return x_t.reshape(E, sample, A, -1, 2)
+    return x_t.reshape(sample, A, -1, 2)
+
+
+def integrate(vel: Tensor, p0: Tensor, dt: float) -> Tensor:
+    """SingleIntegrator.integrate_samples (MID/models/encoders/dynamics/single_integrator.py:290-321):
+    vel [..., K, A, T, 2], p0 [..., A, 2] -> pos = cumsum(vel, T) * dt + p0."""
+    return torch.cumsum(vel, dim=-2) * dt + p0.unsqueeze(-2).unsqueeze(-4)
+
+
+# --------------------------------------------------------------------------- context encoder
+def lstm_last(w: Mapping[str, Tensor], name: str, x: Tensor) -> Tensor:
+    """Last hidden state of a single-layer nn.LSTM(batch_first) over full-length sequences, h0=c0=0
+    (gate order i,f,g,o).  MID/models/encoders/model_utils.py:77-105 degenerates to this because
+    every sequence is full length (first_history_index == 0)."""
+    Wih, Whh = w[f"{name}.weight_ih_l0"], w[f"{name}.weight_hh_l0"]
+    bih, bhh = w[f"{name}.bias_ih_l0"], w[f"{name}.bias_hh_l0"]
+    Bn, Tn, _ = x.shape
+    H = Whh.shape[1]
+    h = x.new_zeros(Bn, H)
+    c = x.new_zeros(Bn, H)
+    for t in range(Tn):
+        g = F.linear(x[:, t], Wih, bih) + F.linear(h, Whh, bhh)
+        i, f, gg, o = g.chunk(4, dim=-1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+    return h
+
+
+def encode_context(w: Mapping[str, Tensor], x_st: Tensor, nbr_sum: Tensor, edge_mask: Tensor) -> Tensor:
+    """Trajectron++ front end in PREDICT mode -> ctx [A, 2*H].
+
+    MID/models/encoders/mgcvae.py:505-681 (obtain_encoded_tensors), :683-708 (history),
+    :710-824 (edge, "sum" combine + dynamic edge mask), :826-880 + components/additive_attention.py:6-47.
+
+    x_st     [A, Th, 6]     standardized own history
+    nbr_sum  [A, 2, Th, 6]  per edge type (PED->PED, PED->ROBOT): sum over neighbours of their
+                            standardized-relative history (zeros if none)            (mgcvae.py:726-741,753-757)
+    edge_mask[A, 2]         per edge type: clamp(sum(edge values), max=1)             (mgcvae.py:758-768)
+    """
+    h_hist = lstm_last(w, NODE_HIST, x_st)
+    encs = []
+    for e, name in enumerate((EDGE_PED, EDGE_ROBOT)):
+        joint_history = torch.cat([nbr_sum[:, e], x_st], dim=-1)
+        u = lstm_last(w, name, joint_history) * edge_mask[:, e:e + 1]
+        encs.append(u)
+    enc = torch.stack(encs, dim=1)                                                     # [A,2,H]
+    W1, W2, v = w[f"{EDGE_INFL}.w1.weight"], w[f"{EDGE_INFL}.w2.weight"], w[f"{EDGE_INFL}.v.weight"]
+    score = torch.cat([F.linear(torch.tanh(F.linear(enc[:, i], W1) + F.linear(h_hist, W2)), v)
+                       for i in range(enc.shape[1])], dim=1)
+    probs = F.softmax(score, dim=1).unsqueeze(2)
+    infl = torch.sum(probs * enc, dim=1)
+    return torch.cat([infl, h_hist], dim=1)
+
+
+# --------------------------------------------------------------------------- KDE top-k
+def most_likely_samples(forecasts: Tensor, num_ret: int) -> Tuple[Tensor, Tensor]:
+    """get_most_likely_samples, joint branch (mid_sim_wrapper.py:14-169).
+
+    forecasts [K, A, H, 2] -> (top-k forecasts [A, k, H, 2], log-weights [A, k])."""
+    K, A, H, _ = forecasts.shape
+    preds = forecasts.permute(2, 0, 1, 3).reshape(H, K, A * 2)
+    bandwidth = torch.exp(torch.linspace(math.log(0.01), math.log(0.1), steps=H)).to(forecasts.dtype)
+    d = 2 * A
+    n = torch.tensor(float(K), dtype=torch.float32)
+    pi = torch.tensor(math.pi)
+    preds_diff = preds - preds.mean(dim=1, keepdim=True)
+    cov = torch.bmm(preds_diff.transpose(1, 2), preds_diff) / (n - 1)
+    scale_cov_inv = bandwidth[:, None, None] ** -2 * cov
+    scale_cov_inv = scale_cov_inv + torch.eye(d).expand_as(cov) * 1e-6
+    scale_cov = torch.inverse(scale_cov_inv)
+    L = torch.linalg.cholesky_ex(scale_cov)[0]
+    diffs = preds.unsqueeze(2) - preds.unsqueeze(1)
+    inv_L = torch.linalg.inv(L).unsqueeze(1)
+    diffs = torch.matmul(diffs, inv_L) / bandwidth[:, None, None, None]
+    log_exp = -0.5 * torch.norm(diffs, p=2, dim=-1) ** 2
+    log_det = 2 * torch.sum(torch.log(torch.diagonal(L, dim1=-2, dim2=-1)), dim=-1)
+    Z = 0.5 * d * torch.log(2 * pi) + 0.5 * log_det.unsqueeze(-1) + torch.log(n)
+    ll = torch.logsumexp(log_exp - Z.unsqueeze(-1), dim=-1)
+    ll = ll - torch.logsumexp(ll, dim=1, keepdim=True)
+    ll_all = ll.sum(dim=0)
+    idx = torch.argsort(ll_all, dim=-1)[-num_ret:]
+    new_f = forecasts[idx]
+    top = ll_all[idx]
+    top = top - torch.logsumexp(top, dim=-1, keepdim=True)
+    return new_f.permute(1, 0, 2, 3), top.unsqueeze(0).expand(A, num_ret)
+
+
+def to_dtype(w: Mapping[str, Tensor], dtype) -> Dict[str, Tensor]:
+    return {k: v.to(dtype) for k, v in w.items()}
