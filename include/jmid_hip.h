@@ -1,0 +1,158 @@
+/*
+ * jmid_hip.h  --  C ABI of libjmid_hip.so: the MI355X (gfx950) implementation of the
+ * SICNav-Diffusion trajectory predictor hot path (iMID / JMID).
+ *
+ * The reference (sepsamavi/safe-interactive-crowdnav) has no FFI: its boundary is the
+ * Python class HumanTrajectoryForecasterSim (sicnav_diffusion/JMID/mid_sim_wrapper.py:207).
+ * The Python host layer in safe-interactive-crowdnav_amd/ keeps that class surface and
+ * binds the entry points below with ctypes.  Every entry point names
+ * the reference code it replaces (paths relative to sicnav_diffusion/JMID/).
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, ints, floats.  No torch / HIP types.
+ *   - every function returns 0 on success, a negative JMID_E* code otherwise; the message
+ *     is available from jmid_last_error().
+ *   - buffers are caller-owned.  `mem` says where they live: JMID_MEM_HOST (the library
+ *     copies through its stream) or JMID_MEM_DEVICE (device pointers on the handle's GPU,
+ *     e.g. torch.Tensor.data_ptr(); no copies are made).
+ *   - one HIP stream per handle; a handle is not re-entrant (the reference is a
+ *     single-threaded caller; mid_sim_wrapper.py:174 only locks its history buffer).
+ *   - all floating point buffers are fp32, row-major, densely packed.
+ *
+ * Row / token order used throughout (matches the reference's `context.repeat(sample, 1)`,
+ * MID/models/diffusion.py:496, extended with a leading episode axis):
+ *     row r = (e * K + s) * A + a          e: episode, s: sample, a: agent
+ *     x[r, t, c]                           t: horizon step, c in {x, y}
+ */
+#ifndef JMID_HIP_H
+#define JMID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct jmid_ctx* jmid_handle_t;
+
+enum { JMID_NET_IMID = 0, JMID_NET_JMID = 1 };
+enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
+/* arithmetic used for the GEMM / attention contractions (softmax, LayerNorm, gates, DDIM are
+ * always fp32):
+ *   JMID_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   JMID_PREC_F16X3   fp32 emulated by three fp16 MFMAs per product on hi/lo-split operands
+ *                     (~22 significand bits, fp32 accumulate)
+ *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only) */
+enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2 };
+
+enum {
+    JMID_OK = 0,
+    JMID_EINVAL = -1,     /* bad argument / unsupported dimension */
+    JMID_ENOWEIGHT = -2,  /* a required weight has not been loaded */
+    JMID_EHIP = -3,       /* HIP runtime error */
+    JMID_ENOMEM = -4,
+    JMID_ERANGE = -5      /* F16X3/F16: an operand left the fp16 range; rerun with JMID_PREC_F32 */
+};
+
+/* Library / build identification (also the cheap "does it load" probe). */
+const char* jmid_version(void);
+/* Number of visible HIP devices (0 when there is no GPU); never fails. */
+int jmid_device_count(void);
+
+/* Construct a predictor engine on `device_id`.
+ * Replaces the module construction of MID._build_model (MID/mid.py:1270-1297):
+ *   net_kind  JMID_NET_JMID -> JointPredictionTransformerConcatLinear (MID/models/diffusion.py:153)
+ *             JMID_NET_IMID -> TransformerConcatLinear               (MID/models/diffusion.py:112)
+ *   ctx_dim   the yaml key `encoder_dim` (d_model = 2*ctx_dim, ff = 4*ctx_dim, LSTM hidden = ctx_dim/2)
+ *   tf_layer  the yaml key `tf_layer`;  nhead is 4 in the reference (diffusion.py:121,162)
+ *   hist_len  history frames fed to the context encoder (`past_num_frames`, 6 in env.config:11) */
+int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, int tf_layer, int nhead,
+                int hist_len);
+int jmid_destroy(jmid_handle_t h);
+const char* jmid_last_error(jmid_handle_t h);
+
+/* Upload one named fp32 parameter from HOST memory.  Names are the reference's state-dict keys
+ * (net: "concat1._layer.weight", "transformer_encoder.layers.0.self_attn.in_proj_weight", ...;
+ * encoder: "PEDESTRIAN/node_history_encoder.weight_ih_l0", ...), i.e. what
+ * model.load_state_dict(ckpt["ddpm"]) / registrar.load_models(ckpt["encoder"]) consume
+ * (MID/mid.py:1231-1232, 1291).  Unknown names are rejected. */
+int jmid_load_weight(jmid_handle_t h, const char* name, const float* host_data, size_t n_elems);
+/* Check that every parameter is present and build the device-side derived forms
+ * (fp16 hi/lo planes, positional-encoding table).  Must be called once after loading. */
+int jmid_finalize_weights(jmid_handle_t h);
+
+/* Install the DDIM step table: n_steps entries, one per reverse step, in execution order.
+ * Replaces VarianceSchedule + the scalar bookkeeping of sample_sicnav_inference
+ * (MID/models/diffusion.py:12-64, 507-528):
+ *   beta[i]                       betas[t_i]
+ *   c_e[i] = sqrt(1 - abar_t)     c_x[i] = sqrt(abar_t)
+ *   n_x[i] = sqrt(abar_{t-s})     n_e[i] = sqrt(1 - abar_{t-s})
+ * so that  x0 = (x - e*c_e)/c_x ;  x <- n_x*x0 + n_e*e . */
+int jmid_set_ddim_table(jmid_handle_t h, int n_steps, const float* beta, const float* c_e, const float* c_x,
+                        const float* n_x, const float* n_e);
+
+/* Context encoder: Trajectron.get_latent in PREDICT mode
+ * (MID/models/trajectron.py:416-454 -> MID/models/encoders/mgcvae.py:505-880).
+ *   n_agents   total rows (episodes * agents), any order
+ *   x_st       [n_agents, hist_len, 6]     standardized own history
+ *   nbr_sum    [n_agents, 2, hist_len, 6]  per edge type (PED->PED, PED->ROBOT) the summed neighbour
+ *                                          histories (zeros when there is none; mgcvae.py:726-757)
+ *   edge_mask  [n_agents, 2]               clamp(sum(edge values), max=1)  (mgcvae.py:758-768, 821-822)
+ *   ctx_out    [n_agents, ctx_dim] */
+int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* nbr_sum, const float* edge_mask,
+                float* ctx_out, int mem);
+
+/* The batched reverse-denoising loop + integrator:
+ * DiffusionTraj.sample_sicnav_inference with sampling="ddim" (MID/models/diffusion.py:478-541),
+ * the net forward (diffusion.py:133-150 / 173-209) and SingleIntegrator.integrate_samples
+ * (MID/models/encoders/dynamics/single_integrator.py:290-321).
+ *   E, A, K, T  episodes, agents per episode, samples, horizon
+ *   x_T       [E, K*A, T, 2]  initial noise (drawn by the host with torch's CPU generator so that the
+ *                             reference's RNG contract is kept, diffusion.py:499)
+ *   ctx       [E, A, ctx_dim]
+ *   p0        [E, A, 2]       current positions (initial condition of the integrator); may be NULL
+ *                             when pos_out is NULL
+ *   dt        env time_step
+ *   vel_out   [E, K, A, T, 2] predicted velocities            (may be NULL)
+ *   pos_out   [E, K, A, T, 2] cumsum(vel)*dt + p0             (may be NULL)
+ * JMID attention spans all (t, s, a) tokens of ONE episode (block-diagonal over episodes). */
+int jmid_denoise(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, const float* ctx,
+                 const float* p0, float dt, int precision, float* vel_out, float* pos_out, int mem);
+
+/* One evaluation of the denoising net e_theta([x, ctx], beta) for step-table entry `step_idx`
+ * (diffusion.py:520); used by the parity tests.  x [E, K*A, T, 2] -> e_out same shape. */
+int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, const float* x, const float* ctx,
+                  int precision, float* e_out, int mem);
+
+/* ---- tuning / measurement ------------------------------------------------------------------ */
+/* Episodes processed together per pass of the 50-step loop (0 = automatic).  Smaller chunks keep the
+ * activations of one pass resident in the 256 MiB Infinity Cache. */
+int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
+/* Per-kernel-class timing with HIP events recorded on the handle's stream.
+ * mask: bit i enables class i (see jmid_kernel_class_name); 0 disables.  Timers accumulate until reset. */
+int jmid_profile_enable(jmid_handle_t h, uint32_t class_mask);
+int jmid_profile_reset(jmid_handle_t h);
+/* Synchronizes the stream and returns, for kernel class `cls`, the number of launches and the summed
+ * duration in milliseconds since the last reset. */
+int jmid_profile_get(jmid_handle_t h, int cls, int64_t* n_launches, double* total_ms);
+int jmid_kernel_class_count(void);
+const char* jmid_kernel_class_name(int cls);
+/* Block until all work queued on the handle's stream has finished. */
+int jmid_synchronize(jmid_handle_t h);
+
+/* ---- diagnostics: single-kernel entry points for the unit tests (HOST buffers only) ----------- */
+/* C[M,N] = A[M,K] . Wt[N,K]^T + bias (optional ReLU): the nn.Linear contraction of every layer. */
+int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
+                  int precision, float* C);
+/* Multi-head self-attention over `nseq` sequences of length S from a packed QKV buffer
+ * [nseq*S, 3*d_model] -> OUT [nseq*S, d_model] (heads/dims of the handle). */
+int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT);
+/* X <- LayerNorm(X + Y) * gamma + beta, eps = 1e-5 (post-norm residual of nn.TransformerEncoderLayer). */
+int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float* Y, const float* gamma,
+                           const float* beta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JMID_HIP_H */

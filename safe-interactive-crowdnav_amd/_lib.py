@@ -1,0 +1,78 @@
+"""ctypes binding of libjmid_hip.so (include/jmid_hip.h).  Fails loudly when the library is missing:
+there is no Python/CPU fallback for the compute path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import library_path
+
+c_float_p = C.POINTER(C.c_float)
+Handle = C.c_void_p
+
+NET_IMID, NET_JMID = 0, 1
+MEM_HOST, MEM_DEVICE = 0, 1
+PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16}
+
+ERR_NAMES = {-1: "JMID_EINVAL", -2: "JMID_ENOWEIGHT", -3: "JMID_EHIP", -4: "JMID_ENOMEM", -5: "JMID_ERANGE"}
+
+# name -> (restype, argtypes): every symbol declared in include/jmid_hip.h
+SIGNATURES = {
+    "jmid_version": (C.c_char_p, []),
+    "jmid_device_count": (C.c_int, []),
+    "jmid_create": (C.c_int, [C.POINTER(Handle), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "jmid_destroy": (C.c_int, [Handle]),
+    "jmid_last_error": (C.c_char_p, [Handle]),
+    "jmid_load_weight": (C.c_int, [Handle, C.c_char_p, C.c_void_p, C.c_size_t]),
+    "jmid_finalize_weights": (C.c_int, [Handle]),
+    "jmid_set_ddim_table": (C.c_int, [Handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jmid_encode": (C.c_int, [Handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "jmid_denoise": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "jmid_net_eval": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                C.c_int, C.c_void_p, C.c_int]),
+    "jmid_set_chunk_episodes": (C.c_int, [Handle, C.c_int]),
+    "jmid_profile_enable": (C.c_int, [Handle, C.c_uint32]),
+    "jmid_profile_reset": (C.c_int, [Handle]),
+    "jmid_profile_get": (C.c_int, [Handle, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "jmid_kernel_class_count": (C.c_int, []),
+    "jmid_kernel_class_name": (C.c_char_p, [C.c_int]),
+    "jmid_synchronize": (C.c_int, [Handle]),
+    "jmid_dbg_gemm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                C.c_int, C.c_void_p]),
+    "jmid_dbg_attention": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "jmid_dbg_add_layernorm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+class JmidError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+_LIB = None
+
+
+def load_library() -> C.CDLL:
+    """Load (once) the in-tree HIP library.  Raises if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # torch first: it bundles its own HIP runtime (libamdhip64) and must be the one instance in the process,
+    # otherwise a second runtime loaded from /opt/rocm sees no device and device pointers cannot be shared
+    import torch  # noqa: F401
+
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The predictor has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib

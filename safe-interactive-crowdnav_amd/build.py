@@ -1,0 +1,44 @@
+"""Builds csrc/libjmid_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "libjmid_hip.so")
+SOURCES = ["jmid_api.hip"]
+
+
+def _newest_source_mtime() -> float:
+    m = 0.0
+    for root in (CSRC, os.path.join(os.path.dirname(CSRC), "..", "include")):
+        for f in os.listdir(root):
+            if f.endswith((".hip", ".hpp", ".h")):
+                m = max(m, os.path.getmtime(os.path.join(root, f)))
+    return m
+
+
+def library_path() -> str:
+    return LIB
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP library in-tree.  Returns the path of the .so."""
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libjmid_hip.so")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+           "-o", LIB] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{proc.stdout}\n{proc.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,58 @@
+// Common device/host helpers for libjmid_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace jmid {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+
+// Layout of the per-(episode,agent) ConcatSquash "hyper" vector and of the per-step time table:
+// [gate1 | bias1 | gate3 | bias3 | gate4 | bias4 | gateO | biasO]   (MID/models/common.py:58-72)
+struct HyperLayout {
+    int g1, b1, g3, b3, g4, b4, go, bo, total;
+};
+__host__ __device__ inline HyperLayout make_hyper_layout(int d_model, int d_mid, int d_low) {
+    HyperLayout L;
+    L.g1 = 0;
+    L.b1 = L.g1 + d_model;
+    L.g3 = L.b1 + d_model;
+    L.b3 = L.g3 + d_mid;
+    L.g4 = L.b3 + d_mid;
+    L.b4 = L.g4 + d_low;
+    L.go = L.b4 + d_low;
+    L.bo = L.go + 2;
+    L.total = L.bo + 2;
+    return L;
+}
+
+// token m -> (episode, agent) row of the hyper buffer.  rows: r = (e*K + s)*A + a ; m = r*T + t
+struct RowMap {
+    int T, A, KA;  // KA = K*A
+    __device__ __forceinline__ int ea(int m) const {
+        int r = m / T;
+        int e = r / KA;
+        int a = r % A;
+        return e * A + a;
+    }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// C/D fragment row of a 32x32 MFMA accumulator register (col = lane & 31)
+__device__ __forceinline__ int frag_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
+
+}  // namespace jmid

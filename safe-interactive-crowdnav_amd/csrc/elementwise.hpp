@@ -1,0 +1,159 @@
+// Bandwidth-bound pieces of one denoise step (all fp32):
+//   embed        concat1 (ConcatSquashLinear 2 -> d) + positional encoding    diffusion.py:183-185, common.py:37-72
+//   add_ln       residual + post-LayerNorm of nn.TransformerEncoderLayer       (norm_first=False, eps 1e-5)
+//   out_ddim     final ConcatSquashLinear (d_low -> 2) + DDIM update           diffusion.py:209, 524-528
+//   integrate    SingleIntegrator.integrate_samples                            single_integrator.py:290-321
+#pragma once
+#include "common.hpp"
+
+namespace jmid {
+
+// ------------------------------------------------------------------------------------------------ embed
+struct EmbedArgs {
+    const float* x;      // [M, 2]
+    const float* W1;     // [d, 2]
+    const float* b1;     // [d]
+    const float* pe;     // [max_len, d]
+    const float* hyp;    // [EA, hyp_ld]
+    const float* thyp;   // [hyp_ld]
+    float* X;            // [M, d]
+    int M, d, hyp_ld, goff, boff;
+    RowMap rmap;
+};
+
+// one thread per (token, 4 channels)
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+    const int d4 = a.d >> 2;
+    const long total = (long)a.M * d4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / d4), j = (int)(idx % d4) * 4;
+        const float x0 = a.x[2 * (size_t)m], x1 = a.x[2 * (size_t)m + 1];
+        const int t = m % a.rmap.T;
+        const float* hrow = a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = j + e;
+            const float lin = a.W1[2 * c] * x0 + a.W1[2 * c + 1] * x1 + a.b1[c];
+            const float gate = sigmoidf_(hrow[a.goff + c] + a.thyp[a.goff + c]);
+            const float bias = hrow[a.boff + c] + a.thyp[a.boff + c];
+            o[e] = lin * gate + bias + a.pe[(size_t)t * a.d + c];
+        }
+        *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ add + LayerNorm
+// X[m,:] = LN(X[m,:] + Y[m,:]) * gamma + beta ; one wave per row, d <= 64*4*VPL
+template <int VPL>  // float4 vectors per lane
+__global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, const float* gamma, const float* beta,
+                                                     int M, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float* xr = X + (size_t)row * d;
+    const float* yr = Y + (size_t)row * d;
+    f32x4 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(xr + c);
+            f32x4 b = *reinterpret_cast<const f32x4*>(yr + c);
+            v[i] = a + b;
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
+            f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+            *reinterpret_cast<f32x4*>(xr + c) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ final CSL + DDIM
+struct OutArgs {
+    const float* Y4;     // [M, dl]
+    const float* Wo;     // [2, dl]
+    const float* bo;     // [2]
+    const float* hyp;    // [EA, hyp_ld]
+    const float* thyp;   // [hyp_ld]
+    float* x;            // [M, 2] in/out (DDIM) ; untouched when e_out != nullptr
+    float* e_out;        // [M, 2] or nullptr: write e_theta instead of updating x
+    int M, dl, hyp_ld, goff, boff;
+    float c_e, c_x, n_x, n_e;
+    RowMap rmap;
+};
+
+// one wave per token
+__global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const float* y = a.Y4 + (size_t)m * a.dl;
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = lane; c < a.dl; c += 64) {
+        const float v = y[c];
+        s0 += v * a.Wo[c];
+        s1 += v * a.Wo[a.dl + c];
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+        const float* hrow = a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld;
+        const float e0 = (s0 + a.bo[0]) * sigmoidf_(hrow[a.goff] + a.thyp[a.goff]) + hrow[a.boff] + a.thyp[a.boff];
+        const float e1 = (s1 + a.bo[1]) * sigmoidf_(hrow[a.goff + 1] + a.thyp[a.goff + 1]) + hrow[a.boff + 1] +
+                         a.thyp[a.boff + 1];
+        if (a.e_out) {
+            a.e_out[2 * (size_t)m] = e0;
+            a.e_out[2 * (size_t)m + 1] = e1;
+        } else {
+            // x0 = (x - e*sqrt(1-abar_t))/sqrt(abar_t) ; x <- sqrt(abar_next)*x0 + sqrt(1-abar_next)*e
+            const float x0 = a.x[2 * (size_t)m], x1 = a.x[2 * (size_t)m + 1];
+            const float p0 = (x0 - e0 * a.c_e) / a.c_x, p1 = (x1 - e1 * a.c_e) / a.c_x;
+            a.x[2 * (size_t)m] = a.n_x * p0 + a.n_e * e0;
+            a.x[2 * (size_t)m + 1] = a.n_x * p1 + a.n_e * e1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ integrator
+// vel [R, T, 2] (R = E*K*A rows, r = (e*K+s)*A + a) -> pos = cumsum_t(vel)*dt + p0[e, a]
+__global__ void integrate_kernel(const float* vel, const float* p0, float* pos, int R, int T, int A, int KA, float dt) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (row, c)
+    if (idx >= R * 2) return;
+    const int r = idx >> 1, c = idx & 1;
+    const int e = r / KA, ag = r % A;
+    const float base = p0[((size_t)e * A + ag) * 2 + c];
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        acc += vel[((size_t)r * T + t) * 2 + c];
+        pos[((size_t)r * T + t) * 2 + c] = acc * dt + base;
+    }
+}
+
+}  // namespace jmid

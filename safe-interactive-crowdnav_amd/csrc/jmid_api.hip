@@ -1,0 +1,850 @@
+// libjmid_hip.so  --  C ABI (include/jmid_hip.h) + host orchestration of the HIP kernels.
+// gfx950 only.  No CPU fallback: every entry point that computes needs a HIP device.
+#include "../../include/jmid_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "attn_f32.hpp"
+#include "common.hpp"
+#include "elementwise.hpp"
+#include "encoder.hpp"
+#include "gemm_f32.hpp"
+
+using namespace jmid;
+
+namespace {
+
+enum KClass {
+    KC_GEMM_QKV = 0,
+    KC_GEMM_OUT,
+    KC_GEMM_FF1,
+    KC_GEMM_FF2,
+    KC_GEMM_TAIL,
+    KC_ATTN,
+    KC_ADD_LN,
+    KC_EMBED,
+    KC_OUT_DDIM,
+    KC_HYPER,
+    KC_ENCODER,
+    KC_INTEGRATE,
+    KC_COUNT
+};
+const char* kClassNames[KC_COUNT] = {"gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_tail", "attention",
+                                     "add_layernorm", "embed", "out_ddim", "hyper", "encoder", "integrate"};
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+};
+
+struct EvPair {
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct jmid_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
+    int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
+    HyperLayout hl;
+    std::map<std::string, std::vector<size_t>> expected;  // name -> shape
+    std::map<std::string, DevBuf> w;
+    bool finalized = false;
+    // derived device buffers
+    float* pe = nullptr;
+    float* Whyp = nullptr;
+    float* bhyp = nullptr;
+    float* thyp = nullptr;  // [n_steps, hl.total]
+    std::vector<float> time_w;  // host [hl.total][3] time columns of the hyper nets
+    float* lstmT[3][3] = {{nullptr}};  // [hist, edge_ped, edge_robot] x [WihT, WhhT, b]
+    float* attW1T = nullptr;
+    float* attW2T = nullptr;
+    // ddim table (host)
+    std::vector<float> beta, c_e, c_x, n_x, n_e;
+    // workspace arena
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    // I/O staging
+    int chunk_eps = 0;
+    // profiling
+    uint32_t prof_mask = 0;
+    std::vector<EvPair> prof_ev[KC_COUNT];
+    std::vector<EvPair> ev_pool;
+    double prof_ms[KC_COUNT] = {0};
+    int64_t prof_n[KC_COUNT] = {0};
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(jmid_ctx* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                               \
+    do {                                                                                              \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess)                                                                        \
+            return fail(h, JMID_EHIP, std::string(#expr) + ": " + hipGetErrorString(e__));            \
+    } while (0)
+
+struct ProfScope {
+    jmid_ctx* h;
+    int cls;
+    bool on;
+    EvPair ev;
+    ProfScope(jmid_ctx* h_, int cls_) : h(h_), cls(cls_), on((h_->prof_mask >> cls_) & 1u) {
+        if (on) {
+            if (!h->ev_pool.empty()) {
+                ev = h->ev_pool.back();
+                h->ev_pool.pop_back();
+            } else {
+                hipEventCreate(&ev.a);
+                hipEventCreate(&ev.b);
+            }
+            hipEventRecord(ev.a, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            hipEventRecord(ev.b, h->stream);
+            h->prof_ev[cls].push_back(ev);
+        }
+    }
+};
+
+void register_shapes(jmid_ctx* h) {
+    auto& E = h->expected;
+    const size_t d = h->d, ff = h->ff, c = h->ctx_dim + 3, H = h->H;
+    auto csl = [&](const std::string& p, size_t din, size_t dout) {
+        E[p + "._layer.weight"] = {dout, din};
+        E[p + "._layer.bias"] = {dout};
+        E[p + "._hyper_bias.weight"] = {dout, c};
+        E[p + "._hyper_gate.weight"] = {dout, c};
+        E[p + "._hyper_gate.bias"] = {dout};
+    };
+    csl("concat1", 2, d);
+    for (int l = 0; l < h->tf_layer; ++l) {
+        std::string p = "transformer_encoder.layers." + std::to_string(l);
+        E[p + ".self_attn.in_proj_weight"] = {3 * d, d};
+        E[p + ".self_attn.in_proj_bias"] = {3 * d};
+        E[p + ".self_attn.out_proj.weight"] = {d, d};
+        E[p + ".self_attn.out_proj.bias"] = {d};
+        E[p + ".linear1.weight"] = {ff, d};
+        E[p + ".linear1.bias"] = {ff};
+        E[p + ".linear2.weight"] = {d, ff};
+        E[p + ".linear2.bias"] = {d};
+        E[p + ".norm1.weight"] = {d};
+        E[p + ".norm1.bias"] = {d};
+        E[p + ".norm2.weight"] = {d};
+        E[p + ".norm2.bias"] = {d};
+    }
+    csl("concat3", d, h->dmid);
+    csl("concat4", h->dmid, h->dlow);
+    csl("linear", h->dlow, 2);
+    const char* lstm[3] = {"PEDESTRIAN/node_history_encoder", "PEDESTRIAN->PEDESTRIAN/edge_encoder",
+                           "PEDESTRIAN->JRDB_ROBOT/edge_encoder"};
+    for (int i = 0; i < 3; ++i) {
+        std::string p = lstm[i];
+        size_t in = i == 0 ? 6 : 12;
+        E[p + ".weight_ih_l0"] = {4 * H, in};
+        E[p + ".weight_hh_l0"] = {4 * H, H};
+        E[p + ".bias_ih_l0"] = {4 * H};
+        E[p + ".bias_hh_l0"] = {4 * H};
+    }
+    E["PEDESTRIAN/edge_influence_encoder.w1.weight"] = {H, H};
+    E["PEDESTRIAN/edge_influence_encoder.w2.weight"] = {H, H};
+    E["PEDESTRIAN/edge_influence_encoder.v.weight"] = {1, H};
+}
+
+size_t numel(const std::vector<size_t>& s) {
+    size_t n = 1;
+    for (size_t v : s) n *= v;
+    return n;
+}
+
+int dev_alloc_copy(jmid_ctx* h, float** out, const std::vector<float>& host) {
+    HIPCHK(h, hipMalloc((void**)out, host.size() * sizeof(float)));
+    HIPCHK(h, hipMemcpy(*out, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int fetch_host(jmid_ctx* h, const std::string& name, std::vector<float>& out) {
+    auto it = h->w.find(name);
+    if (it == h->w.end()) return fail(h, JMID_ENOWEIGHT, "missing weight " + name);
+    out.resize(it->second.n);
+    HIPCHK(h, hipMemcpy(out.data(), it->second.p, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+const float* W(jmid_ctx* h, const std::string& name) { return h->w[name].p; }
+
+int ensure_arena(jmid_ctx* h, size_t bytes) {
+    if (bytes <= h->arena_bytes) return 0;
+    if (h->arena) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->arena));
+        h->arena = nullptr;
+        h->arena_bytes = 0;
+    }
+    hipError_t e = hipMalloc((void**)&h->arena, bytes);
+    if (e != hipSuccess) return fail(h, JMID_ENOMEM, "workspace allocation of " + std::to_string(bytes) + " bytes failed");
+    h->arena_bytes = bytes;
+    return 0;
+}
+
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    float* take(size_t nfloats) {
+        float* p = reinterpret_cast<float*>(base ? base + off : nullptr);
+        off += ((nfloats * sizeof(float) + 255) / 256) * 256;
+        return p;
+    }
+};
+
+// upload the per-step time part of the four hyper nets: thyp[i][j] = w0*beta + w1*sin(beta) + w2*cos(beta)
+int upload_time_table(jmid_ctx* h) {
+    if (!h->finalized || h->beta.empty()) return 0;
+    const int n = (int)h->beta.size(), tot = h->hl.total;
+    std::vector<float> t((size_t)n * tot);
+    for (int i = 0; i < n; ++i) {
+        const float b = h->beta[i], sb = sinf(b), cb = cosf(b);
+        for (int j = 0; j < tot; ++j) {
+            const float* w3 = &h->time_w[(size_t)j * 3];
+            t[(size_t)i * tot + j] = w3[0] * b + w3[1] * sb + w3[2] * cb;
+        }
+    }
+    if (h->thyp) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(h->thyp));
+        h->thyp = nullptr;
+    }
+    return dev_alloc_copy(h, &h->thyp, t);
+}
+
+// ---------------------------------------------------------------------------------------------- launch helpers
+template <int EPI>
+int run_gemm(jmid_ctx* h, int cls, GemmArgs& g) {
+    if (g.K % GEMM_BK != 0) return fail(h, JMID_EINVAL, "GEMM K must be a multiple of 32");
+    ProfScope ps(h, cls);
+    HIPCHK(h, launch_gemm_f32<EPI>(g, h->stream));
+    return 0;
+}
+
+int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const float* bt, int M, int d) {
+    ProfScope ps(h, KC_ADD_LN);
+    const int rows_per_block = 4;
+    dim3 grid((M + rows_per_block - 1) / rows_per_block);
+    const int vpl = (d + 255) / 256;
+    switch (vpl) {
+        case 1: hipLaunchKernelGGL(add_ln_kernel<1>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f); break;
+        case 2: hipLaunchKernelGGL(add_ln_kernel<2>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f); break;
+        case 3:
+        case 4: hipLaunchKernelGGL(add_ln_kernel<4>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f); break;
+        default: return fail(h, JMID_EINVAL, "d_model too large for add_ln");
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+struct StepBuffers {
+    float *X, *QKV, *ATT, *Y, *H1, *Y3, *Y4;
+};
+
+size_t step_ws_floats(const jmid_ctx* h, size_t Mc, StepBuffers* sb, char* base) {
+    Carver c(base);
+    StepBuffers s;
+    s.X = c.take(Mc * h->d);
+    s.QKV = c.take(Mc * 3 * h->d);
+    s.ATT = c.take(Mc * h->d);
+    s.Y = c.take(Mc * h->d);
+    s.H1 = c.take(Mc * h->ff);
+    s.Y3 = c.take(Mc * h->dmid);
+    s.Y4 = c.take(Mc * h->dlow);
+    if (sb) *sb = s;
+    return c.off;
+}
+
+// one evaluation of the net on a chunk of whole episodes + (optionally) the DDIM update
+int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, int step_idx, float* x_chunk,
+             const float* hyp_chunk, float* e_out) {
+    const int R = Ec * K * A, M = R * T;
+    const int d = h->d, ff = h->ff;
+    const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
+    RowMap rm{T, A, K * A};
+    {
+        ProfScope ps(h, KC_EMBED);
+        EmbedArgs ea{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, thyp,
+                     sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm};
+        const long total = (long)M * (d / 4);
+        int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
+        hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), 0, h->stream, ea);
+        HIPCHK(h, hipGetLastError());
+    }
+    const int nseq = h->net_kind == JMID_NET_JMID ? Ec : R;
+    const int S = h->net_kind == JMID_NET_JMID ? K * A * T : T;
+    const int hd = d / h->nhead;
+    for (int l = 0; l < h->tf_layer; ++l) {
+        const std::string p = "transformer_encoder.layers." + std::to_string(l);
+        GemmArgs g{};
+        g.rmap = rm;
+        // QKV projection
+        g.A = sb.X; g.lda = d; g.W = W(h, p + ".self_attn.in_proj_weight"); g.ldw = d;
+        g.bias = W(h, p + ".self_attn.in_proj_bias"); g.C = sb.QKV; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
+        if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g)) return rc;
+        {
+            ProfScope ps(h, KC_ATTN);
+            AttnArgs aa{sb.QKV, sb.ATT, S, d, h->nhead, 1.0f / sqrtf((float)hd)};
+            HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
+        }
+        // attention output projection + residual + LN1
+        g.A = sb.ATT; g.lda = d; g.W = W(h, p + ".self_attn.out_proj.weight"); g.ldw = d;
+        g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+        if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_OUT, g)) return rc;
+        if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d)) return rc;
+        // feed-forward
+        g.A = sb.X; g.lda = d; g.W = W(h, p + ".linear1.weight"); g.ldw = d; g.bias = W(h, p + ".linear1.bias");
+        g.C = sb.H1; g.ldc = ff; g.N = ff; g.K = d;
+        if (int rc = run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_FF1, g)) return rc;
+        g.A = sb.H1; g.lda = ff; g.W = W(h, p + ".linear2.weight"); g.ldw = ff; g.bias = W(h, p + ".linear2.bias");
+        g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
+        if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_FF2, g)) return rc;
+        if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d)) return rc;
+    }
+    // tail: concat3, concat4 (ConcatSquash epilogues), then final CSL + DDIM
+    {
+        GemmArgs g{};
+        g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
+        g.A = sb.X; g.lda = d; g.W = W(h, "concat3._layer.weight"); g.ldw = d; g.bias = W(h, "concat3._layer.bias");
+        g.C = sb.Y3; g.ldc = h->dmid; g.N = h->dmid; g.K = d; g.goff = h->hl.g3; g.boff = h->hl.b3;
+        if (int rc = run_gemm<EPI_CSL>(h, KC_GEMM_TAIL, g)) return rc;
+        g.A = sb.Y3; g.lda = h->dmid; g.W = W(h, "concat4._layer.weight"); g.ldw = h->dmid;
+        g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
+        g.goff = h->hl.g4; g.boff = h->hl.b4;
+        if (int rc = run_gemm<EPI_CSL>(h, KC_GEMM_TAIL, g)) return rc;
+    }
+    {
+        ProfScope ps(h, KC_OUT_DDIM);
+        OutArgs oa{sb.Y4, W(h, "linear._layer.weight"), W(h, "linear._layer.bias"), hyp_chunk, thyp, x_chunk, e_out,
+                   M, h->dlow, h->hl.total, h->hl.go, h->hl.bo,
+                   h->c_e[step_idx], h->c_x[step_idx], h->n_x[step_idx], h->n_e[step_idx], rm};
+        hipLaunchKernelGGL(out_ddim_kernel, dim3((M + 3) / 4), dim3(256), 0, h->stream, oa);
+        HIPCHK(h, hipGetLastError());
+    }
+    return 0;
+}
+
+int pick_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
+    if (h->chunk_eps > 0) return std::min(E, h->chunk_eps);
+    const long target = 24576;  // tokens per pass: ~150 MB of fp32 activations, inside the 256 MiB Infinity Cache
+    long c = target / std::max(1, tokens_per_episode);
+    if (c < 1) c = 1;
+    return (int)std::min<long>(c, E);
+}
+
+int check_ready(jmid_ctx* h) {
+    if (!h) return JMID_EINVAL;
+    if (!h->finalized) return fail(h, JMID_ENOWEIGHT, "jmid_finalize_weights has not been called");
+    if (h->beta.empty() || !h->thyp) return fail(h, JMID_EINVAL, "jmid_set_ddim_table has not been called");
+    return 0;
+}
+
+int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, const float* ctx, const float* p0, float dt,
+                int precision, int single_step, float* vel_out, float* pos_out, float* e_out, int mem) {
+    if (int rc = check_ready(h)) return rc;
+    if (E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "E, A, K, T must be positive");
+    if (T > 24) return fail(h, JMID_EINVAL, "T exceeds the positional-encoding table (max_len=24, diffusion.py:116-118)");
+    if (precision != JMID_PREC_F32) return fail(h, JMID_EINVAL, "precision mode not available in this build");
+    if (!x_in || !ctx) return fail(h, JMID_EINVAL, "null input");
+    if (pos_out && !p0) return fail(h, JMID_EINVAL, "pos_out requested without p0");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t R = (size_t)E * K * A, M = R * T, EA = (size_t)E * A;
+    const int Ec = pick_chunk(h, E, K * A * T);
+    const size_t Mc = (size_t)Ec * K * A * T;
+    // ---- workspace
+    size_t io_off;
+    {
+        Carver c(nullptr);
+        c.take(M * 2);                 // x_cur
+        c.take(EA * h->ctx_dim);       // ctx
+        c.take(EA * h->hl.total);      // hyp
+        c.take(EA * 2);                // p0
+        c.take(M * 2);                 // e / pos staging
+        io_off = c.off;
+    }
+    const size_t need = io_off + step_ws_floats(h, Mc, nullptr, nullptr);
+    if (int rc = ensure_arena(h, need)) return rc;
+    Carver c(h->arena);
+    float* x_cur = c.take(M * 2);
+    float* ctx_d = c.take(EA * h->ctx_dim);
+    float* hyp = c.take(EA * h->hl.total);
+    float* p0_d = c.take(EA * 2);
+    float* stage = c.take(M * 2);
+    StepBuffers sb;
+    step_ws_floats(h, Mc, &sb, h->arena + io_off);
+
+    const hipMemcpyKind kin = mem == JMID_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const hipMemcpyKind kout = mem == JMID_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPCHK(h, hipMemcpyAsync(x_cur, x_in, M * 2 * sizeof(float), kin, h->stream));
+    const float* ctx_use = ctx;
+    if (mem == JMID_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(ctx_d, ctx, EA * h->ctx_dim * sizeof(float), kin, h->stream));
+        ctx_use = ctx_d;
+    }
+    const float* p0_use = p0;
+    if (p0 && mem == JMID_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(p0_d, p0, EA * 2 * sizeof(float), kin, h->stream));
+        p0_use = p0_d;
+    }
+    // ---- ctx part of the four hyper nets, once per call (ctx is constant over the denoise steps)
+    {
+        GemmArgs g{};
+        g.A = ctx_use; g.lda = h->ctx_dim; g.W = h->Whyp; g.ldw = h->ctx_dim; g.bias = h->bhyp; g.C = hyp;
+        g.ldc = h->hl.total; g.M = (int)EA; g.N = h->hl.total; g.K = h->ctx_dim;
+        if (int rc = run_gemm<EPI_BIAS>(h, KC_HYPER, g)) return rc;
+    }
+    const int n_steps = (int)h->beta.size();
+    for (int e0 = 0; e0 < E; e0 += Ec) {
+        const int ec = std::min(Ec, E - e0);
+        float* xc = x_cur + (size_t)e0 * K * A * T * 2;
+        const float* hc = hyp + (size_t)e0 * A * h->hl.total;
+        if (single_step >= 0) {
+            float* eo = stage + (size_t)e0 * K * A * T * 2;
+            if (int rc = net_step(h, sb, ec, A, K, T, single_step, xc, hc, eo)) return rc;
+        } else {
+            for (int i = 0; i < n_steps; ++i)
+                if (int rc = net_step(h, sb, ec, A, K, T, i, xc, hc, nullptr)) return rc;
+        }
+    }
+    if (single_step >= 0) {
+        HIPCHK(h, hipMemcpyAsync(e_out, stage, M * 2 * sizeof(float), kout, h->stream));
+    } else {
+        if (vel_out) HIPCHK(h, hipMemcpyAsync(vel_out, x_cur, M * 2 * sizeof(float), kout, h->stream));
+        if (pos_out) {
+            {
+                ProfScope ps(h, KC_INTEGRATE);
+                const int n = (int)R * 2;
+                hipLaunchKernelGGL(integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, x_cur, p0_use,
+                                   stage, (int)R, T, A, K * A, dt);
+                HIPCHK(h, hipGetLastError());
+            }
+            HIPCHK(h, hipMemcpyAsync(pos_out, stage, M * 2 * sizeof(float), kout, h->stream));
+        }
+    }
+    if (mem == JMID_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+const char* jmid_version(void) { return "jmid_hip 0.1.0 (gfx950; f32-mfma)"; }
+
+int jmid_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* jmid_last_error(jmid_handle_t h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, int tf_layer, int nhead, int hist_len) {
+    if (!out) return JMID_EINVAL;
+    *out = nullptr;
+    if (net_kind != JMID_NET_IMID && net_kind != JMID_NET_JMID) return fail(nullptr, JMID_EINVAL, "bad net_kind");
+    if (ctx_dim < 32 || ctx_dim % 32 != 0 || ctx_dim > 512)
+        return fail(nullptr, JMID_EINVAL, "ctx_dim must be a multiple of 32 in [32, 512]");
+    if (tf_layer < 1 || tf_layer > 16) return fail(nullptr, JMID_EINVAL, "bad tf_layer");
+    const int d = 2 * ctx_dim;
+    if (nhead < 1 || d % nhead != 0) return fail(nullptr, JMID_EINVAL, "nhead must divide d_model");
+    const int hd = d / nhead;
+    if (hd != 16 && hd != 32 && hd != 64 && hd != 128)
+        return fail(nullptr, JMID_EINVAL, "head_dim must be one of 16, 32, 64, 128");
+    if (hist_len < 1 || hist_len > ENC_MAX_TH) return fail(nullptr, JMID_EINVAL, "hist_len out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, JMID_EHIP, "no HIP device available (libjmid_hip has no CPU fallback)");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, JMID_EINVAL, "device_id out of range");
+    jmid_ctx* h = new jmid_ctx();
+    h->device = device_id;
+    h->net_kind = net_kind;
+    h->ctx_dim = ctx_dim;
+    h->tf_layer = tf_layer;
+    h->nhead = nhead;
+    h->hist_len = hist_len;
+    h->d = d;
+    h->ff = 4 * ctx_dim;
+    h->dmid = ctx_dim;
+    h->dlow = ctx_dim / 2;
+    h->H = ctx_dim / 2;
+    h->hl = make_hyper_layout(h->d, h->dmid, h->dlow);
+    register_shapes(h);
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+        delete h;
+        return fail(nullptr, JMID_EHIP, "cannot create a HIP stream");
+    }
+    *out = h;
+    return JMID_OK;
+}
+
+int jmid_destroy(jmid_handle_t h) {
+    if (!h) return JMID_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (auto& kv : h->w) hipFree(kv.second.p);
+    for (float* p : {h->pe, h->Whyp, h->bhyp, h->thyp, h->attW1T, h->attW2T})
+        if (p) hipFree(p);
+    for (auto& l : h->lstmT)
+        for (float* p : l)
+            if (p) hipFree(p);
+    if (h->arena) hipFree(h->arena);
+    for (int c = 0; c < KC_COUNT; ++c)
+        for (auto& ev : h->prof_ev[c]) {
+            hipEventDestroy(ev.a);
+            hipEventDestroy(ev.b);
+        }
+    for (auto& ev : h->ev_pool) {
+        hipEventDestroy(ev.a);
+        hipEventDestroy(ev.b);
+    }
+    hipStreamDestroy(h->stream);
+    delete h;
+    return JMID_OK;
+}
+
+int jmid_load_weight(jmid_handle_t h, const char* name, const float* host_data, size_t n_elems) {
+    if (!h || !name || !host_data) return JMID_EINVAL;
+    auto it = h->expected.find(name);
+    if (it == h->expected.end()) return fail(h, JMID_EINVAL, std::string("unknown weight name ") + name);
+    if (numel(it->second) != n_elems)
+        return fail(h, JMID_EINVAL, std::string("size mismatch for ") + name + ": expected " +
+                                        std::to_string(numel(it->second)) + ", got " + std::to_string(n_elems));
+    HIPCHK(h, hipSetDevice(h->device));
+    DevBuf& b = h->w[name];
+    if (!b.p) HIPCHK(h, hipMalloc((void**)&b.p, n_elems * sizeof(float)));
+    b.n = n_elems;
+    HIPCHK(h, hipMemcpy(b.p, host_data, n_elems * sizeof(float), hipMemcpyHostToDevice));
+    h->finalized = false;
+    return JMID_OK;
+}
+
+int jmid_finalize_weights(jmid_handle_t h) {
+    if (!h) return JMID_EINVAL;
+    for (auto& kv : h->expected)
+        if (!h->w.count(kv.first)) return fail(h, JMID_ENOWEIGHT, "missing weight " + kv.first);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (float** p : {&h->pe, &h->Whyp, &h->bhyp, &h->attW1T, &h->attW2T})
+        if (*p) {
+            hipFree(*p);
+            *p = nullptr;
+        }
+    for (auto& l : h->lstmT)
+        for (float*& p : l)
+            if (p) {
+                hipFree(p);
+                p = nullptr;
+            }
+    const int d = h->d, C = h->ctx_dim, CC = C + 3;
+    // positional encoding table, max_len = 24 (MID/models/common.py:37-51; diffusion.py:116-118)
+    {
+        std::vector<float> pe((size_t)24 * d);
+        const float coef = (float)(-std::log(10000.0) / (double)d);  // python scalar -> fp32, as torch does
+        for (int pos = 0; pos < 24; ++pos)
+            for (int i = 0; i < d; i += 2) {
+                const float div = (float)std::exp((double)((float)i * coef));
+                const float arg = (float)pos * div;
+                pe[(size_t)pos * d + i] = (float)std::sin((double)arg);
+                if (i + 1 < d) pe[(size_t)pos * d + i + 1] = (float)std::cos((double)arg);
+            }
+        if (int rc = dev_alloc_copy(h, &h->pe, pe)) return rc;
+    }
+    // packed ctx-part of the hyper nets [hl.total, C], their biases, and the 3 time columns (host)
+    {
+        const HyperLayout& L = h->hl;
+        std::vector<float> Wp((size_t)L.total * C), bp(L.total, 0.f);
+        h->time_w.assign((size_t)L.total * 3, 0.f);
+        struct Part {
+            const char* prefix;
+            int goff, boff, dout;
+        } parts[4] = {{"concat1", L.g1, L.b1, d}, {"concat3", L.g3, L.b3, h->dmid}, {"concat4", L.g4, L.b4, h->dlow},
+                      {"linear", L.go, L.bo, 2}};
+        for (auto& pt : parts) {
+            std::vector<float> wg, bg, wb;
+            if (int rc = fetch_host(h, std::string(pt.prefix) + "._hyper_gate.weight", wg)) return rc;
+            if (int rc = fetch_host(h, std::string(pt.prefix) + "._hyper_gate.bias", bg)) return rc;
+            if (int rc = fetch_host(h, std::string(pt.prefix) + "._hyper_bias.weight", wb)) return rc;
+            for (int j = 0; j < pt.dout; ++j) {
+                for (int c = 0; c < C; ++c) {
+                    Wp[(size_t)(pt.goff + j) * C + c] = wg[(size_t)j * CC + 3 + c];
+                    Wp[(size_t)(pt.boff + j) * C + c] = wb[(size_t)j * CC + 3 + c];
+                }
+                bp[pt.goff + j] = bg[j];
+                for (int c = 0; c < 3; ++c) {
+                    h->time_w[(size_t)(pt.goff + j) * 3 + c] = wg[(size_t)j * CC + c];
+                    h->time_w[(size_t)(pt.boff + j) * 3 + c] = wb[(size_t)j * CC + c];
+                }
+            }
+        }
+        if (int rc = dev_alloc_copy(h, &h->Whyp, Wp)) return rc;
+        if (int rc = dev_alloc_copy(h, &h->bhyp, bp)) return rc;
+    }
+    // transposed LSTM / attention weights for the encoder kernel
+    {
+        const char* lstm[3] = {"PEDESTRIAN/node_history_encoder", "PEDESTRIAN->PEDESTRIAN/edge_encoder",
+                               "PEDESTRIAN->JRDB_ROBOT/edge_encoder"};
+        const int H = h->H, H4 = 4 * H;
+        for (int i = 0; i < 3; ++i) {
+            const int in = i == 0 ? 6 : 12;
+            std::vector<float> wih, whh, bih, bhh;
+            std::string p = lstm[i];
+            if (int rc = fetch_host(h, p + ".weight_ih_l0", wih)) return rc;
+            if (int rc = fetch_host(h, p + ".weight_hh_l0", whh)) return rc;
+            if (int rc = fetch_host(h, p + ".bias_ih_l0", bih)) return rc;
+            if (int rc = fetch_host(h, p + ".bias_hh_l0", bhh)) return rc;
+            std::vector<float> wihT((size_t)in * H4), whhT((size_t)H * H4), b(H4);
+            for (int r = 0; r < H4; ++r) {
+                for (int k = 0; k < in; ++k) wihT[(size_t)k * H4 + r] = wih[(size_t)r * in + k];
+                for (int k = 0; k < H; ++k) whhT[(size_t)k * H4 + r] = whh[(size_t)r * H + k];
+                b[r] = bih[r] + bhh[r];
+            }
+            if (int rc = dev_alloc_copy(h, &h->lstmT[i][0], wihT)) return rc;
+            if (int rc = dev_alloc_copy(h, &h->lstmT[i][1], whhT)) return rc;
+            if (int rc = dev_alloc_copy(h, &h->lstmT[i][2], b)) return rc;
+        }
+        std::vector<float> w1, w2;
+        if (int rc = fetch_host(h, "PEDESTRIAN/edge_influence_encoder.w1.weight", w1)) return rc;
+        if (int rc = fetch_host(h, "PEDESTRIAN/edge_influence_encoder.w2.weight", w2)) return rc;
+        std::vector<float> w1T((size_t)H * H), w2T((size_t)H * H);
+        for (int r = 0; r < H; ++r)
+            for (int k = 0; k < H; ++k) {
+                w1T[(size_t)k * H + r] = w1[(size_t)r * H + k];
+                w2T[(size_t)k * H + r] = w2[(size_t)r * H + k];
+            }
+        if (int rc = dev_alloc_copy(h, &h->attW1T, w1T)) return rc;
+        if (int rc = dev_alloc_copy(h, &h->attW2T, w2T)) return rc;
+    }
+    h->finalized = true;
+    return upload_time_table(h);
+}
+
+int jmid_set_ddim_table(jmid_handle_t h, int n_steps, const float* beta, const float* c_e, const float* c_x,
+                        const float* n_x, const float* n_e) {
+    if (!h || n_steps <= 0 || !beta || !c_e || !c_x || !n_x || !n_e) return fail(h, JMID_EINVAL, "bad ddim table");
+    h->beta.assign(beta, beta + n_steps);
+    h->c_e.assign(c_e, c_e + n_steps);
+    h->c_x.assign(c_x, c_x + n_steps);
+    h->n_x.assign(n_x, n_x + n_steps);
+    h->n_e.assign(n_e, n_e + n_steps);
+    HIPCHK(h, hipSetDevice(h->device));
+    return upload_time_table(h);
+}
+
+int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* nbr_sum, const float* edge_mask,
+                float* ctx_out, int mem) {
+    if (!h) return JMID_EINVAL;
+    if (!h->finalized) return fail(h, JMID_ENOWEIGHT, "jmid_finalize_weights has not been called");
+    if (n_agents <= 0 || !x_st || !nbr_sum || !edge_mask || !ctx_out) return fail(h, JMID_EINVAL, "bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int Th = h->hist_len, H = h->H;
+    const size_t n = n_agents;
+    const float *xs = x_st, *ns = nbr_sum, *em = edge_mask;
+    float* co = ctx_out;
+    if (mem == JMID_MEM_HOST) {
+        Carver c0(nullptr);
+        c0.take(n * Th * 6); c0.take(n * 2 * Th * 6); c0.take(n * 2); c0.take(n * 2 * H);
+        if (int rc = ensure_arena(h, c0.off)) return rc;
+        Carver c(h->arena);
+        float* dx = c.take(n * Th * 6);
+        float* dn = c.take(n * 2 * Th * 6);
+        float* de = c.take(n * 2);
+        co = c.take(n * 2 * H);
+        HIPCHK(h, hipMemcpyAsync(dx, x_st, n * Th * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(dn, nbr_sum, n * 2 * Th * 6 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(de, edge_mask, n * 2 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        xs = dx; ns = dn; em = de;
+    }
+    {
+        ProfScope ps(h, KC_ENCODER);
+        EncArgs ea{};
+        ea.x_st = xs; ea.nbr_sum = ns; ea.edge_mask = em;
+        ea.hist = LstmW{h->lstmT[0][0], h->lstmT[0][1], h->lstmT[0][2]};
+        ea.edge[0] = LstmW{h->lstmT[1][0], h->lstmT[1][1], h->lstmT[1][2]};
+        ea.edge[1] = LstmW{h->lstmT[2][0], h->lstmT[2][1], h->lstmT[2][2]};
+        ea.W1T = h->attW1T; ea.W2T = h->attW2T; ea.v = W(h, "PEDESTRIAN/edge_influence_encoder.v.weight");
+        ea.ctx = co; ea.n = n_agents; ea.Th = Th; ea.H = H;
+        hipLaunchKernelGGL(encoder_kernel, dim3(n_agents), dim3(4 * H), 0, h->stream, ea);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (mem == JMID_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(ctx_out, co, n * 2 * H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return JMID_OK;
+}
+
+int jmid_denoise(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, const float* ctx, const float* p0,
+                 float dt, int precision, float* vel_out, float* pos_out, int mem) {
+    if (!h) return JMID_EINVAL;
+    return run_network(h, E, A, K, T, x_T, ctx, p0, dt, precision, -1, vel_out, pos_out, nullptr, mem);
+}
+
+int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, const float* x, const float* ctx,
+                  int precision, float* e_out, int mem) {
+    if (!h) return JMID_EINVAL;
+    if (!e_out) return fail(h, JMID_EINVAL, "null e_out");
+    if (step_idx < 0 || step_idx >= (int)h->beta.size()) return fail(h, JMID_EINVAL, "step_idx out of range");
+    return run_network(h, E, A, K, T, x, ctx, nullptr, 0.f, precision, step_idx, nullptr, nullptr, e_out, mem);
+}
+
+int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
+    if (!h || episodes < 0) return JMID_EINVAL;
+    h->chunk_eps = episodes;
+    return JMID_OK;
+}
+
+int jmid_profile_enable(jmid_handle_t h, uint32_t class_mask) {
+    if (!h) return JMID_EINVAL;
+    h->prof_mask = class_mask;
+    return JMID_OK;
+}
+
+static int prof_collect(jmid_ctx* h) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int c = 0; c < KC_COUNT; ++c) {
+        for (auto& ev : h->prof_ev[c]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+                h->prof_ms[c] += ms;
+                h->prof_n[c] += 1;
+            }
+            h->ev_pool.push_back(ev);
+        }
+        h->prof_ev[c].clear();
+    }
+    return 0;
+}
+
+int jmid_profile_reset(jmid_handle_t h) {
+    if (!h) return JMID_EINVAL;
+    if (int rc = prof_collect(h)) return rc;
+    for (int c = 0; c < KC_COUNT; ++c) {
+        h->prof_ms[c] = 0;
+        h->prof_n[c] = 0;
+    }
+    return JMID_OK;
+}
+
+int jmid_profile_get(jmid_handle_t h, int cls, int64_t* n_launches, double* total_ms) {
+    if (!h || cls < 0 || cls >= KC_COUNT) return JMID_EINVAL;
+    if (int rc = prof_collect(h)) return rc;
+    if (n_launches) *n_launches = h->prof_n[cls];
+    if (total_ms) *total_ms = h->prof_ms[cls];
+    return JMID_OK;
+}
+
+int jmid_kernel_class_count(void) { return KC_COUNT; }
+const char* jmid_kernel_class_name(int cls) { return (cls >= 0 && cls < KC_COUNT) ? kClassNames[cls] : ""; }
+
+int jmid_synchronize(jmid_handle_t h) {
+    if (!h) return JMID_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return JMID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- diagnostics
+// Single-op entry points used by the unit tests (host buffers only).
+int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
+                  int precision, float* C) {
+    if (!h || !A || !Wt || !C) return JMID_EINVAL;
+    if (precision != JMID_PREC_F32) return fail(h, JMID_EINVAL, "precision mode not available in this build");
+    HIPCHK(h, hipSetDevice(h->device));
+    float *dA, *dW, *dB = nullptr, *dC;
+    HIPCHK(h, hipMalloc((void**)&dA, (size_t)M * K * 4));
+    HIPCHK(h, hipMalloc((void**)&dW, (size_t)N * K * 4));
+    HIPCHK(h, hipMalloc((void**)&dC, (size_t)M * N * 4));
+    HIPCHK(h, hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dW, Wt, (size_t)N * K * 4, hipMemcpyHostToDevice));
+    if (bias) {
+        HIPCHK(h, hipMalloc((void**)&dB, (size_t)N * 4));
+        HIPCHK(h, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
+    }
+    GemmArgs g{};
+    g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    int rc = relu ? run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_QKV, g) : run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+    }
+    if (!rc) HIPCHK(h, hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dW); hipFree(dC);
+    if (dB) hipFree(dB);
+    return rc;
+}
+
+int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT) {
+    if (!h || !QKV || !OUT) return JMID_EINVAL;
+    if (precision != JMID_PREC_F32) return fail(h, JMID_EINVAL, "precision mode not available in this build");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t Mt = (size_t)nseq * S;
+    float *dQ, *dO;
+    HIPCHK(h, hipMalloc((void**)&dQ, Mt * 3 * h->d * 4));
+    HIPCHK(h, hipMalloc((void**)&dO, Mt * h->d * 4));
+    HIPCHK(h, hipMemcpy(dQ, QKV, Mt * 3 * h->d * 4, hipMemcpyHostToDevice));
+    const int hd = h->d / h->nhead;
+    AttnArgs aa{dQ, dO, S, h->d, h->nhead, 1.0f / sqrtf((float)hd)};
+    int rc = 0;
+    {
+        ProfScope ps(h, KC_ATTN);
+        hipError_t e = launch_attn_f32(aa, nseq, hd, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+    }
+    if (!rc) HIPCHK(h, hipMemcpy(OUT, dO, Mt * h->d * 4, hipMemcpyDeviceToHost));
+    hipFree(dQ); hipFree(dO);
+    return rc;
+}
+
+int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float* Y, const float* gamma,
+                           const float* beta) {
+    if (!h || !X || !Y || !gamma || !beta) return JMID_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    float *dX, *dY, *dG, *dB;
+    HIPCHK(h, hipMalloc((void**)&dX, (size_t)M * d * 4));
+    HIPCHK(h, hipMalloc((void**)&dY, (size_t)M * d * 4));
+    HIPCHK(h, hipMalloc((void**)&dG, (size_t)d * 4));
+    HIPCHK(h, hipMalloc((void**)&dB, (size_t)d * 4));
+    HIPCHK(h, hipMemcpy(dX, X, (size_t)M * d * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dY, Y, (size_t)M * d * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dG, gamma, (size_t)d * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(dB, beta, (size_t)d * 4, hipMemcpyHostToDevice));
+    int rc = run_add_ln(h, dX, dY, dG, dB, M, d);
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+    }
+    if (!rc) HIPCHK(h, hipMemcpy(X, dX, (size_t)M * d * 4, hipMemcpyDeviceToHost));
+    hipFree(dX); hipFree(dY); hipFree(dG); hipFree(dB);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""Single-kernel checks of the HIP library against float64 numpy/torch references (GPU box only)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from safe_interactive_crowdnav_amd.engine import JmidEngine
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+
+PRECISIONS = ["f32"]
+# max abs error allowed relative to max|ref| per precision mode
+TOL = {"f32": 2e-5, "f16x3": 4e-5, "f16": 2e-2}
+
+
+@pytest.fixture(scope="module", params=[32, 256])
+def engine(request):
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=request.param), 1), joint=True)
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("M,N,K,relu", [(1200, 1536, 512, False), (77, 16, 32, False), (300, 192, 64, True),
+                                        (129, 130, 96, False), (2500, 512, 1024, True), (5, 1796, 256, False),
+                                        (40000, 512, 512, False)])
+def test_gemm_matches_float64(engine, M, N, K, relu, precision):
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    # asymmetric data (transpose-detecting): scale rows / cols differently
+    A *= np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
+    W *= np.linspace(1.5, 0.5, N, dtype=np.float32)[:, None]
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    out = engine.dbg_gemm(A, W, b, relu=relu, precision=precision)
+    err = np.abs(out - ref).max()
+    assert err <= TOL[precision] * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("nseq,S", [(2, 1200), (7, 12), (3, 48), (2, 33), (1, 129), (5, 1), (2, 24)])
+def test_attention_matches_float64(engine, nseq, S, precision):
+    d = 2 * engine.dims.ctx_dim
+    nh = engine.dims.nhead
+    hd = d // nh
+    rng = np.random.default_rng(nseq * 1000 + S)
+    qkv = rng.standard_normal((nseq * S, 3 * d)).astype(np.float32)
+    qkv[:, :d] *= 1.7  # sharper softmax
+    out = engine.dbg_attention(qkv, nseq, S, precision=precision)
+    t = torch.from_numpy(qkv).double().view(nseq, S, 3, nh, hd)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(nseq * S, d).numpy()
+    assert np.abs(out - ref).max() <= TOL[precision] * max(1.0, np.abs(ref).max())
+
+
+def test_attention_online_softmax_rescale_branch(engine):
+    """A key whose score dwarfs everything seen so far must rescale the running state correctly:
+    spike one key late in the sequence (cdna guide rule: force the rare branch)."""
+    d = 2 * engine.dims.ctx_dim
+    nh = engine.dims.nhead
+    hd = d // nh
+    S = 200
+    rng = np.random.default_rng(0)
+    qkv = rng.standard_normal((S, 3 * d)).astype(np.float32)
+    qkv[150, d:2 * d] = 6.0 * qkv[17, :d]  # key 150 aligned with query 17 -> huge score in a late tile
+    out = engine.dbg_attention(qkv, 1, S)
+    t = torch.from_numpy(qkv).double().view(1, S, 3, nh, hd)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(S, d).numpy()
+    assert np.abs(out - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("M", [1, 5, 1200])
+def test_add_layernorm_matches_torch(engine, M):
+    d = 2 * engine.dims.ctx_dim
+    rng = np.random.default_rng(M)
+    X = rng.standard_normal((M, d)).astype(np.float32)
+    Y = rng.standard_normal((M, d)).astype(np.float32)
+    g = rng.standard_normal(d).astype(np.float32)
+    b = rng.standard_normal(d).astype(np.float32)
+    out = engine.dbg_add_layernorm(X, Y, g, b)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(X + Y).double(), (d,), torch.from_numpy(g).double(),
+                                         torch.from_numpy(b).double(), 1e-5).numpy()
+    assert np.abs(out - ref).max() <= 1e-5

@@ -1,0 +1,136 @@
+"""Parity of the HIP path (through the C ABI) with the REFERENCE golden vectors and with the oracle.
+
+mean ADE = mean over (episode, sample, agent, t) of the L2 distance, the per-element definition of
+compute_ade (MID/evaluation/evaluation.py:20-26) applied between two predictors.  Gate: 1e-4 (north_star).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jmid_oracle as O
+from safe_interactive_crowdnav_amd.engine import JmidEngine
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ADE_GATE = 1e-4
+PRECISIONS = ["f32"]
+
+
+def ade(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64), axis=-1).mean())
+
+
+_ENGINES = {}
+
+
+def get_engine(ctx_dim, wseed, joint):
+    key = (ctx_dim, wseed, joint)
+    if key not in _ENGINES:
+        w = JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), wseed)
+        _ENGINES[key] = (JmidEngine(w, joint=joint), w)
+    return _ENGINES[key]
+
+
+NET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "net_*.npz")))
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", NET_CASES)
+def test_net_eval_and_denoise_match_reference_golden(case, precision):
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    assert w.checksum() == str(z["wsum"])
+    A, K, T, step = int(z["A"]), int(z["K"]), int(z["T"]), int(z["step"])
+    eng.set_step(step)
+    ctx = z["ctx"][None]                 # [1, A, C]
+    x_T = z["x_T"][None]                 # [1, K*A, T, 2]
+    e = eng.net_eval(x_T, ctx, step_idx=0, precision=precision)[0]
+    assert ade(e, z["e_first"]) <= 1e-5, ("e_theta", ade(e, z["e_first"]))
+    vel, _ = eng.denoise(x_T, ctx, precision=precision, want_pos=False)
+    a = ade(vel[0], z["vel"])
+    print(f"{case} [{precision}] mean ADE(vel) vs reference = {a:.3e}")
+    assert a <= ADE_GATE, a
+
+
+WRAP_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "wrapper_*.npz")))
+
+
+@pytest.mark.parametrize("case", WRAP_CASES)
+def test_context_encoder_matches_reference_golden(case):
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    ctx = eng.encode(z["x_st"], z["nbr_sum"], z["edge_mask"])
+    np.testing.assert_allclose(ctx, z["ctx"], rtol=0, atol=5e-6)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("joint", [True, False])
+def test_multi_episode_batch_is_block_diagonal(joint, precision):
+    """E episodes in one call == E independent single-scene calls == the oracle per episode,
+    for any chunking (JMID attention must not leak across episodes)."""
+    eng, w = get_engine(32, 77, joint)
+    eng.set_step(10)
+    E, A, K, T = 5, 3, 4, 6
+    g = torch.Generator().manual_seed(5)
+    ctx = torch.randn([E, A, 32], generator=g)
+    x_T = torch.randn([E, K * A, T, 2], generator=g)
+    p0 = torch.randn([E, A, 2], generator=g)
+    with torch.no_grad():
+        ref = torch.stack([O.denoise(w.tensors, ctx[e], x_T[e], sample=K, step=10, joint=joint) for e in range(E)])
+        ref_multi = O.denoise(w.tensors, ctx, x_T, sample=K, step=10, joint=joint)
+        ref_pos = O.integrate(ref, p0, 0.25)
+    assert ade(ref_multi.numpy(), ref.numpy()) <= 1e-6  # the oracle's own multi-episode extension
+    outs = []
+    for chunk in (0, 1, 2, 5):
+        eng.set_chunk_episodes(chunk)
+        vel, pos = eng.denoise(x_T.numpy(), ctx.numpy(), p0.numpy(), dt=0.25, precision=precision)
+        assert ade(vel, ref.numpy()) <= ADE_GATE
+        assert ade(pos, ref_pos.numpy()) <= ADE_GATE
+        outs.append(vel)
+    eng.set_chunk_episodes(0)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])  # chunking must not change a single bit
+
+
+def test_device_pointers_match_host_path():
+    eng, w = get_engine(32, 77, True)
+    eng.set_step(5)
+    E, A, K, T = 2, 2, 3, 4
+    g = torch.Generator().manual_seed(9)
+    ctx = torch.randn([E, A, 32], generator=g)
+    x_T = torch.randn([E, K * A, T, 2], generator=g)
+    p0 = torch.randn([E, A, 2], generator=g)
+    vel_h, pos_h = eng.denoise(x_T.numpy(), ctx.numpy(), p0.numpy())
+    vel_d, pos_d = eng.denoise(x_T.cuda(), ctx.cuda(), p0.cuda())
+    eng.synchronize()
+    np.testing.assert_array_equal(vel_d.cpu().numpy(), vel_h)
+    np.testing.assert_array_equal(pos_d.cpu().numpy(), pos_h)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_property_checks(precision):
+    """BASELINE cfg3-like size (scaled: 32 episodes x N=5 x K=20 x H=12, 50 steps) through size-independent
+    properties: (a) permuting episodes permutes outputs bit-exactly, (b) duplicated episodes give identical
+    outputs, (c) pos = cumsum(vel)*dt + p0."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(50)
+    E, A, K, T = 32, 5, 20, 12
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn([E, A, 256], generator=g)
+    x_T = torch.randn([E, K * A, T, 2], generator=g)
+    p0 = torch.randn([E, A, 2], generator=g)
+    ctx[7], x_T[7], p0[7] = ctx[3], x_T[3], p0[3]
+    vel, pos = eng.denoise(x_T.cuda(), ctx.cuda(), p0.cuda(), dt=0.25, precision=precision)
+    vel, pos = vel.cpu(), pos.cpu()
+    assert torch.isfinite(vel).all()
+    assert torch.equal(vel[7], vel[3]) and torch.equal(pos[7], pos[3])
+    perm = torch.randperm(E, generator=g)
+    vel_p, _ = eng.denoise(x_T[perm].cuda(), ctx[perm].cuda(), p0[perm].cuda(), dt=0.25, precision=precision)
+    assert torch.equal(vel_p.cpu(), vel[perm])
+    ref_pos = torch.cumsum(vel, dim=3) * 0.25 + p0[:, None, :, None, :]
+    assert (pos - ref_pos).abs().max() <= 1e-4
