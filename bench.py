@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Throughput bench of the JMID predictor hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full predictor pass over one batch of synthetic scenes already resident in HBM:
+context encoder -> 50-step batched DDIM reverse-denoising loop -> integrator -> per-episode metrics
+(+ one RCCL gather of the metrics when N > 1).  Episodes are independent and shard across ranks
+(weak scaling: E episodes per GPU).  Metric: sampled trajectories / s = N_gpus * E * N * K / time.
+
+Default workload = BASELINE.json configs[2] ("256 parallel episodes x N=5 x K=20, 1 MI355X"), the
+configuration the throughput target and the roofline are quoted on; the single-scene case (configs[1], E=1)
+is measured in the same run and reported under "single_scene".  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+from safe_interactive_crowdnav_amd.engine import JmidEngine  # noqa: E402
+from safe_interactive_crowdnav_amd.scene import synthetic_episodes  # noqa: E402
+from safe_interactive_crowdnav_amd.sweep import gather_metrics  # noqa: E402
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims  # noqa: E402
+
+WORKLOADS = {
+    # name: (episodes per GPU, N humans, K samples, H horizon, DDIM steps)
+    "cfg2": (1, 5, 20, 12, 50),      # BASELINE.json configs[1]: one scene
+    "cfg3": (256, 5, 20, 12, 50),    # configs[2]: 256 parallel episodes on one GPU
+    "cfg4": (1, 25, 64, 12, 50),     # configs[3]: dense crowd, one scene
+    "cfg5": (512, 5, 20, 12, 50),    # configs[4]: 4096 episodes sharded 512 / GPU
+}
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16": 1}
+
+
+def algorithmic_flops(dims: NetDims, joint: bool, E, A, K, T):
+    """FLOPs of ONE denoise step for E episodes, per kernel class."""
+    d, ff, dm, dl = dims.d_model, dims.d_ff, dims.d_mid, dims.d_low
+    M = E * K * A * T
+    S = K * A * T if joint else T
+    return {
+        "gemm_qkv": 2.0 * M * d * 3 * d * dims.tf_layer,
+        "gemm_attn_out": 2.0 * M * d * d * dims.tf_layer,
+        "gemm_ff1": 2.0 * M * d * ff * dims.tf_layer,
+        "gemm_ff2": 2.0 * M * d * ff * dims.tf_layer,
+        "gemm_tail": 2.0 * M * (d * dm + dm * dl),
+        "attention": 4.0 * M * S * d * dims.tf_layer,
+    }
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--episodes-per-gpu", type=int, default=0)
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
+    ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
+    ap.add_argument("--cpu-episodes", type=int, default=4, help="episodes timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    E, N, K, H, steps50 = WORKLOADS[args.workload]
+    if args.episodes_per_gpu > 0:
+        E = args.episodes_per_gpu
+    joint = args.net == "jmid"
+    dims = NetDims(ctx_dim=256)
+    weights = JMIDWeights.from_seed(dims, args.seed)
+    eng = JmidEngine(weights, joint=joint, device_id=local_rank, step=steps50)
+    eng.set_chunk_episodes(args.chunk)
+
+    # ---- synthetic scene batches, resident in HBM before the timed region
+    syn = synthetic_episodes(E, N, seed=args.seed * 1000 + rank, horizon=H)
+    A = N
+    x_st = torch.from_numpy(syn["x_st"].reshape(E * A, 6, 6)).to(dev)
+    nbr = torch.from_numpy(syn["nbr_sum"].reshape(E * A, 2, 6, 6)).to(dev)
+    emask = torch.from_numpy(syn["edge_mask"].reshape(E * A, 2)).to(dev)
+    p0 = torch.from_numpy(syn["p0"]).to(dev)
+    gt = torch.from_numpy(syn["gt"]).to(dev)
+    x_T_host = torch.stack([torch.randn([K * A, H, 2], generator=torch.Generator().manual_seed(
+        args.seed + rank * E + e)) for e in range(E)])
+    x_T = x_T_host.to(dev)
+
+    def one_step(e_slice=slice(None)):
+        ctx = eng.encode(x_st, nbr, emask)
+        vel, pos = eng.denoise(x_T, ctx.view(E, A, -1), p0, dt=0.25, precision=args.precision, want_vel=False)
+        met = eng.episode_metrics(pos, gt)
+        eng.synchronize()            # the library runs on its own stream
+        allm = gather_metrics(met, E * world)
+        return pos, met, allm
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log(f"inputs resident: E={E} A={A} K={K} H={H} precision={args.precision}")
+    for _ in range(args.warmup):
+        one_step()
+        log("warmup step done")
+    prof_classes = ["gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_tail", "attention"]
+    if not args.no_profile:
+        eng.profile_enable(prof_classes)
+        eng.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pos, met, allm = one_step()
+        log("timed step done")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    log(f"timed region: {elapsed:.3f}s")
+    prof = eng.profile_get() if not args.no_profile else {}
+    eng.profile_disable()
+    log("profile collected")
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    traj = world * E * A * K
+    value = traj * args.steps / elapsed
+    out = {
+        "metric": "sampled trajectories/sec (N x K, 50 denoise steps)",
+        "value": round(value, 2), "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": {"f32": "f32", "f16x3": "f32 (fp16x3 split-MFMA, fp32 accumulate)",
+                                       "f16": "f16"}[args.precision],
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {E} episodes/GPU x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
+                               f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
+                   "episodes_per_gpu": E, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
+                   "net": args.net, "precision": args.precision},
+    }
+    # ---- roofline of the dominant kernel class (HIP events on the library's stream, timed region only)
+    if prof:
+        fl = algorithmic_flops(dims, joint, E, A, K, H)
+        per = {}
+        for cls in prof_classes:
+            n, ms = prof[cls]
+            if n == 0:
+                continue
+            total_flops = fl[cls] * steps50 * args.steps        # all launches of the class in the timed region
+            per[cls] = {"launches": n, "avg_ms": ms / n, "total_ms": ms, "tflops": total_flops / (ms * 1e-3) / 1e12}
+        dom = max(per, key=lambda c: per[c]["total_ms"])
+        peak = PEAK_TFLOPS[args.precision]
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(per[dom]["tflops"], 2), "peak": peak,
+                           "unit": "TFLOP/s", "frac": round(per[dom]["tflops"] / peak, 4), "traffic": None,
+                           "mfma_passes_per_product": MFMA_PASSES[args.precision],
+                           "flops_per_launch": fl[dom] * steps50 * args.steps / per[dom]["launches"],
+                           "avg_launch_ms": round(per[dom]["avg_ms"], 4)}
+        out["kernels"] = {c: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
+                              "total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 2)}
+                          for c, v in per.items()}
+        out["kernel_time_fraction_of_step"] = round(sum(v["total_ms"] for v in per.values()) / (1e3 * elapsed), 4)
+    out["sweep_metrics"] = {"episodes": int(allm.shape[0]), "mean_ADE_m": float(np.nanmean(allm[:, 0])),
+                            "mean_minADE_m": float(np.nanmean(allm[:, 1])), "mean_FDE_m": float(np.nanmean(allm[:, 2])),
+                            "note": "random-init weights: displacement vs the constant-velocity future is not meaningful"}
+
+    # ---- single scene (BASELINE configs[1]) latency in the same run
+    if world == 1:
+        eng1 = eng
+        ctx1 = eng1.encode(x_st[:A], nbr[:A], emask[:A]).view(1, A, -1)
+        for _ in range(2):
+            eng1.denoise(x_T[:1], ctx1, p0[:1], dt=0.25, precision=args.precision, want_vel=False)
+        eng1.synchronize()
+        t1 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            c1 = eng1.encode(x_st[:A], nbr[:A], emask[:A]).view(1, A, -1)
+            eng1.denoise(x_T[:1], c1, p0[:1], dt=0.25, precision=args.precision, want_vel=False)
+        eng1.synchronize()
+        dt1 = (time.perf_counter() - t1) / reps
+        out["single_scene"] = {"workload": f"cfg2: 1 scene x N={N} x K={K} x H={H}, {steps50} steps",
+                               "ms_per_call": round(1e3 * dt1, 3), "traj_per_s": round(A * K / dt1, 1)}
+
+    log("single-scene done")
+    # ---- CPU baseline (the oracle, a port of the reference; bounded sample) + parity on the same episodes
+    if world == 1 and args.cpu_episodes > 0:
+        from oracle import jmid_oracle as O
+        ne = min(args.cpu_episodes, E)
+        wt = weights.tensors
+        # torch's default intra-op thread count (affinity / cgroup aware); os.cpu_count() can exceed the cores
+        # this process may actually use and oversubscription makes the oracle crawl
+        # calibrate the intra-op thread count on a 2-step run: more threads than the small GEMMs can use makes the
+        # CPU path slower, and the baseline should be the CPU's best
+        avail = len(os.sched_getaffinity(0))
+        best = (float("inf"), torch.get_num_threads())
+        with torch.no_grad():
+            ctx_cal = O.encode_context(wt, x_st[:A].cpu(), nbr[:A].cpu(), emask[:A].cpu())
+            for nt in (8, 16, 32, 64, 128, 256):
+                if nt > avail:
+                    break
+                torch.set_num_threads(nt)
+                O.denoise(wt, ctx_cal, x_T_host[0], sample=K, step=1, joint=joint)
+                tcal = time.perf_counter()
+                O.denoise(wt, ctx_cal, x_T_host[0], sample=K, step=2, joint=joint)
+                tcal = time.perf_counter() - tcal
+                log(f"cpu calibration: {nt} threads -> {tcal:.3f}s / 2 steps")
+                best = min(best, (tcal, nt))
+        cores = best[1]
+        torch.set_num_threads(cores)
+        log(f"cpu baseline on {cores} threads (os.cpu_count={os.cpu_count()}, affinity={avail})")
+        xs_c, nb_c, em_c = x_st[: ne * A].cpu(), nbr[: ne * A].cpu(), emask[: ne * A].cpu()
+        with torch.no_grad():
+            O.denoise(wt, O.encode_context(wt, xs_c[:A], nb_c[:A], em_c[:A]), x_T_host[0], sample=K, step=2,
+                      joint=joint)       # warm-up
+            tc = time.perf_counter()
+            pos_ref = []
+            for e in range(ne):
+                ctx_c = O.encode_context(wt, xs_c[e * A:(e + 1) * A], nb_c[e * A:(e + 1) * A], em_c[e * A:(e + 1) * A])
+                v = O.denoise(wt, ctx_c, x_T_host[e], sample=K, step=steps50, joint=joint)
+                pos_ref.append(O.integrate(v, p0[e].cpu(), 0.25))
+                log(f"cpu episode {e} done")
+            cpu_s = time.perf_counter() - tc
+        pos_ref = torch.stack(pos_ref).numpy()
+        ade = float(np.linalg.norm(pos[:ne].cpu().numpy() - pos_ref, axis=-1).mean())
+        out["cpu_baseline"] = {"value": round(ne * A * K / cpu_s, 2), "unit": "traj/s", "cores": torch.get_num_threads(),
+                               "kind": "port",
+                               "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, "
+                                         f"{cpu_s:.1f} s; oracle/jmid_oracle.py, torch-CPU fp32)"}
+        out["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4}
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,12 @@ int jmid_denoise(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, 
 int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, const float* x, const float* ctx,
                   int precision, float* e_out, int mem);
 
+/* Per-episode displacement metrics of the sampled futures for the multi-episode evaluation sweep (ADE / FDE as
+ * defined in MID/evaluation/evaluation.py:11-28; minimum taken jointly over the scene's agents):
+ *   pos [E, K, A, T, 2], gt [E, A, T, 2] -> out [E, 4] = {mean ADE, min-over-samples ADE, mean FDE, min FDE}. */
+int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const float* pos, const float* gt,
+                         float* out, int mem);
+
 /* ---- tuning / measurement ------------------------------------------------------------------ */
 /* Episodes processed together per pass of the 50-step loop (0 = automatic).  Smaller chunks keep the
  * activations of one pass resident in the 256 MiB Infinity Cache. */

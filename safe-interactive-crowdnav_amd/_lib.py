@@ -32,6 +32,8 @@ SIGNATURES = {
                                C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "jmid_net_eval": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                 C.c_int, C.c_void_p, C.c_int]),
+    "jmid_episode_metrics": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int]),
     "jmid_set_chunk_episodes": (C.c_int, [Handle, C.c_int]),
     "jmid_profile_enable": (C.c_int, [Handle, C.c_uint32]),
     "jmid_profile_reset": (C.c_int, [Handle]),

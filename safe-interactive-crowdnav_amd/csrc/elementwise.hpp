@@ -156,4 +156,59 @@ __global__ void integrate_kernel(const float* vel, const float* p0, float* pos, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ sweep metrics
+// Per-episode displacement metrics of the sampled futures against a ground-truth future (the per-element ADE/FDE
+// definition of MID/evaluation/evaluation.py:11-28, with the joint (scene-level) minimum over samples):
+//   out[e] = { mean ADE over (sample, agent, t),  min over samples of the agent-mean ADE,
+//              mean FDE over (sample, agent),     min over samples of the agent-mean FDE }
+// pos [E, K, A, T, 2], gt [E, A, T, 2].  One workgroup per episode, one wave per sample (strided).
+__global__ __launch_bounds__(256) void episode_metrics_kernel(const float* pos, const float* gt, float* out, int K, int A,
+                                                              int T) {
+    __shared__ float s_ade[256], s_fde[256];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    float sum_ade = 0.f, sum_fde = 0.f, min_ade = INFINITY, min_fde = INFINITY;
+    for (int s = tid; s < K; s += blockDim.x) {
+        float ade = 0.f, fde = 0.f;
+        for (int a = 0; a < A; ++a) {
+            const float* p = pos + (((size_t)e * K + s) * A + a) * T * 2;
+            const float* g = gt + ((size_t)e * A + a) * T * 2;
+            float acc = 0.f, last = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const float dx = p[2 * t] - g[2 * t], dy = p[2 * t + 1] - g[2 * t + 1];
+                last = sqrtf(dx * dx + dy * dy);
+                acc += last;
+            }
+            ade += acc / (float)T;
+            fde += last;
+        }
+        ade /= (float)A;
+        fde /= (float)A;
+        sum_ade += ade;
+        sum_fde += fde;
+        min_ade = fminf(min_ade, ade);
+        min_fde = fminf(min_fde, fde);
+    }
+    // block reductions (sum, min) through LDS
+    s_ade[tid] = sum_ade; s_fde[tid] = sum_fde;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_ade[tid] += s_ade[tid + o]; s_fde[tid] += s_fde[tid + o]; }
+        __syncthreads();
+    }
+    const float tot_ade = s_ade[0], tot_fde = s_fde[0];
+    __syncthreads();
+    s_ade[tid] = min_ade; s_fde[tid] = min_fde;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_ade[tid] = fminf(s_ade[tid], s_ade[tid + o]); s_fde[tid] = fminf(s_fde[tid], s_fde[tid + o]); }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[4 * e + 0] = tot_ade / (float)K;
+        out[4 * e + 1] = s_ade[0];
+        out[4 * e + 2] = tot_fde / (float)K;
+        out[4 * e + 3] = s_fde[0];
+    }
+}
+
 }  // namespace jmid

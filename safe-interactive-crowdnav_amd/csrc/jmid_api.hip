@@ -34,10 +34,12 @@ enum KClass {
     KC_HYPER,
     KC_ENCODER,
     KC_INTEGRATE,
+    KC_METRICS,
     KC_COUNT
 };
 const char* kClassNames[KC_COUNT] = {"gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_tail", "attention",
-                                     "add_layernorm", "embed", "out_ddim", "hyper", "encoder", "integrate"};
+                                     "add_layernorm", "embed", "out_ddim", "hyper", "encoder", "integrate",
+                                     "episode_metrics"};
 
 struct DevBuf {
     float* p = nullptr;
@@ -712,6 +714,37 @@ int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, con
     if (!e_out) return fail(h, JMID_EINVAL, "null e_out");
     if (step_idx < 0 || step_idx >= (int)h->beta.size()) return fail(h, JMID_EINVAL, "step_idx out of range");
     return run_network(h, E, A, K, T, x, ctx, nullptr, 0.f, precision, step_idx, nullptr, nullptr, e_out, mem);
+}
+
+int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const float* pos, const float* gt,
+                         float* out, int mem) {
+    if (!h || !pos || !gt || !out || E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t np_ = (size_t)E * K * A * T * 2, ng = (size_t)E * A * T * 2;
+    const float *dp = pos, *dg = gt;
+    float* dout = out;
+    if (mem == JMID_MEM_HOST) {
+        Carver c0(nullptr);
+        c0.take(np_); c0.take(ng); c0.take((size_t)E * 4);
+        if (int rc = ensure_arena(h, c0.off)) return rc;
+        Carver c(h->arena);
+        float* a = c.take(np_);
+        float* b = c.take(ng);
+        dout = c.take((size_t)E * 4);
+        HIPCHK(h, hipMemcpyAsync(a, pos, np_ * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(b, gt, ng * 4, hipMemcpyHostToDevice, h->stream));
+        dp = a; dg = b;
+    }
+    {
+        ProfScope ps(h, KC_METRICS);
+        hipLaunchKernelGGL(episode_metrics_kernel, dim3(E), dim3(256), 0, h->stream, dp, dg, dout, K, A, T);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (mem == JMID_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(out, dout, (size_t)E * 4 * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return JMID_OK;
 }
 
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {

@@ -169,6 +169,23 @@ class JmidEngine:
                                             _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return out
 
+    def episode_metrics(self, pos: ArrayLike, gt: ArrayLike) -> ArrayLike:
+        """pos [E,K,A,T,2], gt [E,A,T,2] -> [E,4] = (mean ADE, joint min ADE, mean FDE, joint min FDE)."""
+        dev = _is_cuda(pos)
+        E, K, A, T, _ = (int(v) for v in pos.shape)
+        if tuple(gt.shape) != (E, A, T, 2):
+            raise ValueError("gt must be [E, A, T, 2]")
+        bp, bg = _Buf(pos, dev), _Buf(gt, dev)
+        if dev:
+            out = torch.empty((E, 4), dtype=torch.float32, device=pos.device)
+            optr = C.c_void_p(out.data_ptr())
+        else:
+            out = np.empty((E, 4), dtype=np.float32)
+            optr = C.c_void_p(out.ctypes.data)
+        self._check(self._lib.jmid_episode_metrics(self._h, E, A, K, T, bp.ptr, bg.ptr, optr,
+                                                   _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        return out
+
     # ------------------------------------------------------------------ measurement
     def kernel_classes(self):
         return [self._lib.jmid_kernel_class_name(i).decode() for i in range(self._lib.jmid_kernel_class_count())]

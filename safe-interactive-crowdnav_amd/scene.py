@@ -1,0 +1,236 @@
+"""Host-side batch builder: agent histories -> the arrays the device encoder consumes.
+
+A NumPy restatement (no pandas, no Scene/Node objects) of what the reference does between
+``update_state_hists`` and ``Trajectron.get_latent``:
+
+  * history frame table, resampling to the ``time_step`` grid from the last stamp backwards, keep-last per
+    bin, linear interpolation of empty bins      (``JMID/mid_sim_wrapper.py:244-310``)
+  * cluster selection around the human nearest the robot, constant-velocity forecasts for everybody else
+                                                 (``mid_sim_wrapper.py:313-437``)
+  * per-node state [pos, vel, acc] by first differences   (``MID/environment/data_utils.py:24-37``)
+  * standardisation, neighbour sets, edge scaling (``MID/dataset/preprocessing.py:428-620``,
+    ``MID/environment/scene_graph.py:111-250, 280-313``)
+  * the reductions the encoder applies before its LSTMs: per edge type the SUM of neighbour histories and
+    clamp(sum(edge values), 1)                    (``MID/models/encoders/mgcvae.py:726-768``)
+
+All arithmetic is float64 until the final cast to float32, as in the reference
+(``preprocessing.py:495-499``: ``torch.tensor(..., dtype=torch.float)``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+ATTENTION_RADIUS = 3.0                       # mid_sim_wrapper.py:234-238
+STATE_STD = np.array([3.0, 3.0, 2.0, 2.0, 1.0, 1.0])   # pos std overridden by the attention radius
+                                                        # (mid_sim_wrapper.py:219-231, preprocessing.py:477-478)
+EDGE_ADDITION_FILTER = (0.25, 0.5, 0.75, 1.0)           # trajectron_hypers.py:83
+EDGE_REMOVAL_FILTER = (1.0, 0.0)                        # trajectron_hypers.py:84
+TYPE_VALUE_PED, TYPE_VALUE_ROBOT = 1, 2                 # NodeType enum values (environment/node_type.py)
+ROBOT_ID = -1
+
+
+class HistoryTooShortError(TypeError):
+    """Fewer resampled frames than ``past_num_frames``.  The reference fails in the same situation
+    (``get_timesteps_data`` returns None -> ``TypeError`` at MID/mid.py:326); callers catch and re-raise
+    (``sicnav_diffusion/policy/sicnav_acados.py:1176-1180``)."""
+
+
+def derivative_of(x: np.ndarray, dt: float) -> np.ndarray:
+    """data_utils.py:24-37 for NaN-free input: first difference, first element duplicated."""
+    if x.shape[-1] < 2:
+        return np.zeros_like(x)
+    return np.ediff1d(x, to_begin=(x[1] - x[0])) / dt
+
+
+# --------------------------------------------------------------------------------------------- history table
+def frame_table(prev_states: Sequence[Sequence[Sequence[float]]], prev_robot_states: Sequence[Sequence[float]],
+                time_step: float, num_hist_frames: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """mid_sim_wrapper.py:244-298.
+
+    prev_states: per human a list of [x, y, t]; prev_robot_states: list of [x, y, t].
+    Returns (human_xy [F, N, 2], robot_xy [F, 2], pose_now [N, 2]) with F <= num_hist_frames resampled frames.
+    """
+    N = len(prev_states)
+    h0 = np.asarray(prev_states[0], dtype=np.float64).reshape(-1, 3)
+    times = h0[:, 2]
+    table = np.full((len(times), 2 * N + 2), np.nan)
+    table[:, 0:2] = h0[:, 0:2]
+    for i in range(1, N):                       # left-join on exactly equal stamps
+        hi = np.asarray(prev_states[i], dtype=np.float64).reshape(-1, 3)
+        lut = {t: k for k, t in enumerate(hi[:, 2])}
+        for r, t in enumerate(times):
+            k = lut.get(t)
+            if k is not None:
+                table[r, 2 * i:2 * i + 2] = hi[k, 0:2]
+    pose_now = table[-1, :2 * N].reshape(N, 2).copy()      # agent_df.tail(1), before the robot join
+    rob = np.asarray(prev_robot_states, dtype=np.float64).reshape(-1, 3)
+    lut = {t: k for k, t in enumerate(rob[:, 2])}
+    for r, t in enumerate(times):
+        k = lut.get(t)
+        if k is not None:
+            table[r, 2 * N:2 * N + 2] = rob[k, 0:2]
+    keep = ~np.isnan(table).any(axis=1)         # dropna
+    table, times = table[keep], times[keep]
+    order = np.argsort(times, kind="stable")
+    table, times = table[order], times[order]
+    if len(times) == 0:
+        raise HistoryTooShortError("no complete history frame")
+    # subsample_df: stamps*100 -> integer nanoseconds (truncation), bins of round(time_step*100) ns anchored at
+    # the LAST stamp, right-closed; keep the last row per bin; interpolate empty bins linearly
+    ns = np.trunc(times * 100.0).astype(np.int64)
+    w = int(round(time_step * 100))
+    k = (ns[-1] - ns) // w                      # bin index counted backwards from the end
+    nb = int(k.max()) + 1
+    out = np.full((nb, table.shape[1]), np.nan)
+    for r in range(len(times)):                 # ascending time: later rows overwrite -> "last"
+        out[nb - 1 - int(k[r])] = table[r]
+    idx = np.arange(nb)
+    good = ~np.isnan(out[:, 0])
+    if not good.all():
+        for c in range(out.shape[1]):
+            out[:, c] = np.interp(idx, idx[good], out[good, c])
+    out = out[-num_hist_frames:]
+    human_xy = out[:, :2 * N].reshape(-1, N, 2)
+    robot_xy = out[:, 2 * N:2 * N + 2]
+    return human_xy, robot_xy, pose_now
+
+
+# --------------------------------------------------------------------------------------------- scene batch
+@dataclass
+class SceneBatch:
+    ids_in: np.ndarray               # pedestrian track ids inside the chosen cluster, ascending == batch row order
+    ids_out: np.ndarray              # pedestrian track ids outside the cluster (constant-velocity fill)
+    x: np.ndarray                    # [A, F, 6] f32 raw state  [px, py, vx, vy, ax, ay]
+    x_st: np.ndarray                 # [A, F, 6] f32 standardized
+    nbr_sum: np.ndarray              # [A, 2, F, 6] f32   edge types (PED->PED, PED->ROBOT)
+    edge_mask: np.ndarray            # [A, 2] f32
+    p0: np.ndarray                   # [A, 2] f32 current positions (integrator initial condition)
+    cv_forecasts: Dict[int, np.ndarray] = field(default_factory=dict)   # id -> [H, 2] f64
+    pose_now: Optional[np.ndarray] = None                               # [N, 2] f64
+    robot_in_cluster: bool = False
+
+
+def edge_scaling_last(adj3: np.ndarray) -> np.ndarray:
+    """scene_graph.py:203-225 evaluated at the last of 3 frames.  adj3 [3, n, n] (type-valued adjacency).
+    conv with the addition filter, clamp 1, zero where not adjacent now; the removal filter [1, 0] is the
+    identity at this frame."""
+    f = EDGE_ADDITION_FILTER
+    s = np.minimum(f[0] * adj3[2] + f[1] * adj3[1] + f[2] * adj3[0], 1.0)
+    s = np.where(adj3[2] == 0, 0.0, s)
+    return np.minimum(s, 1.0)
+
+
+def build_scene(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float, horizon: int,
+                num_hist_frames: int = 6, force_all_in_cluster: bool = False) -> SceneBatch:
+    """mid_sim_wrapper.py:313-437 + preprocessing.py:428-694 for one scene.
+
+    human_xy [F, N, 2], robot_xy [F, 2] on the ``time_step`` grid (oldest first).
+    """
+    F, N, _ = human_xy.shape
+    if F < num_hist_frames:
+        raise HistoryTooShortError(f"{F} history frames available, {num_hist_frames} needed")
+    dt = time_step
+    # positions at the last frame, sorted by track id: robot (-1) first
+    pos_last = np.concatenate([robot_xy[-1:], human_xy[-1]], axis=0)           # [N+1, 2]
+    track_ids = np.concatenate([[ROBOT_ID], np.arange(N)])
+    sq = np.square(pos_last[:, None] - pos_last[None, :])
+    dists = np.sqrt(np.sum(sq, axis=2))
+    mask = dists < ATTENTION_RADIUS
+    if force_all_in_cluster:
+        in_mask = np.ones(N + 1, dtype=bool)
+    else:
+        cluster_means = (mask @ pos_last) / mask.sum(axis=1, keepdims=True)
+        robot_dist = np.linalg.norm(cluster_means - pos_last[0], axis=1)
+        chosen = int(np.argmin(robot_dist[1:])) + 1
+        in_mask = mask[chosen]
+    ids_in_all = track_ids[in_mask]
+    ids_out_all = track_ids[~in_mask]
+
+    def node_state(xy):                                                        # [F, 2] -> [F, 6]
+        vx, vy = derivative_of(xy[:, 0], dt), derivative_of(xy[:, 1], dt)
+        ax, ay = derivative_of(vx, dt), derivative_of(vy, dt)
+        return np.stack([xy[:, 0], xy[:, 1], vx, vy, ax, ay], axis=1)
+
+    # scene nodes in track-id order (robot first when it is in the cluster)
+    node_ids = list(ids_in_all)
+    states = [node_state(robot_xy if i == ROBOT_ID else human_xy[:, i]) for i in node_ids]
+    types = np.array([TYPE_VALUE_ROBOT if i == ROBOT_ID else TYPE_VALUE_PED for i in node_ids])
+    n = len(node_ids)
+    S = np.stack(states, axis=0) if n else np.zeros((0, F, 6))                 # [n, F, 6]
+
+    # constant-velocity forecasts for pedestrians outside the cluster (mid_sim_wrapper.py:413-429)
+    cv = {}
+    for i in ids_out_all:
+        if i == ROBOT_ID:
+            continue
+        xy = human_xy[:, i]
+        vx, vy = derivative_of(xy[:, 0], dt), derivative_of(xy[:, 1], dt)
+        fc = np.zeros((horizon, 2))
+        fc[:, 0] = xy[-1, 0] + np.cumsum(np.tile(vx[-1] * dt, horizon))
+        fc[:, 1] = xy[-1, 1] + np.cumsum(np.tile(vy[-1] * dt, horizon))
+        cv[int(i)] = fc
+
+    # temporal scene graph over the last 3 frames (scene.py:67-110, scene_graph.py:111-201)
+    P3 = S[:, F - 3:F, 0:2].transpose(1, 0, 2)                                 # [3, n, 2]
+    d3 = np.sqrt(np.square(P3[:, :, None] - P3[:, None, :]).sum(-1))           # [3, n, n]
+    type_mat = np.tile(types[None, :], (n, 1)).astype(np.float64)
+    np.fill_diagonal(type_mat, 0)
+    adj3 = (d3 <= ATTENTION_RADIUS).astype(np.float64) * type_mat[None]
+    for t in range(3):
+        np.fill_diagonal(adj3[t], 0)
+    scaling = edge_scaling_last(adj3)                                          # [n, n]
+    connected = scaling > 1e-2
+
+    ped_rows = [k for k, i in enumerate(node_ids) if i != ROBOT_ID]
+    A = len(ped_rows)
+    x = np.zeros((A, F, 6))
+    x_st = np.zeros((A, F, 6))
+    nbr_sum = np.zeros((A, 2, F, 6), dtype=np.float32)
+    edge_mask = np.zeros((A, 2), dtype=np.float32)
+    for r, k in enumerate(ped_rows):
+        xs = S[k]
+        x[r] = xs
+        rel = np.zeros(6)
+        rel[0:2] = xs[-1, 0:2]
+        x_st[r] = (xs - rel) / STATE_STD
+        # edge values are NOT filtered by edge type (scene_graph.py:293-299): both types see the same sum
+        ev = scaling[k, connected[k]].astype(np.float32)
+        em = np.float32(min(float(ev.sum(dtype=np.float32)), 1.0)) if ev.size else np.float32(0.0)
+        edge_mask[r, :] = em
+        for e, tv in enumerate((TYPE_VALUE_PED, TYPE_VALUE_ROBOT)):
+            acc = np.zeros((F, 6), dtype=np.float32)
+            for j in np.nonzero(connected[k] & (type_mat[k] == tv))[0]:
+                # neighbour state relative to the ego's WHOLE present state (preprocessing.py:531-550)
+                acc = acc + ((S[j] - xs[-1][None, :]) / STATE_STD).astype(np.float32)
+            nbr_sum[r, e] = acc
+    ids_in = np.array([i for i in node_ids if i != ROBOT_ID], dtype=np.int64)
+    ids_out = np.array([i for i in ids_out_all if i != ROBOT_ID], dtype=np.int64)
+    return SceneBatch(ids_in=ids_in, ids_out=ids_out, x=x.astype(np.float32), x_st=x_st.astype(np.float32),
+                      nbr_sum=nbr_sum, edge_mask=edge_mask, p0=x[:, -1, 0:2].astype(np.float32),
+                      cv_forecasts=cv, robot_in_cluster=bool(in_mask[0]))
+
+
+# --------------------------------------------------------------------------------------------- synthetic feeds
+def synthetic_episodes(E: int, N: int, seed: int, time_step: float = 0.25, num_hist_frames: int = 6,
+                       horizon: int = 12) -> Dict[str, np.ndarray]:
+    """Synthetic scene batches for measurement: per episode pos0 ~ U(-2,2)^2,
+    vel ~ U(-0.5,0.5)^2 m/s, 7 frames at dt (6 kept), robot at (0,-3) + 0.2 t y; all agents forced into the
+    cluster (A = N).  Returns stacked encoder inputs and the constant-velocity ground truth."""
+    rng = np.random.default_rng(seed)
+    xs, xst, nb, em, p0, gt = [], [], [], [], [], []
+    for _ in range(E):
+        pos0 = rng.uniform(-2.0, 2.0, (N, 2))
+        vel = rng.uniform(-0.5, 0.5, (N, 2))
+        t = np.arange(num_hist_frames + 1) * time_step
+        hum = pos0[None] + vel[None] * t[:, None, None]
+        rob = np.array([0.0, -3.0])[None] + np.array([0.0, 0.2])[None] * t[:, None]
+        sb = build_scene(hum[-num_hist_frames:], rob[-num_hist_frames:], time_step, horizon, num_hist_frames,
+                         force_all_in_cluster=True)
+        xs.append(sb.x); xst.append(sb.x_st); nb.append(sb.nbr_sum); em.append(sb.edge_mask); p0.append(sb.p0)
+        steps = (np.arange(horizon) + 1)[None, :, None] * time_step
+        gt.append((hum[-1][:, None, :] + vel[:, None, :] * steps).astype(np.float32))
+    return dict(x=np.stack(xs), x_st=np.stack(xst), nbr_sum=np.stack(nb), edge_mask=np.stack(em),
+                p0=np.stack(p0), gt=np.stack(gt))

@@ -1,0 +1,74 @@
+"""Host-side logic that needs no GPU: KDE top-k, weight container round trip, DDIM step table."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from safe_interactive_crowdnav_amd.kde import most_likely_samples
+from safe_interactive_crowdnav_amd.schedule import VarianceSchedule, ddim_steps
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims, all_shapes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "kde_*.npz"))))
+def test_kde_topk_matches_reference(case):
+    z = np.load(os.path.join(GOLDEN, case))
+    top, lw = most_likely_samples(z["forecasts"], int(z["k_ret"]))
+    np.testing.assert_array_equal(top, z["top"])
+    np.testing.assert_allclose(lw, z["logw"], rtol=1e-5, atol=1e-5)
+
+
+def test_schedule_matches_reference_buffers():
+    z = np.load(os.path.join(GOLDEN, "schedule.npz"))
+    s = VarianceSchedule.linear()
+    np.testing.assert_array_equal(s.betas, z["betas"])
+    np.testing.assert_array_equal(s.alpha_bars, z["alpha_bars"])
+
+
+def test_ddim_table():
+    s = VarianceSchedule.linear()
+    tab = ddim_steps(s, 50)
+    assert [x.t for x in tab] == list(range(100, 0, -2))
+    assert tab[-1].n_x == np.float32(1.0) and tab[-1].n_e == np.float32(0.0)   # abar_0 = 1: last step returns x0
+    assert [x.t for x in ddim_steps(s, 2)] == [100, 50]
+    with pytest.raises(ValueError):
+        ddim_steps(s, 30)   # stride 3 does not divide 100 (reference would wrap around)
+
+
+def test_weight_container_roundtrip(tmp_path):
+    dims = NetDims(ctx_dim=32)
+    w = JMIDWeights.from_seed(dims, 3)
+    assert list(w.tensors) == list(all_shapes(dims))
+    assert w.checksum() == JMIDWeights.from_seed(dims, 3).checksum() != JMIDWeights.from_seed(dims, 4).checksum()
+    p = str(tmp_path / "w.npz")
+    w.save(p)
+    w2 = JMIDWeights.load(p)
+    assert w2.dims == dims and w2.checksum() == w.checksum()
+    n_live = sum(int(np.prod(s)) for k, s in all_shapes(NetDims()).items() if "/" not in k)
+    assert n_live == 6_940_432    # live parameter count of the net
+    with pytest.raises(KeyError):
+        JMIDWeights(dims, {})
+
+
+def test_reference_state_import():
+    """from_reference_state accepts the checkpoint's own key layout (vel_predictor.net.* + ModuleDict)."""
+    dims = NetDims(ctx_dim=32)
+    w = JMIDWeights.from_seed(dims, 1)
+    net_state = {"vel_predictor.net." + k: v for k, v in w.net_state_dict().items()}
+    net_state["vel_predictor.net.layer.linear1.weight"] = torch.zeros(1)   # the unused template copy is ignored
+    mods = {}
+    for name, sd in w.encoder_state_dicts().items():
+        if "edge_influence" in name:
+            m = torch.nn.Module()
+            m.w1 = torch.nn.Linear(16, 16, bias=False)
+            m.w2 = torch.nn.Linear(16, 16, bias=False)
+            m.v = torch.nn.Linear(16, 1, bias=False)
+        else:
+            m = torch.nn.LSTM(sd["weight_ih_l0"].shape[1], 16, batch_first=True)
+        m.load_state_dict(sd)
+        mods[name] = m
+    w2 = JMIDWeights.from_reference_state(dims, net_state, mods)
+    assert w2.checksum() == w.checksum()
