@@ -1,0 +1,223 @@
+// Flash attention with fp32-class accuracy on the fp16 matrix cores (hi/lo split operands, see gemm_f16x3.hpp).
+//
+// Same transposed formulation as attn_f32.hpp (a lane owns one query row, softmax state is lane-local):
+//   S^T = K . Q^T      3 MFMAs per 16-deep step:  Khi.Qhi  (+ 2^-11 (Khi.Qlo + Klo.Qhi))
+//   O^T = V^T . P^T    P is split to hi/lo in registers straight from the S^T accumulators; V^T comes
+//                      key-contiguous from the QKV GEMM epilogue, so no transpose is needed on the way in.
+// The 2^-11-weighted correction terms go to a scratch accumulator that is folded into the fp32 state once per
+// key tile, which keeps the register cost of the split at 16 VGPRs instead of doubling the O accumulator.
+//
+// Inputs : Qhi/Qlo, Khi/Klo [nseq*S, d] planes;  Vthi/Vtlo [nseq][nhead][hd][Spad] planes.
+// Output : hi/lo planes [nseq*S, d] (operand of the attention out-projection GEMM).
+#pragma once
+#include "common.hpp"
+#include "gemm_f16x3.hpp"
+
+namespace jmid {
+
+struct AttnHArgs {
+    const half_t *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;
+    half_t *Ohi, *Olo;
+    int S, Spad, d, nhead;
+    float scale;
+    int* range_flag;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
+    constexpr int KT = 32;                    // keys per tile
+    constexpr int KLD = HD + 8;               // halfs per K row in LDS (row = 2*HD + 16 bytes)
+    constexpr int VLD = KT + 4;               // halfs per V^T row in LDS (72 bytes)
+    constexpr int NT = (HD + 31) / 32;        // 32-wide tiles of the head dim in O^T
+    constexpr int NKS = HD / 16;              // 16-deep steps of the QK^T contraction
+    constexpr int VROWS = NT * 32;
+    __shared__ __attribute__((aligned(16))) half_t Ksh[KT * KLD], Ksl[KT * KLD];
+    __shared__ __attribute__((aligned(16))) half_t Vsh[VROWS * VLD], Vsl[VROWS * VLD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y, seq = blockIdx.z;
+    const int S = a.S, d = a.d;
+    const size_t tok0 = (size_t)seq * S;
+    const int q = (blockIdx.x * 4 + wid) * 32 + l31;
+    const int qc = q < S ? q : S - 1;
+
+    // Q fragments (B operand of S^T): 8 consecutive d per lane and step; the softmax scale is applied to the
+    // fp32 scores, not to the fp16 operands
+    f16x8 qh[NKS], ql[NKS];
+    {
+        const size_t o = (tok0 + qc) * d + h * HD + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qh[ks] = *reinterpret_cast<const f16x8*>(a.Qhi + o + 16 * ks);
+            ql[ks] = *reinterpret_cast<const f16x8*>(a.Qlo + o + 16 * ks);
+        }
+    }
+    f32x16 ot[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // zero the padding rows of the V^T tile once (HD < 32)
+    if (HD % 32 != 0) {
+        for (int i = tid; i < VROWS * VLD; i += 256) {
+            Vsh[i] = (half_t)0.f;
+            Vsl[i] = (half_t)0.f;
+        }
+    }
+    const half_t* kh_g = a.Khi + tok0 * d + h * HD;
+    const half_t* kl_g = a.Klo + tok0 * d + h * HD;
+    const size_t vt0 = ((size_t)seq * a.nhead + h) * HD * a.Spad;
+    constexpr int KCH = HD / 8;               // 16-byte chunks per K row
+    const int ntiles = (S + KT - 1) / KT;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                      // previous tile fully consumed (also orders the padding zero-fill)
+        // ---- stage K tile [KT][HD] (rows past S zero-filled)
+        for (int idx = tid; idx < KT * KCH; idx += 256) {
+            const int row = idx / KCH, c = idx % KCH;
+            const int key = kt * KT + row;
+            f16x8 vh = {0, 0, 0, 0, 0, 0, 0, 0}, vl = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (key < S) {
+                vh = *reinterpret_cast<const f16x8*>(kh_g + (size_t)key * d + c * 8);
+                vl = *reinterpret_cast<const f16x8*>(kl_g + (size_t)key * d + c * 8);
+            }
+            *reinterpret_cast<f16x8*>(&Ksh[row * KLD + c * 8]) = vh;
+            *reinterpret_cast<f16x8*>(&Ksl[row * KLD + c * 8]) = vl;
+        }
+        // ---- stage V^T tile [HD][KT]: 8-byte pieces (4 keys); keys past Spad zero-filled
+        for (int idx = tid; idx < HD * (KT / 4); idx += 256) {
+            const int row = idx / (KT / 4), c = idx % (KT / 4);
+            const int key = kt * KT + c * 4;
+            f16x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+            if (key < a.Spad) {
+                vh = *reinterpret_cast<const f16x4*>(a.Vthi + vt0 + (size_t)row * a.Spad + key);
+                vl = *reinterpret_cast<const f16x4*>(a.Vtlo + vt0 + (size_t)row * a.Spad + key);
+            }
+            *reinterpret_cast<f16x4*>(&Vsh[row * VLD + c * 4]) = vh;
+            *reinterpret_cast<f16x4*>(&Vsl[row * VLD + c * 4]) = vl;
+        }
+        __syncthreads();
+
+        // ---- S^T = K . Q^T  (rows = keys, cols = queries)
+        f32x16 sm, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sm[r] = 0.f;
+            sc[r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(&Ksh[l31 * KLD + 16 * ks + 8 * hi]);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(&Ksl[l31 * KLD + 16 * ks + 8 * hi]);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+        }
+        // ---- online softmax (fp32) over the 32 keys of this tile
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = (sm[r] + sc[r] * kLoInv) * a.scale;
+            const int key = kt * KT + frag_row(r, hi);
+            s = key < S ? s : -INFINITY;
+            sm[r] = s;
+            tmax = fmaxf(tmax, s);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sm[r] = expf(sm[r] - m_new);
+            psum += sm[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // P fragments (B operand of O^T): register r = 8*mf + j holds key frag_row(r, hi)
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half_t hh, ll;
+                split_f32(sm[8 * mf + j], hh, ll);
+                ph[mf][j] = hh;
+                pl[mf][j] = ll;
+            }
+        // ---- O^T = alpha * O^T + V^T . P^T
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x16 tc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ot[n][r] *= alpha;
+                tc[r] = 0.f;
+            }
+            const int vrow = n * 32 + l31;
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                // keys of this lane-half for MFMA mf: {16mf + 4hi + 0..3, 16mf + 8 + 4hi + 0..3}
+                const int c0 = vrow * VLD + 16 * mf + 4 * hi;
+                const f16x4 vh0 = *reinterpret_cast<const f16x4*>(&Vsh[c0]);
+                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(&Vsh[c0 + 8]);
+                const f16x4 vl0 = *reinterpret_cast<const f16x4*>(&Vsl[c0]);
+                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(&Vsl[c0 + 8]);
+                const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+                const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
+                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], tc, 0, 0, 0);
+                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], tc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[n][r] += tc[r] * kLoInv;
+        }
+    }
+
+    // ---- normalise, split and store: register r of tile n is head-dim n*32 + frag_row(r, hi)
+    if (q < S) {
+        const float inv = 1.0f / l_run;
+        const size_t o = (tok0 + q) * d + h * HD;
+        bool overflow = false;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c0 = n * 32 + 8 * r4 + 4 * hi;
+                if (HD % 32 == 0 || c0 < HD) {
+                    f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = ot[n][4 * r4 + e] * inv;
+                        half_t hh, ll;
+                        split_f32(v, hh, ll);
+                        overflow |= !(fabsf(v) <= kHalfMax);
+                        vh[e] = hh;
+                        vl[e] = ll;
+                    }
+                    *reinterpret_cast<f16x4*>(a.Ohi + o + c0) = vh;
+                    *reinterpret_cast<f16x4*>(a.Olo + o + c0) = vl;
+                }
+            }
+        }
+        if (overflow) atomicOr(a.range_flag, 1);
+    }
+}
+
+inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, hipStream_t st) {
+    dim3 grid((a.S + 127) / 128, a.nhead, nseq);
+    switch (head_dim) {
+        case 16: hipLaunchKernelGGL((attn_f16x3_kernel<16>), grid, dim3(256), 0, st, a); break;
+        case 32: hipLaunchKernelGGL((attn_f16x3_kernel<32>), grid, dim3(256), 0, st, a); break;
+        case 64: hipLaunchKernelGGL((attn_f16x3_kernel<64>), grid, dim3(256), 0, st, a); break;
+        case 128: hipLaunchKernelGGL((attn_f16x3_kernel<128>), grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace jmid

@@ -14,6 +14,7 @@
 // takes keys {k0, k0+4} straight from the registers - no cross-lane shuffle of P at all.
 #pragma once
 #include "common.hpp"
+#include "gemm_f16x3.hpp"
 
 namespace jmid {
 
@@ -22,6 +23,8 @@ struct AttnArgs {
     float* OUT;        // [nseq*S, d]
     int S, d, nhead;
     float scale;       // 1/sqrt(head_dim)
+    half_t* Ohi;       // optional: write hi/lo planes [nseq*S, d] instead of OUT (split-fp16 pipeline, iMID)
+    half_t* Olo;
 };
 
 template <int HD, int NWAVES>
@@ -146,7 +149,21 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_f32_kernel(AttnArgs a) {
                 if (HD % 32 == 0 || c0 < HD) {
                     f32x4 v = {ot[n][4 * r4 + 0] * inv, ot[n][4 * r4 + 1] * inv, ot[n][4 * r4 + 2] * inv,
                                ot[n][4 * r4 + 3] * inv};
-                    *reinterpret_cast<f32x4*>(op + c0) = v;
+                    if (a.Ohi) {
+                        f16x4 vh, vl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            half_t hh, ll;
+                            split_f32(v[e], hh, ll);
+                            vh[e] = hh;
+                            vl[e] = ll;
+                        }
+                        const size_t oo = ((size_t)seq * S + q) * d + h * HD + c0;
+                        *reinterpret_cast<f16x4*>(a.Ohi + oo) = vh;
+                        *reinterpret_cast<f16x4*>(a.Olo + oo) = vl;
+                    } else {
+                        *reinterpret_cast<f32x4*>(op + c0) = v;
+                    }
                 }
             }
         }

@@ -5,6 +5,7 @@
 //   integrate    SingleIntegrator.integrate_samples                            single_integrator.py:290-321
 #pragma once
 #include "common.hpp"
+#include "gemm_f16x3.hpp"
 
 namespace jmid {
 
@@ -19,6 +20,8 @@ struct EmbedArgs {
     float* X;            // [M, d]
     int M, d, hyp_ld, goff, boff;
     RowMap rmap;
+    half_t* Xh;          // optional hi/lo planes of X for the split-fp16 GEMMs (nullptr: not written)
+    half_t* Xl;
 };
 
 // one thread per (token, 4 channels)
@@ -40,6 +43,18 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
             o[e] = lin * gate + bias + a.pe[(size_t)t * a.d + c];
         }
         *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
+        if (a.Xh) {
+            f16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                half_t hh, ll;
+                split_f32(o[e], hh, ll);
+                vh[e] = hh;
+                vl[e] = ll;
+            }
+            *reinterpret_cast<f16x4*>(a.Xh + (size_t)m * a.d + j) = vh;
+            *reinterpret_cast<f16x4*>(a.Xl + (size_t)m * a.d + j) = vl;
+        }
     }
 }
 
@@ -47,7 +62,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 // X[m,:] = LN(X[m,:] + Y[m,:]) * gamma + beta ; one wave per row, d <= 64*4*VPL
 template <int VPL>  // float4 vectors per lane
 __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, const float* gamma, const float* beta,
-                                                     int M, int d, float eps) {
+                                                     int M, int d, float eps, half_t* Xh, half_t* Xl) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -91,6 +106,18 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
             *reinterpret_cast<f32x4*>(xr + c) = o;
+            if (Xh) {
+                f16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    half_t hh, ll;
+                    split_f32(o[e], hh, ll);
+                    vh[e] = hh;
+                    vl[e] = ll;
+                }
+                *reinterpret_cast<f16x4*>(Xh + (size_t)row * d + c) = vh;
+                *reinterpret_cast<f16x4*>(Xl + (size_t)row * d + c) = vl;
+            }
         }
     }
 }

@@ -11,10 +11,12 @@
 #include <string>
 #include <vector>
 
+#include "attn_f16x3.hpp"
 #include "attn_f32.hpp"
 #include "common.hpp"
 #include "elementwise.hpp"
 #include "encoder.hpp"
+#include "gemm_f16x3.hpp"
 #include "gemm_f32.hpp"
 
 using namespace jmid;
@@ -50,6 +52,11 @@ struct EvPair {
     hipEvent_t a, b;
 };
 
+struct HalfPair {
+    half_t* hi = nullptr;
+    half_t* lo = nullptr;
+};
+
 }  // namespace
 
 struct jmid_ctx {
@@ -60,6 +67,9 @@ struct jmid_ctx {
     HyperLayout hl;
     std::map<std::string, std::vector<size_t>> expected;  // name -> shape
     std::map<std::string, DevBuf> w;
+    std::map<std::string, HalfPair> wsplit;  // hi/lo fp16 planes of the GEMM weights (F16X3 path)
+    int* range_flag = nullptr;               // device word: an fp16 operand left the fp16 range
+    bool weights_in_half_range = true;
     bool finalized = false;
     // derived device buffers
     float* pe = nullptr;
@@ -248,16 +258,26 @@ int run_gemm(jmid_ctx* h, int cls, GemmArgs& g) {
     return 0;
 }
 
-int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const float* bt, int M, int d) {
+template <int EPI, int OUT>
+int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
+    if (g.K % GEMMH_BK != 0) return fail(h, JMID_EINVAL, "GEMM K must be a multiple of 32");
+    g.range_flag = h->range_flag;
+    ProfScope ps(h, cls);
+    HIPCHK(h, (launch_gemm_h<EPI, OUT>(g, h->stream)));
+    return 0;
+}
+
+int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const float* bt, int M, int d,
+               half_t* Xh = nullptr, half_t* Xl = nullptr) {
     ProfScope ps(h, KC_ADD_LN);
     const int rows_per_block = 4;
     dim3 grid((M + rows_per_block - 1) / rows_per_block);
     const int vpl = (d + 255) / 256;
     switch (vpl) {
-        case 1: hipLaunchKernelGGL(add_ln_kernel<1>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f); break;
-        case 2: hipLaunchKernelGGL(add_ln_kernel<2>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f); break;
+        case 1: hipLaunchKernelGGL(add_ln_kernel<1>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); break;
+        case 2: hipLaunchKernelGGL(add_ln_kernel<2>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); break;
         case 3:
-        case 4: hipLaunchKernelGGL(add_ln_kernel<4>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f); break;
+        case 4: hipLaunchKernelGGL(add_ln_kernel<4>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); break;
         default: return fail(h, JMID_EINVAL, "d_model too large for add_ln");
     }
     HIPCHK(h, hipGetLastError());
@@ -266,25 +286,65 @@ int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const flo
 
 struct StepBuffers {
     float *X, *QKV, *ATT, *Y, *H1, *Y3, *Y4;
+    // F16X3 path: hi/lo planes
+    half_t *Xh, *Xl, *Qh, *Ql, *Kh, *Kl, *Vth, *Vtl, *Ah, *Al, *H1h, *H1l, *Y3h, *Y3l;
+    size_t vt_elems;
 };
 
-size_t step_ws_floats(const jmid_ctx* h, size_t Mc, StepBuffers* sb, char* base) {
+half_t* take_half(Carver& c, size_t n) { return reinterpret_cast<half_t*>(c.take((n + 1) / 2)); }
+
+// attention geometry of a chunk
+struct SeqGeom {
+    int nseq, S, Spad;
+};
+SeqGeom seq_geom(const jmid_ctx* h, int Ec, int A, int K, int T) {
+    SeqGeom g;
+    g.nseq = h->net_kind == JMID_NET_JMID ? Ec : Ec * K * A;
+    g.S = h->net_kind == JMID_NET_JMID ? K * A * T : T;
+    g.Spad = (g.S + 7) / 8 * 8;
+    return g;
+}
+
+size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom& sg, StepBuffers* sb, char* base) {
     Carver c(base);
-    StepBuffers s;
+    StepBuffers s{};
     s.X = c.take(Mc * h->d);
-    s.QKV = c.take(Mc * 3 * h->d);
-    s.ATT = c.take(Mc * h->d);
     s.Y = c.take(Mc * h->d);
-    s.H1 = c.take(Mc * h->ff);
-    s.Y3 = c.take(Mc * h->dmid);
     s.Y4 = c.take(Mc * h->dlow);
+    if (precision == JMID_PREC_F32) {
+        s.QKV = c.take(Mc * 3 * h->d);
+        s.ATT = c.take(Mc * h->d);
+        s.H1 = c.take(Mc * h->ff);
+        s.Y3 = c.take(Mc * h->dmid);
+    } else {
+        s.Xh = take_half(c, Mc * h->d);
+        s.Xl = take_half(c, Mc * h->d);
+        if (h->net_kind == JMID_NET_JMID) {
+            s.Qh = take_half(c, Mc * h->d);
+            s.Ql = take_half(c, Mc * h->d);
+            s.Kh = take_half(c, Mc * h->d);
+            s.Kl = take_half(c, Mc * h->d);
+            s.vt_elems = (size_t)sg.nseq * h->d * sg.Spad;
+            s.Vth = take_half(c, s.vt_elems);
+            s.Vtl = take_half(c, s.vt_elems);
+        } else {
+            s.QKV = c.take(Mc * 3 * h->d);  // iMID: sequences of T tokens, exact-fp32 attention kernel
+        }
+        s.Ah = take_half(c, Mc * h->d);
+        s.Al = take_half(c, Mc * h->d);
+        s.H1h = take_half(c, Mc * h->ff);
+        s.H1l = take_half(c, Mc * h->ff);
+        s.Y3h = take_half(c, Mc * h->dmid);
+        s.Y3l = take_half(c, Mc * h->dmid);
+    }
     if (sb) *sb = s;
     return c.off;
 }
 
 // one evaluation of the net on a chunk of whole episodes + (optionally) the DDIM update
 int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, int step_idx, float* x_chunk,
-             const float* hyp_chunk, float* e_out) {
+             const float* hyp_chunk, float* e_out, int precision) {
+    const bool split = precision != JMID_PREC_F32;
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
@@ -292,44 +352,46 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     {
         ProfScope ps(h, KC_EMBED);
         EmbedArgs ea{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, thyp,
-                     sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm};
+                     sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
+                     split ? sb.Xl : nullptr};
         const long total = (long)M * (d / 4);
         int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
         hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), 0, h->stream, ea);
         HIPCHK(h, hipGetLastError());
     }
-    const int nseq = h->net_kind == JMID_NET_JMID ? Ec : R;
-    const int S = h->net_kind == JMID_NET_JMID ? K * A * T : T;
+    const SeqGeom sg = seq_geom(h, Ec, A, K, T);
+    const int nseq = sg.nseq, S = sg.S;
     const int hd = d / h->nhead;
-    for (int l = 0; l < h->tf_layer; ++l) {
-        const std::string p = "transformer_encoder.layers." + std::to_string(l);
-        GemmArgs g{};
-        g.rmap = rm;
-        // QKV projection
-        g.A = sb.X; g.lda = d; g.W = W(h, p + ".self_attn.in_proj_weight"); g.ldw = d;
-        g.bias = W(h, p + ".self_attn.in_proj_bias"); g.C = sb.QKV; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
-        if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g)) return rc;
-        {
-            ProfScope ps(h, KC_ATTN);
-            AttnArgs aa{sb.QKV, sb.ATT, S, d, h->nhead, 1.0f / sqrtf((float)hd)};
-            HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
+    const float att_scale = 1.0f / sqrtf((float)hd);
+    if (!split) {
+        for (int l = 0; l < h->tf_layer; ++l) {
+            const std::string p = "transformer_encoder.layers." + std::to_string(l);
+            GemmArgs g{};
+            g.rmap = rm;
+            // QKV projection
+            g.A = sb.X; g.lda = d; g.W = W(h, p + ".self_attn.in_proj_weight"); g.ldw = d;
+            g.bias = W(h, p + ".self_attn.in_proj_bias"); g.C = sb.QKV; g.ldc = 3 * d; g.M = M; g.N = 3 * d; g.K = d;
+            if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g)) return rc;
+            {
+                ProfScope ps(h, KC_ATTN);
+                AttnArgs aa{sb.QKV, sb.ATT, S, d, h->nhead, att_scale, nullptr, nullptr};
+                HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
+            }
+            // attention output projection + residual + LN1
+            g.A = sb.ATT; g.lda = d; g.W = W(h, p + ".self_attn.out_proj.weight"); g.ldw = d;
+            g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+            if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_OUT, g)) return rc;
+            if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d)) return rc;
+            // feed-forward
+            g.A = sb.X; g.lda = d; g.W = W(h, p + ".linear1.weight"); g.ldw = d; g.bias = W(h, p + ".linear1.bias");
+            g.C = sb.H1; g.ldc = ff; g.N = ff; g.K = d;
+            if (int rc = run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_FF1, g)) return rc;
+            g.A = sb.H1; g.lda = ff; g.W = W(h, p + ".linear2.weight"); g.ldw = ff; g.bias = W(h, p + ".linear2.bias");
+            g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
+            if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_FF2, g)) return rc;
+            if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d)) return rc;
         }
-        // attention output projection + residual + LN1
-        g.A = sb.ATT; g.lda = d; g.W = W(h, p + ".self_attn.out_proj.weight"); g.ldw = d;
-        g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
-        if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_OUT, g)) return rc;
-        if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d)) return rc;
-        // feed-forward
-        g.A = sb.X; g.lda = d; g.W = W(h, p + ".linear1.weight"); g.ldw = d; g.bias = W(h, p + ".linear1.bias");
-        g.C = sb.H1; g.ldc = ff; g.N = ff; g.K = d;
-        if (int rc = run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_FF1, g)) return rc;
-        g.A = sb.H1; g.lda = ff; g.W = W(h, p + ".linear2.weight"); g.ldw = ff; g.bias = W(h, p + ".linear2.bias");
-        g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
-        if (int rc = run_gemm<EPI_BIAS>(h, KC_GEMM_FF2, g)) return rc;
-        if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d)) return rc;
-    }
-    // tail: concat3, concat4 (ConcatSquash epilogues), then final CSL + DDIM
-    {
+        // tail: concat3, concat4 (ConcatSquash epilogues)
         GemmArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
         g.A = sb.X; g.lda = d; g.W = W(h, "concat3._layer.weight"); g.ldw = d; g.bias = W(h, "concat3._layer.bias");
@@ -339,6 +401,61 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
         g.goff = h->hl.g4; g.boff = h->hl.b4;
         if (int rc = run_gemm<EPI_CSL>(h, KC_GEMM_TAIL, g)) return rc;
+    } else {
+        const bool joint = h->net_kind == JMID_NET_JMID;
+        for (int l = 0; l < h->tf_layer; ++l) {
+            const std::string p = "transformer_encoder.layers." + std::to_string(l);
+            GemmHArgs g{};
+            g.rmap = rm; g.M = M;
+            const HalfPair& win = h->wsplit[p + ".self_attn.in_proj_weight"];
+            g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = win.hi; g.Wlo = win.lo; g.ldw = d;
+            g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
+            if (joint) {
+                g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl; g.Vthi = sb.Vth; g.Vtlo = sb.Vtl;
+                g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad;
+                if (int rc = (run_gemm_h<EPI_BIAS, OUT_QKV>(h, KC_GEMM_QKV, g))) return rc;
+                ProfScope ps(h, KC_ATTN);
+                AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
+                             att_scale, h->range_flag};
+                HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
+            } else {
+                g.C = sb.QKV; g.ldc = 3 * d;
+                if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g))) return rc;
+                ProfScope ps(h, KC_ATTN);
+                AttnArgs aa{sb.QKV, nullptr, S, d, h->nhead, att_scale, sb.Ah, sb.Al};
+                HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
+            }
+            const HalfPair& wout = h->wsplit[p + ".self_attn.out_proj.weight"];
+            g.Ahi = sb.Ah; g.Alo = sb.Al; g.lda = d; g.Whi = wout.hi; g.Wlo = wout.lo; g.ldw = d;
+            g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+            if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
+            if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
+                                    sb.Xl))
+                return rc;
+            const HalfPair& w1 = h->wsplit[p + ".linear1.weight"];
+            g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = w1.hi; g.Wlo = w1.lo; g.ldw = d;
+            g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
+            if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
+            const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
+            g.Ahi = sb.H1h; g.Alo = sb.H1l; g.lda = ff; g.Whi = w2.hi; g.Wlo = w2.lo; g.ldw = ff;
+            g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
+            if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
+            if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
+                                    sb.Xl))
+                return rc;
+        }
+        GemmHArgs g{};
+        g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
+        const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
+        g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = w3.hi; g.Wlo = w3.lo; g.ldw = d;
+        g.bias = W(h, "concat3._layer.bias"); g.Chi = sb.Y3h; g.Clo = sb.Y3l; g.ldc = h->dmid; g.N = h->dmid; g.K = d;
+        g.goff = h->hl.g3; g.boff = h->hl.b3;
+        if (int rc = (run_gemm_h<EPI_CSL, OUT_SPLIT>(h, KC_GEMM_TAIL, g))) return rc;
+        const HalfPair& w4 = h->wsplit["concat4._layer.weight"];
+        g.Ahi = sb.Y3h; g.Alo = sb.Y3l; g.lda = h->dmid; g.Whi = w4.hi; g.Wlo = w4.lo; g.ldw = h->dmid;
+        g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
+        g.goff = h->hl.g4; g.boff = h->hl.b4;
+        if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
     }
     {
         ProfScope ps(h, KC_OUT_DDIM);
@@ -371,7 +488,10 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     if (int rc = check_ready(h)) return rc;
     if (E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "E, A, K, T must be positive");
     if (T > 24) return fail(h, JMID_EINVAL, "T exceeds the positional-encoding table (max_len=24, diffusion.py:116-118)");
-    if (precision != JMID_PREC_F32) return fail(h, JMID_EINVAL, "precision mode not available in this build");
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3)
+        return fail(h, JMID_EINVAL, "precision must be JMID_PREC_F32 or JMID_PREC_F16X3 (JMID_PREC_F16 is not built)");
+    if (precision == JMID_PREC_F16X3 && !h->weights_in_half_range)
+        return fail(h, JMID_ERANGE, "a weight exceeds the fp16 range: use JMID_PREC_F32");
     if (!x_in || !ctx) return fail(h, JMID_EINVAL, "null input");
     if (pos_out && !p0) return fail(h, JMID_EINVAL, "pos_out requested without p0");
     HIPCHK(h, hipSetDevice(h->device));
@@ -389,7 +509,8 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         c.take(M * 2);                 // e / pos staging
         io_off = c.off;
     }
-    const size_t need = io_off + step_ws_floats(h, Mc, nullptr, nullptr);
+    const SeqGeom sg_full = seq_geom(h, Ec, A, K, T);
+    const size_t need = io_off + step_ws_floats(h, Mc, precision, sg_full, nullptr, nullptr);
     if (int rc = ensure_arena(h, need)) return rc;
     Carver c(h->arena);
     float* x_cur = c.take(M * 2);
@@ -398,7 +519,14 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     float* p0_d = c.take(EA * 2);
     float* stage = c.take(M * 2);
     StepBuffers sb;
-    step_ws_floats(h, Mc, &sb, h->arena + io_off);
+    step_ws_floats(h, Mc, precision, sg_full, &sb, h->arena + io_off);
+    if (precision == JMID_PREC_F16X3) {
+        HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
+        if (sb.Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
+            HIPCHK(h, hipMemsetAsync(sb.Vth, 0, sb.vt_elems * sizeof(half_t), h->stream));
+            HIPCHK(h, hipMemsetAsync(sb.Vtl, 0, sb.vt_elems * sizeof(half_t), h->stream));
+        }
+    }
 
     const hipMemcpyKind kin = mem == JMID_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind kout = mem == JMID_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -427,10 +555,10 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         const float* hc = hyp + (size_t)e0 * A * h->hl.total;
         if (single_step >= 0) {
             float* eo = stage + (size_t)e0 * K * A * T * 2;
-            if (int rc = net_step(h, sb, ec, A, K, T, single_step, xc, hc, eo)) return rc;
+            if (int rc = net_step(h, sb, ec, A, K, T, single_step, xc, hc, eo, precision)) return rc;
         } else {
             for (int i = 0; i < n_steps; ++i)
-                if (int rc = net_step(h, sb, ec, A, K, T, i, xc, hc, nullptr)) return rc;
+                if (int rc = net_step(h, sb, ec, A, K, T, i, xc, hc, nullptr, precision)) return rc;
         }
     }
     if (single_step >= 0) {
@@ -448,7 +576,15 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
             HIPCHK(h, hipMemcpyAsync(pos_out, stage, M * 2 * sizeof(float), kout, h->stream));
         }
     }
-    if (mem == JMID_MEM_HOST) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (precision == JMID_PREC_F16X3) {
+        // an activation outside the fp16 range poisons the split operands: report it instead of returning garbage
+        int flag = 0;
+        HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3: rerun with JMID_PREC_F32");
+    } else if (mem == JMID_MEM_HOST) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return 0;
 }
 
@@ -457,7 +593,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* jmid_version(void) { return "jmid_hip 0.1.0 (gfx950; f32-mfma)"; }
+const char* jmid_version(void) { return "jmid_hip 0.2.0 (gfx950; f32-mfma + f16x3 split-mfma)"; }
 
 int jmid_device_count(void) {
     int n = 0;
@@ -511,6 +647,11 @@ int jmid_destroy(jmid_handle_t h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (auto& kv : h->w) hipFree(kv.second.p);
+    for (auto& kv : h->wsplit) {
+        hipFree(kv.second.hi);
+        hipFree(kv.second.lo);
+    }
+    if (h->range_flag) hipFree(h->range_flag);
     for (float* p : {h->pe, h->Whyp, h->bhyp, h->thyp, h->attW1T, h->attW2T})
         if (p) hipFree(p);
     for (auto& l : h->lstmT)
@@ -642,6 +783,41 @@ int jmid_finalize_weights(jmid_handle_t h) {
             }
         if (int rc = dev_alloc_copy(h, &h->attW1T, w1T)) return rc;
         if (int rc = dev_alloc_copy(h, &h->attW2T, w2T)) return rc;
+    }
+    // hi/lo fp16 planes of every GEMM weight (split once; activations are split by the producing kernels)
+    {
+        for (auto& kv : h->wsplit) {
+            hipFree(kv.second.hi);
+            hipFree(kv.second.lo);
+        }
+        h->wsplit.clear();
+        if (!h->range_flag) {
+            HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
+        }
+        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+        std::vector<std::string> names = {"concat3._layer.weight", "concat4._layer.weight"};
+        for (int l = 0; l < h->tf_layer; ++l) {
+            const std::string p = "transformer_encoder.layers." + std::to_string(l);
+            names.push_back(p + ".self_attn.in_proj_weight");
+            names.push_back(p + ".self_attn.out_proj.weight");
+            names.push_back(p + ".linear1.weight");
+            names.push_back(p + ".linear2.weight");
+        }
+        for (const auto& nm : names) {
+            const DevBuf& b = h->w[nm];
+            HalfPair hp;
+            HIPCHK(h, hipMalloc((void**)&hp.hi, b.n * sizeof(half_t)));
+            HIPCHK(h, hipMalloc((void**)&hp.lo, b.n * sizeof(half_t)));
+            hipLaunchKernelGGL(split_planes_kernel, dim3(256), dim3(256), 0, h->stream, b.p, hp.hi, hp.lo, b.n,
+                               h->range_flag);
+            HIPCHK(h, hipGetLastError());
+            h->wsplit[nm] = hp;
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        int flag = 0;
+        HIPCHK(h, hipMemcpy(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));
+        h->weights_in_half_range = flag == 0;
+        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
     }
     h->finalized = true;
     return upload_time_table(h);
@@ -809,8 +985,12 @@ int jmid_synchronize(jmid_handle_t h) {
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
                   int precision, float* C) {
     if (!h || !A || !Wt || !C) return JMID_EINVAL;
-    if (precision != JMID_PREC_F32) return fail(h, JMID_EINVAL, "precision mode not available in this build");
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3) return fail(h, JMID_EINVAL, "bad precision");
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->range_flag) {
+        HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
+        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+    }
     float *dA, *dW, *dB = nullptr, *dC;
     HIPCHK(h, hipMalloc((void**)&dA, (size_t)M * K * 4));
     HIPCHK(h, hipMalloc((void**)&dW, (size_t)N * K * 4));
@@ -821,9 +1001,26 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
         HIPCHK(h, hipMalloc((void**)&dB, (size_t)N * 4));
         HIPCHK(h, hipMemcpy(dB, bias, (size_t)N * 4, hipMemcpyHostToDevice));
     }
-    GemmArgs g{};
-    g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
-    int rc = relu ? run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_QKV, g) : run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g);
+    int rc = 0;
+    half_t *ah = nullptr, *al = nullptr, *wh = nullptr, *wl = nullptr;
+    if (precision == JMID_PREC_F32) {
+        GemmArgs g{};
+        g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        rc = relu ? run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_QKV, g) : run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g);
+    } else {
+        HIPCHK(h, hipMalloc((void**)&ah, (size_t)M * K * 2));
+        HIPCHK(h, hipMalloc((void**)&al, (size_t)M * K * 2));
+        HIPCHK(h, hipMalloc((void**)&wh, (size_t)N * K * 2));
+        HIPCHK(h, hipMalloc((void**)&wl, (size_t)N * K * 2));
+        hipLaunchKernelGGL(split_planes_kernel, dim3(256), dim3(256), 0, h->stream, dA, ah, al, (size_t)M * K,
+                           h->range_flag);
+        hipLaunchKernelGGL(split_planes_kernel, dim3(256), dim3(256), 0, h->stream, dW, wh, wl, (size_t)N * K,
+                           h->range_flag);
+        GemmHArgs g{};
+        g.Ahi = ah; g.Alo = al; g.lda = K; g.Whi = wh; g.Wlo = wl; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N;
+        g.M = M; g.N = N; g.K = K;
+        rc = relu ? run_gemm_h<EPI_BIAS_RELU, OUT_F32>(h, KC_GEMM_QKV, g) : run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g);
+    }
     if (!rc) {
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
@@ -831,29 +1028,60 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
     if (!rc) HIPCHK(h, hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost));
     hipFree(dA); hipFree(dW); hipFree(dC);
     if (dB) hipFree(dB);
+    for (half_t* p : {ah, al, wh, wl})
+        if (p) hipFree(p);
     return rc;
 }
 
 int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT) {
     if (!h || !QKV || !OUT) return JMID_EINVAL;
-    if (precision != JMID_PREC_F32) return fail(h, JMID_EINVAL, "precision mode not available in this build");
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3) return fail(h, JMID_EINVAL, "bad precision");
     HIPCHK(h, hipSetDevice(h->device));
+    if (!h->range_flag) {
+        HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
+        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+    }
     const size_t Mt = (size_t)nseq * S;
+    const int d = h->d, hd = h->d / h->nhead;
     float *dQ, *dO;
-    HIPCHK(h, hipMalloc((void**)&dQ, Mt * 3 * h->d * 4));
-    HIPCHK(h, hipMalloc((void**)&dO, Mt * h->d * 4));
-    HIPCHK(h, hipMemcpy(dQ, QKV, Mt * 3 * h->d * 4, hipMemcpyHostToDevice));
-    const int hd = h->d / h->nhead;
-    AttnArgs aa{dQ, dO, S, h->d, h->nhead, 1.0f / sqrtf((float)hd)};
+    HIPCHK(h, hipMalloc((void**)&dQ, Mt * 3 * d * 4));
+    HIPCHK(h, hipMalloc((void**)&dO, Mt * d * 4));
+    HIPCHK(h, hipMemcpy(dQ, QKV, Mt * 3 * d * 4, hipMemcpyHostToDevice));
     int rc = 0;
-    {
+    std::vector<half_t*> tmp;
+    if (precision == JMID_PREC_F32) {
+        AttnArgs aa{dQ, dO, S, d, h->nhead, 1.0f / sqrtf((float)hd), nullptr, nullptr};
         ProfScope ps(h, KC_ATTN);
         hipError_t e = launch_attn_f32(aa, nseq, hd, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+    } else {
+        const int Spad = (S + 7) / 8 * 8;
+        const size_t vt = (size_t)nseq * d * Spad;
+        half_t* b[8];
+        const size_t sz[8] = {Mt * d, Mt * d, Mt * d, Mt * d, vt, vt, Mt * d, Mt * d};
+        for (int i = 0; i < 8; ++i) {
+            HIPCHK(h, hipMalloc((void**)&b[i], sz[i] * sizeof(half_t)));
+            HIPCHK(h, hipMemsetAsync(b[i], 0, sz[i] * sizeof(half_t), h->stream));
+            tmp.push_back(b[i]);
+        }
+        hipLaunchKernelGGL(qkv_to_planes_kernel, dim3(512), dim3(256), 0, h->stream, dQ, b[0], b[1], b[2], b[3], b[4],
+                           b[5], Mt, d, hd, S, Spad);
+        AttnHArgs aa{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], S, Spad, d, h->nhead, 1.0f / sqrtf((float)hd),
+                     h->range_flag};
+        {
+            ProfScope ps(h, KC_ATTN);
+            hipError_t e = launch_attn_f16x3(aa, nseq, hd, h->stream);
+            if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(merge_planes_kernel, dim3(512), dim3(256), 0, h->stream, b[6], b[7], dO, Mt * d);
+    }
+    if (!rc) {
+        hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
     }
-    if (!rc) HIPCHK(h, hipMemcpy(OUT, dO, Mt * h->d * 4, hipMemcpyDeviceToHost));
+    if (!rc) HIPCHK(h, hipMemcpy(OUT, dO, Mt * d * 4, hipMemcpyDeviceToHost));
     hipFree(dQ); hipFree(dO);
+    for (half_t* p : tmp) hipFree(p);
     return rc;
 }
 

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 from safe_interactive_crowdnav_amd.engine import JmidEngine
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
-PRECISIONS = ["f32"]
+PRECISIONS = ["f32", "f16x3"]
 # max abs error allowed relative to max|ref| per precision mode
 TOL = {"f32": 2e-5, "f16x3": 4e-5, "f16": 2e-2}
 

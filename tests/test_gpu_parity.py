@@ -18,7 +18,7 @@ from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ADE_GATE = 1e-4
-PRECISIONS = ["f32"]
+PRECISIONS = ["f32", "f16x3"]
 
 
 def ade(a, b):
@@ -134,3 +134,19 @@ def test_full_size_property_checks(precision):
     assert torch.equal(vel_p.cpu(), vel[perm])
     ref_pos = torch.cumsum(vel, dim=3) * 0.25 + p0[:, None, :, None, :]
     assert (pos - ref_pos).abs().max() <= 1e-4
+
+
+def test_f16x3_reports_range_overflow_instead_of_garbage():
+    """JMID_PREC_F16X3 carries operands as fp16 hi/lo planes: values beyond the fp16 range must surface as
+    JMID_ERANGE (the caller then reruns in JMID_PREC_F32), never as silent inf/NaN trajectories."""
+    from safe_interactive_crowdnav_amd.engine import JmidError
+    eng, w = get_engine(32, 77, True)
+    eng.set_step(2)
+    g = torch.Generator().manual_seed(1)
+    ctx = torch.randn([1, 3, 32], generator=g)
+    x_T = torch.randn([1, 6, 4, 2], generator=g) * 1e9
+    with pytest.raises(JmidError) as ei:
+        eng.denoise(x_T.numpy(), ctx.numpy(), precision="f16x3", want_pos=False)
+    assert ei.value.code == -5
+    vel, _ = eng.denoise(x_T.numpy(), ctx.numpy(), precision="f32", want_pos=False)   # fp32 path still answers
+    assert np.isfinite(vel).all()
