@@ -135,6 +135,12 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
 /* Episodes processed together per pass of the 50-step loop (0 = automatic).  Smaller chunks keep the
  * activations of one pass resident in the 256 MiB Infinity Cache. */
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
+/* Implementation knobs for experiments (never needed for correctness).  Keys:
+ *   "gemm_h_variant"  F16X3 GEMM kernel: 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged,
+ *                     3 = 128x128 LDS-DMA ring
+ *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
+ * Unknown keys return JMID_EINVAL. */
+int jmid_set_tuning(jmid_handle_t h, const char* key, int value);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream.
  * mask: bit i enables class i (see jmid_kernel_class_name); 0 disables.  Timers accumulate until reset. */
 int jmid_profile_enable(jmid_handle_t h, uint32_t class_mask);

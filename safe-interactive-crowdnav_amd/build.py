@@ -27,10 +27,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile the HIP library in-tree.  Returns the path of the .so."""
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
         return LIB
+    # -ffp-contract=off: no implicit FMA contraction, so a value never depends on which template instance /
+    # code path computed it (results are bit-identical across tile variants and chunkings); fmaf() is explicit.
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libjmid_hip.so")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
            "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float s = (sm[r] + sc[r] * kLoInv) * a.scale;
+            float s = fmaf(sc[r], kLoInv, sm[r]) * a.scale;
             const int key = kt * KT + frag_row(r, hi);
             s = key < S ? s : -INFINITY;
             sm[r] = s;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
             psum += sm[r];
         }
         psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
+        l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
         // P fragments (B operand of O^T): register r = 8*mf + j holds key frag_row(r, hi)
         f16x8 ph[2], pl[2];
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
                 tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], tc, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ot[n][r] += tc[r] * kLoInv;
+            for (int r = 0; r < 16; ++r) ot[n][r] = fmaf(tc[r], kLoInv, ot[n][r]);
         }
     }
 
@@ -208,7 +208,221 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for head_dim 128: K and V^T tiles are copied HBM/L2 -> LDS by global_load_lds_dwordx4 into a
+// 2-stage ring, the copy of tile t+1 overlapping the MFMAs of tile t (one raw s_barrier per tile, counted vmcnt).
+// LDS rows are unpadded; bank-conflict swizzles live on the DMA source address:
+//   K  tile [32 keys][16 chunks of 16 B]: chunk c of row r stored at c ^ (r & 15)      (conflict-free b128 reads)
+//   V^T tile [128 d][4 chunks of 16 B]  : chunk c of row r stored at c ^ ((r>>2) & 3)  (<= 2-way on the b64 reads)
+constexpr int ATT_KPLANE = 32 * 128;                        // halfs per K plane per stage (8 KB)
+constexpr int ATT_VPLANE = 128 * 32;                        // halfs per V^T plane per stage (8 KB)
+constexpr int ATT_STAGE = 2 * ATT_KPLANE + 2 * ATT_VPLANE;  // Kh, Kl, Vh, Vl = 32 KB
+constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
+
+__global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt) {
+    constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char att_lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(att_lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    // XCD-aware order: the q-tiles of one (sequence, head) share K/V, keep them on one XCD's L2
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int qt = swz % nqt, sh = swz / nqt;
+    const int h = sh % a.nhead, seq = sh / a.nhead;
+    const int S = a.S, d = a.d;
+    const size_t tok0 = (size_t)seq * S;
+    const int q = (qt * 4 + wid) * 32 + l31;
+    const int qc = q < S ? q : S - 1;
+
+    f16x8 qh[NKS], ql[NKS];
+    {
+        const size_t o = (tok0 + qc) * d + h * HD + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            qh[ks] = *reinterpret_cast<const f16x8*>(a.Qhi + o + 16 * ks);
+            ql[ks] = *reinterpret_cast<const f16x8*>(a.Qlo + o + 16 * ks);
+        }
+    }
+    // the Q loads are ordinary VMEM loads: retire them before the DMA ring starts so that vmcnt counts only DMAs
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qh[ks]), "+v"(ql[ks]));
+
+    f32x16 ot[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // DMA sources.  K rounds 0-3: plane = i>>1, row = 16*(i&1) + tid/16, stored chunk tid&15.
+    //               V rounds 4-7: plane = (i-4)>>1, row = 64*(i&1) + tid/4, stored chunk tid&3.
+    const half_t* kh_g = a.Khi + tok0 * d + h * HD;
+    const half_t* kl_g = a.Klo + tok0 * d + h * HD;
+    const size_t vt0 = ((size_t)seq * a.nhead + h) * HD * a.Spad;
+    const int k_row = tid >> 4, k_c = (tid & 15) ^ (k_row & 15);             // rows 0-15 (+16 for odd rounds)
+    const int v_row = tid >> 2, v_c = (tid & 3) ^ ((v_row >> 2) & 3);       // rows 0-63 (+64 for odd rounds)
+    const int last_vchunk = a.Spad / 8 - 1;
+    auto issue = [&](int kt) {
+        half_t* st = lds + (kt & 1) * ATT_STAGE + wid * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int key = kt * KT + 16 * (i & 1) + k_row;
+            key = key < S ? key : S - 1;
+            const half_t* src = ((i >> 1) ? kl_g : kh_g) + (size_t)key * d + k_c * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 64 * (i & 1) + v_row;
+            int kc = kt * 4 + v_c;
+            kc = kc < last_vchunk ? kc : last_vchunk;
+            const half_t* src = ((i >> 1) ? a.Vtlo : a.Vthi) + vt0 + (size_t)row * a.Spad + kc * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + 2 * ATT_KPLANE + i * 2048), 16,
+                                             0, 0);
+        }
+    };
+    // fragment read offsets (halfs)
+    int offK[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) offK[ks] = l31 * 128 + (((2 * ks + hi) ^ (l31 & 15)) * 8);
+    int offV[NT][2][2];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int vrow = n * 32 + l31;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+                offV[n][mf][pc] = vrow * 32 + (((2 * mf + pc) ^ ((vrow >> 2) & 3)) * 8) + 4 * hi;
+    }
+
+    const int ntiles = (S + KT - 1) / KT;
+    issue(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
+        __builtin_amdgcn_s_barrier();                      // ... and everybody else's; stage (kt+1)&1 is free again
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < ntiles) issue(kt + 1);
+        const half_t* Kh = lds + (kt & 1) * ATT_STAGE;
+        const half_t* Kl = Kh + ATT_KPLANE;
+        const half_t* Vh = Kh + 2 * ATT_KPLANE;
+        const half_t* Vl = Vh + ATT_VPLANE;
+
+        f32x16 sm, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sm[r] = 0.f;
+            sc[r] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + offK[ks]);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + offK[ks]);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = fmaf(sc[r], kLoInv, sm[r]) * a.scale;
+            const int key = kt * KT + frag_row(r, hi);
+            s = key < S ? s : -INFINITY;
+            sm[r] = s;
+            tmax = fmaxf(tmax, s);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sm[r] = expf(sm[r] - m_new);
+            psum += sm[r];
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = fmaf(l_run, alpha, psum);
+        m_run = m_new;
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                half_t hh, ll;
+                split_f32(sm[8 * mf + j], hh, ll);
+                ph[mf][j] = hh;
+                pl[mf][j] = ll;
+            }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x16 tc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ot[n][r] *= alpha;
+                tc[r] = 0.f;
+            }
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                const f16x4 vh0 = *reinterpret_cast<const f16x4*>(Vh + offV[n][mf][0]);
+                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(Vh + offV[n][mf][1]);
+                const f16x4 vl0 = *reinterpret_cast<const f16x4*>(Vl + offV[n][mf][0]);
+                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(Vl + offV[n][mf][1]);
+                const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+                const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
+                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], tc, 0, 0, 0);
+                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], tc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[n][r] = fmaf(tc[r], kLoInv, ot[n][r]);
+        }
+    }
+
+    if (q < S) {
+        const float inv = 1.0f / l_run;
+        const size_t o = (tok0 + q) * d + h * HD;
+        bool overflow = false;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c0 = n * 32 + 8 * r4 + 4 * hi;
+                f16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ot[n][4 * r4 + e] * inv;
+                    half_t hh, ll;
+                    split_f32(v, hh, ll);
+                    overflow |= !(fabsf(v) <= kHalfMax);
+                    vh[e] = hh;
+                    vl[e] = ll;
+                }
+                *reinterpret_cast<f16x4*>(a.Ohi + o + c0) = vh;
+                *reinterpret_cast<f16x4*>(a.Olo + o + c0) = vl;
+            }
+        }
+        if (overflow) atomicOr(a.range_flag, 1);
+    }
+}
+
+static int g_attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
+
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, hipStream_t st) {
+    if (head_dim == 128 && g_attn_h_variant != 1) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+            attr_set = true;
+        }
+        const int nqt = (a.S + 127) / 128;
+        hipLaunchKernelGGL(attn_f16x3_dma_kernel, dim3(nqt * a.nhead * nseq), dim3(256), ATT_DMA_LDS, st, a, nqt);
+        return hipGetLastError();
+    }
     dim3 grid((a.S + 127) / 128, a.nhead, nseq);
     switch (head_dim) {
         case 16: hipLaunchKernelGGL((attn_f16x3_kernel<16>), grid, dim3(256), 0, st, a); break;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_f32_kernel(AttnArgs a) {
             psum += st[r];
         }
         psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
+        l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
 #pragma unroll
         for (int n = 0; n < NT; ++n)

@@ -33,6 +33,8 @@ __device__ __forceinline__ void split_f32(float v, half_t& hi, half_t& lo) {
 
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
+static int g_gemm_h_variant = 0;  // tuning knob (jmid_set_tuning)
+
 struct GemmHArgs {
     const half_t *Ahi, *Alo;  // [M, K], row stride lda (elements)
     const half_t *Whi, *Wlo;  // [N, K], row stride ldw
@@ -42,7 +44,7 @@ struct GemmHArgs {
     half_t *Chi, *Clo;        // OUT_SPLIT: planes [M, N] row stride ldc ; OUT_QKV: Q planes [M, d]
     int ldc;
     half_t *Khi, *Klo;        // OUT_QKV: K planes [M, d]
-    half_t *Vthi, *Vtlo;      // OUT_QKV: V^T planes [nseq][nhead][hd][Spad]
+    half_t *Vthi, *Vtlo;      // OUT_QKV: V planes [M, d] (row-major; transposed afterwards by v_transpose_kernel)
     int d, hd, S, Spad;
     const float* hyp;         // EPI_CSL (see gemm_f32.hpp)
     const float* thyp;
@@ -57,6 +59,107 @@ constexpr int GEMMH_LD = 40;  // halfs per LDS row (80 bytes)
 template <int WM, int WN>
 constexpr size_t gemm_h_lds_bytes() {
     return size_t(2) /*buffers*/ * 2 /*planes*/ * (64 * WM + 64 * WN) * GEMMH_LD * sizeof(half_t);
+}
+
+// three passes over the wave's tiles so that the two MFMAs into the same correction accumulator are WM*WN
+// instructions apart (a back-to-back dependent pair stalls for the MFMA latency)
+template <int WM, int WN>
+__device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[WM], const f16x8 (&wh)[WN],
+                                      const f16x8 (&wl)[WN], f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN]) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], accm[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], accc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], accc[i][j], 0, 0, 0);
+}
+
+// Epilogue.  FULL = the whole block tile is inside [M, N] (block-uniform): no per-element predication, so the
+// stores issue back to back.  The per-column scalars (bias, time part of the hyper nets) are loaded once and pinned
+// with an empty asm: otherwise hipcc re-waits `vmcnt(0)` before every use inside the store loop, and since stores
+// count on vmcnt too (CDNA4) every store would wait for the previous one to complete.
+template <int WM, int WN, int EPI, int OUT, bool FULL>
+__device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN],
+                                                     int m0, int n0, int wr, int wc, int l31, int hi) {
+    bool overflow = false;
+    float bv[WN], tg[WN], tb[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        int n = n0 + wc * WN * 32 + j * 32 + l31;
+        n = (FULL || n < g.N) ? n : g.N - 1;
+        bv[j] = g.bias ? g.bias[n] : 0.f;
+        tg[j] = 0.f;
+        tb[j] = 0.f;
+        if (EPI == EPI_CSL) {
+            tg[j] = g.thyp[g.goff + n];
+            tb[j] = g.thyp[g.boff + n];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]), "+v"(tg[j]), "+v"(tb[j]));
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wc * WN * 32 + j * 32 + l31;
+        if (!FULL && n >= g.N) continue;
+        // OUT_QKV: which of Q / K / V this column belongs to
+        int part = 0, nn = n;
+        if (OUT == OUT_QKV) {
+            part = n / g.d;
+            nn = n - part * g.d;
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * WM * 32 + i * 32 + frag_row(r, hi);
+                if (!FULL && m >= g.M) continue;
+                float v = fmaf(accc[i][j][r], kLoInv, accm[i][j][r]) + bv[j];
+                if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+                if (EPI == EPI_CSL) {
+                    const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
+                    v = fmaf(v, sigmoidf_(hrow[g.goff + n] + tg[j]), hrow[g.boff + n] + tb[j]);
+                }
+                if (OUT == OUT_F32) {
+                    g.C[(size_t)m * g.ldc + n] = v;
+                } else {
+                    half_t h, l;
+                    split_f32(v, h, l);
+                    overflow |= !(fabsf(v) <= kHalfMax);
+                    if (OUT == OUT_SPLIT) {
+                        g.Chi[(size_t)m * g.ldc + n] = h;
+                        g.Clo[(size_t)m * g.ldc + n] = l;
+                    } else {
+                        if (part == 0) {
+                            g.Chi[(size_t)m * g.d + nn] = h;
+                            g.Clo[(size_t)m * g.d + nn] = l;
+                        } else if (part == 1) {
+                            g.Khi[(size_t)m * g.d + nn] = h;
+                            g.Klo[(size_t)m * g.d + nn] = l;
+                        } else {   // V row-major planes; v_transpose_kernel makes them key-contiguous
+                            g.Vthi[(size_t)m * g.d + nn] = h;
+                            g.Vtlo[(size_t)m * g.d + nn] = l;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
+}
+
+template <int WM, int WN, int EPI, int OUT>
+__device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN],
+                                                int m0, int n0, int wr, int wc, int l31, int hi) {
+    if (m0 + 64 * WM <= g.M && n0 + 64 * WN <= g.N)
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, true>(g, accm, accc, m0, n0, wr, wc, l31, hi);
+    else
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, false>(g, accm, accc, m0, n0, wr, wc, l31, hi);
 }
 
 template <int WM, int WN, int EPI, int OUT>
@@ -155,79 +258,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
                 wh[j] = *reinterpret_cast<const f16x8*>(Wh + j * 32 * LD + ks * 16);
                 wl[j] = *reinterpret_cast<const f16x8*>(Wl + j * 32 * LD + ks * 16);
             }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], accm[i][j], 0, 0, 0);
-                    accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], accc[i][j], 0, 0, 0);
-                    accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], accc[i][j], 0, 0, 0);
-                }
+            mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds col = l31, rows frag_row(reg, hi)
-    bool overflow = false;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wc * WN * 32 + j * 32 + l31;
-        if (n >= g.N) continue;
-        const float bv = g.bias ? g.bias[n] : 0.f;
-        float tg = 0.f, tb = 0.f;
-        if (EPI == EPI_CSL) {
-            tg = g.thyp[g.goff + n];
-            tb = g.thyp[g.boff + n];
-        }
-        // OUT_QKV: which of Q / K / V this column belongs to
-        int part = 0, nn = n, vh = 0, vc = 0;
-        if (OUT == OUT_QKV) {
-            part = n / g.d;
-            nn = n - part * g.d;
-            vh = nn / g.hd;
-            vc = nn - vh * g.hd;
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * WM * 32 + i * 32 + frag_row(r, hi);
-                if (m >= g.M) continue;
-                float v = accm[i][j][r] + accc[i][j][r] * kLoInv + bv;
-                if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-                if (EPI == EPI_CSL) {
-                    const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
-                    v = v * sigmoidf_(hrow[g.goff + n] + tg) + (hrow[g.boff + n] + tb);
-                }
-                if (OUT == OUT_F32) {
-                    g.C[(size_t)m * g.ldc + n] = v;
-                } else {
-                    half_t h, l;
-                    split_f32(v, h, l);
-                    overflow |= !(fabsf(v) <= kHalfMax);
-                    if (OUT == OUT_SPLIT) {
-                        g.Chi[(size_t)m * g.ldc + n] = h;
-                        g.Clo[(size_t)m * g.ldc + n] = l;
-                    } else {
-                        if (part == 0) {
-                            g.Chi[(size_t)m * g.d + nn] = h;
-                            g.Clo[(size_t)m * g.d + nn] = l;
-                        } else if (part == 1) {
-                            g.Khi[(size_t)m * g.d + nn] = h;
-                            g.Klo[(size_t)m * g.d + nn] = l;
-                        } else {
-                            const int seq = m / g.S, key = m - seq * g.S;
-                            const size_t o = (((size_t)seq * (g.d / g.hd) + vh) * g.hd + vc) * g.Spad + key;
-                            g.Vthi[o] = h;
-                            g.Vtlo[o] = l;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi);
 }
 
 template <int WM, int WN, int EPI, int OUT>
@@ -245,10 +282,143 @@ inline hipError_t launch_gemm_h_cfg(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (global_load_lds_dwordx4): operand tiles go HBM/L2 -> LDS without passing through VGPRs, into a
+// 4-stage ring with three K-tiles in flight and ONE barrier per K-tile (counted vmcnt, raw s_barrier).
+// 128x128 tile, BK = 32, 4 waves, 128 KB of LDS (one workgroup per CU).
+// A DMA writes LDS lane-linearly (wave base + lane*16), so rows are unpadded 64-byte lines and the bank-conflict
+// swizzle lives on the SOURCE address: 16-byte chunk c of row r is stored at chunk  c ^ ((r>>2)&3).
+// blockIdx is remapped so that each XCD (block b runs on XCD b%8) walks a contiguous range of tiles and the A
+// row-panel shared by consecutive N-tiles stays in that XCD's L2.
+constexpr int DMA_STAGES = 4;
+constexpr int DMA_PLANE = 128 * 32;                       // halfs per plane per stage (8 KB)
+constexpr int DMA_STAGE = 4 * DMA_PLANE;                  // Ahi, Alo, Whi, Wlo
+constexpr size_t DMA_LDS_BYTES = size_t(DMA_STAGES) * DMA_STAGE * sizeof(half_t);
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int ntm, int ntn) {
+    constexpr int WM = 2, WN = 2, BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    // XCD-aware tile order (bijective for any grid size)
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    // L2-aware order inside the XCD's range: N-tiles in groups of NG, all M-tiles of a group before the next group.
+    // The 32 CUs of an XCD then work on (8 M-tiles) x (NG N-tiles): the W group (<= 1 MB) stays in the 4 MB L2 and
+    // every A row-panel is fetched from Infinity Cache / HBM once per group instead of once per N-tile.
+    const int NG = (ntn % 4 == 0) ? 4 : (ntn % 3 == 0) ? 3 : (ntn % 2 == 0) ? 2 : 1;
+    const int per_group = ntm * NG;
+    const int grp = swz / per_group, rem = swz - grp * per_group;
+    const int tm = rem / NG, tn = grp * NG + (rem - tm * NG);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // DMA source addresses: round i (0..7): plane p = i>>1, rows 64*(i&1) + tid/4, stored chunk tid&3
+    const int d_row = tid >> 2, d_pc = tid & 3;
+    const half_t* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = i >> 1, row = 64 * (i & 1) + d_row;
+        const int c = d_pc ^ ((row >> 2) & 3);              // logical chunk held by this stored slot
+        if (p < 2) {
+            int r = m0 + row;
+            r = r < g.M ? r : g.M - 1;
+            src[i] = (p == 0 ? g.Ahi : g.Alo) + (size_t)r * g.lda + c * 8;
+        } else {
+            int r = n0 + row;
+            r = r < g.N ? r : g.N - 1;
+            src[i] = (p == 2 ? g.Whi : g.Wlo) + (size_t)r * g.ldw + c * 8;
+        }
+    }
+    auto issue = [&](int kt) {
+        half_t* st = lds + (kt & (DMA_STAGES - 1)) * DMA_STAGE + wid * 512;   // wave-uniform base (+ lane*16 B by HW)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * GEMMH_BK),
+                                             (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
+    };
+
+    f32x16 accm[WM][WN], accc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[i][j][r] = 0.f;
+                accc[i][j][r] = 0.f;
+            }
+
+    const int nk = g.K / GEMMH_BK;
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    // fragment read offsets (halfs) inside a plane: row*32 + (chunk ^ swz)*8
+    int offA[WM][2], offW[WN][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = wr * 64 + i * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offA[i][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int row = wc * 64 + j * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offW[j][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's DMAs of tile kt have landed once at most (tiles still wanted in flight) * 8 remain outstanding
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // every wave's part of tile kt landed; stage (kt-1)&3 is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 3 < nk) issue(kt + 3);
+        const half_t* st = lds + (kt & (DMA_STAGES - 1)) * DMA_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
+                al[i] = *reinterpret_cast<const f16x8*>(st + DMA_PLANE + offA[i][ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offW[j][ks]);
+                wl[j] = *reinterpret_cast<const f16x8*>(st + 3 * DMA_PLANE + offW[j][ks]);
+            }
+            mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+        }
+    }
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi);
+}
+
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_h_dma(const GemmHArgs& g, hipStream_t st) {
+    const int ntm = (g.M + 127) / 128, ntn = (g.N + 127) / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<EPI, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(256), DMA_LDS_BYTES, st, g, ntm, ntn);
+    return hipGetLastError();
+}
+
 template <int EPI, int OUT>
 inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    if (big >= 512) return launch_gemm_h_cfg<2, 2, EPI, OUT>(g, st);
+    const int v = g_gemm_h_variant;   // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA
+    if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
+    if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT>(g, st);
+    if (v == 3 || (v == 0 && big >= 256)) return launch_gemm_h_dma<EPI, OUT>(g, st);
     return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
 }
 
@@ -264,6 +434,39 @@ __global__ void split_planes_kernel(const float* in, half_t* hi, half_t* lo, siz
         lo[i] = l;
     }
     if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
+// V planes [nseq*S, d] (token-major, as the QKV GEMM emits them) -> V^T planes [nseq][nhead][hd][Spad]
+// (key-contiguous: the k-operand layout of the PV product).  64x64 tiles through LDS; both planes per block.
+// grid = (ceil(S/64), d/64, nseq)
+__global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, const half_t* vl, half_t* vth, half_t* vtl,
+                                                          int S, int Spad, int d, int hd) {
+    __shared__ half_t tile[2][64][64 + 8];
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, seq = blockIdx.z;
+    const size_t tok0 = (size_t)seq * S;
+    // load: 64 keys x 8 chunks of 8 columns, two planes
+    for (int id = tid; id < 1024; id += 256) {
+        const int p = id >> 9, r = (id >> 3) & 63, c = id & 7;
+        const int key = k0 + r;
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < S) v = *reinterpret_cast<const f16x8*>((p ? vl : vh) + (tok0 + key) * d + c0 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[p][r][c * 8 + e] = v[e];
+    }
+    __syncthreads();
+    // store: 64 columns x 8 chunks of 8 keys
+    for (int id = tid; id < 1024; id += 256) {
+        const int p = id >> 9, col = (id >> 3) & 63, kc = id & 7;
+        const int key = k0 + kc * 8;
+        if (key >= Spad) continue;
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[p][kc * 8 + e][col];
+        const int cg = c0 + col, head = cg / hd, vc = cg - head * hd;
+        const size_t o = (((size_t)seq * (d / hd) + head) * hd + vc) * Spad + key;
+        *reinterpret_cast<f16x8*>((p ? vtl : vth) + o) = v;
+    }
 }
 
 // hi/lo planes -> fp32 (diagnostics)

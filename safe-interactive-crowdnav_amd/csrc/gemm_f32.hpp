@@ -36,6 +36,49 @@ constexpr size_t gemm_f32_lds_bytes() {
     return size_t(2) * (64 * WM + 64 * WN) * GEMM_LDS_LD * sizeof(float);
 }
 
+// Epilogue (lane holds col = l31, rows frag_row(reg, hi)).  FULL = block tile entirely inside [M, N]: unpredicated,
+// back-to-back stores.  Per-column scalars are loaded once and pinned by an empty asm so that hipcc does not re-wait
+// vmcnt(0) (which also counts the stores on CDNA4) before every store.
+template <int WM, int WN, int EPI, bool FULL>
+__device__ __forceinline__ void gemm_f32_epilogue(const GemmArgs& g, f32x16 (&acc)[WM][WN], int m0, int n0, int wr,
+                                                  int wc, int l31, int hi) {
+    float bv[WN], tg[WN], tb[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        int n = n0 + wc * WN * 32 + j * 32 + l31;
+        n = (FULL || n < g.N) ? n : g.N - 1;
+        bv[j] = g.bias ? g.bias[n] : 0.f;
+        tg[j] = 0.f;
+        tb[j] = 0.f;
+        if (EPI == EPI_CSL) {
+            tg[j] = g.thyp[g.goff + n];
+            tb[j] = g.thyp[g.boff + n];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]), "+v"(tg[j]), "+v"(tb[j]));
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n0 + wc * WN * 32 + j * 32 + l31;
+        if (!FULL && n >= g.N) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wr * WM * 32 + i * 32 + frag_row(r, hi);
+                if (!FULL && m >= g.M) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+                if (EPI == EPI_CSL) {
+                    const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
+                    v = fmaf(v, sigmoidf_(hrow[g.goff + n] + tg[j]), hrow[g.boff + n] + tb[j]);
+                }
+                g.C[(size_t)m * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
 template <int WM, int WN, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -122,33 +165,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds col = l31, rows frag_row(reg, hi)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n0 + wc * WN * 32 + j * 32 + l31;
-        if (n >= g.N) continue;
-        const float bv = g.bias ? g.bias[n] : 0.f;
-        float tg = 0.f, tb = 0.f;
-        if (EPI == EPI_CSL) {
-            tg = g.thyp[g.goff + n];
-            tb = g.thyp[g.boff + n];
-        }
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * WM * 32 + i * 32 + frag_row(r, hi);
-                if (m >= g.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-                if (EPI == EPI_CSL) {
-                    const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
-                    v = v * sigmoidf_(hrow[g.goff + n] + tg) + (hrow[g.boff + n] + tb);
-                }
-                g.C[(size_t)m * g.ldc + n] = v;
-            }
-        }
-    }
+    if (m0 + BM <= g.M && n0 + BN <= g.N)
+        gemm_f32_epilogue<WM, WN, EPI, true>(g, acc, m0, n0, wr, wc, l31, hi);
+    else
+        gemm_f32_epilogue<WM, WN, EPI, false>(g, acc, m0, n0, wr, wc, l31, hi);
 }
 
 template <int WM, int WN, int EPI>

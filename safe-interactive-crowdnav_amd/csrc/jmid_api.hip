@@ -37,11 +37,12 @@ enum KClass {
     KC_ENCODER,
     KC_INTEGRATE,
     KC_METRICS,
+    KC_VTRANS,
     KC_COUNT
 };
 const char* kClassNames[KC_COUNT] = {"gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_tail", "attention",
                                      "add_layernorm", "embed", "out_ddim", "hyper", "encoder", "integrate",
-                                     "episode_metrics"};
+                                     "episode_metrics", "v_transpose"};
 
 struct DevBuf {
     float* p = nullptr;
@@ -287,7 +288,7 @@ int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const flo
 struct StepBuffers {
     float *X, *QKV, *ATT, *Y, *H1, *Y3, *Y4;
     // F16X3 path: hi/lo planes
-    half_t *Xh, *Xl, *Qh, *Ql, *Kh, *Kl, *Vth, *Vtl, *Ah, *Al, *H1h, *H1l, *Y3h, *Y3l;
+    half_t *Xh, *Xl, *Qh, *Ql, *Kh, *Kl, *Vh, *Vl, *Vth, *Vtl, *Ah, *Al, *H1h, *H1l, *Y3h, *Y3l;
     size_t vt_elems;
 };
 
@@ -324,6 +325,8 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
             s.Ql = take_half(c, Mc * h->d);
             s.Kh = take_half(c, Mc * h->d);
             s.Kl = take_half(c, Mc * h->d);
+            s.Vh = take_half(c, Mc * h->d);
+            s.Vl = take_half(c, Mc * h->d);
             s.vt_elems = (size_t)sg.nseq * h->d * sg.Spad;
             s.Vth = take_half(c, s.vt_elems);
             s.Vtl = take_half(c, s.vt_elems);
@@ -411,9 +414,15 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = win.hi; g.Wlo = win.lo; g.ldw = d;
             g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
             if (joint) {
-                g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl; g.Vthi = sb.Vth; g.Vtlo = sb.Vtl;
+                g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl; g.Vthi = sb.Vh; g.Vtlo = sb.Vl;
                 g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_QKV>(h, KC_GEMM_QKV, g))) return rc;
+                {
+                    ProfScope ps(h, KC_VTRANS);
+                    hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, d / 64, nseq), dim3(256), 0, h->stream,
+                                       sb.Vh, sb.Vl, sb.Vth, sb.Vtl, S, sg.Spad, d, hd);
+                    HIPCHK(h, hipGetLastError());
+                }
                 ProfScope ps(h, KC_ATTN);
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
                              att_scale, h->range_flag};
@@ -927,6 +936,22 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
     if (!h || episodes < 0) return JMID_EINVAL;
     h->chunk_eps = episodes;
     return JMID_OK;
+}
+
+int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
+    if (!h || !key) return JMID_EINVAL;
+    const std::string k(key);
+    if (k == "gemm_h_variant") {
+        if (value < 0 || value > 3) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..3");
+        g_gemm_h_variant = value;
+        return JMID_OK;
+    }
+    if (k == "attn_h_variant") {
+        if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "attn_h_variant must be 0..2");
+        g_attn_h_variant = value;
+        return JMID_OK;
+    }
+    return fail(h, JMID_EINVAL, "unknown tuning key " + k);
 }
 
 int jmid_profile_enable(jmid_handle_t h, uint32_t class_mask) {

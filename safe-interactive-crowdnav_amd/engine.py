@@ -97,6 +97,9 @@ class JmidEngine:
     def set_chunk_episodes(self, n: int) -> None:
         self._check(self._lib.jmid_set_chunk_episodes(self._h, int(n)))
 
+    def set_tuning(self, key: str, value: int) -> None:
+        self._check(self._lib.jmid_set_tuning(self._h, key.encode(), int(value)))
+
     def synchronize(self) -> None:
         self._check(self._lib.jmid_synchronize(self._h))
 
