@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--episodes-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "f16"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
     ap.add_argument("--cpu-episodes", type=int, default=4, help="episodes timed on the host for cpu_baseline (0 = skip)")
@@ -164,8 +164,9 @@ def main():
         "metric": "sampled trajectories/sec (N x K, 50 denoise steps)",
         "value": round(value, 2), "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"f32": "f32", "f16x3": "f32 (fp16x3 split-MFMA, fp32 accumulate)",
-                                       "f16": "f16"}[args.precision],
+        "vs_baseline": None,
+        "dtype": {"f32": "f32", "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate"}[
+            args.precision],
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {E} episodes/GPU x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",

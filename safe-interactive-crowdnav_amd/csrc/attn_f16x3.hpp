@@ -8,7 +8,7 @@
 // key tile, which keeps the register cost of the split at 16 VGPRs instead of doubling the O accumulator.
 //
 // Inputs : Qhi/Qlo, Khi/Klo [nseq*S, d] planes;  Vthi/Vtlo [nseq][nhead][hd][Spad] planes.
-// Output : hi/lo planes [nseq*S, d] (operand of the attention out-projection GEMM).
+// Output : hi/lo planes [nseq*S, d] in the blocked panel layout (operand of the attention out-projection GEMM).
 #pragma once
 #include "common.hpp"
 #include "gemm_f16x3.hpp"
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
     // ---- normalise, split and store: register r of tile n is head-dim n*32 + frag_row(r, hi)
     if (q < S) {
         const float inv = 1.0f / l_run;
-        const size_t o = (tok0 + q) * d + h * HD;
+        const int orow = (int)tok0 + q;
         bool overflow = false;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -199,8 +199,9 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
                         vh[e] = hh;
                         vl[e] = ll;
                     }
-                    *reinterpret_cast<f16x4*>(a.Ohi + o + c0) = vh;
-                    *reinterpret_cast<f16x4*>(a.Olo + o + c0) = vl;
+                    const size_t ob = blk_index(orow, h * HD + c0, d);
+                    *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
+                    *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;
                 }
             }
         }
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units
+    const float scale2 = a.scale * 1.4426950408889634f;   // softmax in base 2: one v_exp_f32 per element
 
     // DMA sources.  K rounds 0-3: plane = i>>1, row = 16*(i&1) + tid/16, stored chunk tid&15.
     //               V rounds 4-7: plane = (i-4)>>1, row = 64*(i&1) + tid/4, stored chunk tid&3.
@@ -285,20 +287,15 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                                              0, 0);
         }
     };
-    // fragment read offsets (halfs)
-    int offK[NKS];
+    // fragment read offsets (halfs), kept to a handful of registers:
+    //   K : row l31, chunk (2ks+hi) ^ (l31&15)                        -> kbase + (((2ks+hi) ^ kx) << 3)
+    //   V : row n*32+l31, chunk (2mf+pc) ^ ((row>>2)&3) (same for every n) -> vbase[mf][pc] + n*1024
+    const int kbase = l31 * 128, kx = l31 & 15;
+    int vbase[2][2];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) offK[ks] = l31 * 128 + (((2 * ks + hi) ^ (l31 & 15)) * 8);
-    int offV[NT][2][2];
+    for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int vrow = n * 32 + l31;
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
-                offV[n][mf][pc] = vrow * 32 + (((2 * mf + pc) ^ ((vrow >> 2) & 3)) * 8) + 4 * hi;
-    }
+        for (int pc = 0; pc < 2; ++pc) vbase[mf][pc] = l31 * 32 + (((2 * mf + pc) ^ ((l31 >> 2) & 3)) * 8) + 4 * hi;
 
     const int ntiles = (S + KT - 1) / KT;
     issue(0);
@@ -320,16 +317,19 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + offK[ks]);
-            const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + offK[ks]);
+            const int ok = kbase + (((2 * ks + hi) ^ kx) << 3);
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + ok);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + ok);
             sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
             sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+            // keep at most two steps of K fragments in flight: hoisting all 16 ds_reads costs 64 VGPRs and spills
+            if (ks & 1) __builtin_amdgcn_sched_barrier(0);
         }
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float s = fmaf(sc[r], kLoInv, sm[r]) * a.scale;
+            float s = fmaf(sc[r], kLoInv, sm[r]) * scale2;
             const int key = kt * KT + frag_row(r, hi);
             s = key < S ? s : -INFINITY;
             sm[r] = s;
@@ -337,11 +337,13 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // the running max of most rows stops moving after a few tiles: alpha == 1 exactly, skip the O rescale
+        const bool rescale = !__all(m_new == m_run);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sm[r] = expf(sm[r] - m_new);
+            sm[r] = __builtin_amdgcn_exp2f(sm[r] - m_new);
             psum += sm[r];
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -357,20 +359,23 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 ph[mf][j] = hh;
                 pl[mf][j] = ll;
             }
+        if (rescale) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x16 tc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                ot[n][r] *= alpha;
-                tc[r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) tc[r] = 0.f;
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
-                const f16x4 vh0 = *reinterpret_cast<const f16x4*>(Vh + offV[n][mf][0]);
-                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(Vh + offV[n][mf][1]);
-                const f16x4 vl0 = *reinterpret_cast<const f16x4*>(Vl + offV[n][mf][0]);
-                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(Vl + offV[n][mf][1]);
+                const f16x4 vh0 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][0]);
+                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][1]);
+                const f16x4 vl0 = *reinterpret_cast<const f16x4*>(Vl + n * 1024 + vbase[mf][0]);
+                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(Vl + n * 1024 + vbase[mf][1]);
                 const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
                 const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
@@ -379,12 +384,13 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) ot[n][r] = fmaf(tc[r], kLoInv, ot[n][r]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     if (q < S) {
         const float inv = 1.0f / l_run;
-        const size_t o = (tok0 + q) * d + h * HD;
+        const int orow = (int)tok0 + q;
         bool overflow = false;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -401,8 +407,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                     vh[e] = hh;
                     vl[e] = ll;
                 }
-                *reinterpret_cast<f16x4*>(a.Ohi + o + c0) = vh;
-                *reinterpret_cast<f16x4*>(a.Olo + o + c0) = vl;
+                const size_t ob = blk_index(orow, h * HD + c0, d);
+                *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
+                *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;
             }
         }
         if (overflow) atomicOr(a.range_flag, 1);

@@ -23,7 +23,7 @@ struct AttnArgs {
     float* OUT;        // [nseq*S, d]
     int S, d, nhead;
     float scale;       // 1/sqrt(head_dim)
-    half_t* Ohi;       // optional: write hi/lo planes [nseq*S, d] instead of OUT (split-fp16 pipeline, iMID)
+    half_t* Ohi;       // optional: write hi/lo planes [nseq*S, d] (blocked panel layout) instead of OUT
     half_t* Olo;
 };
 
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_f32_kernel(AttnArgs a) {
                             vh[e] = hh;
                             vl[e] = ll;
                         }
-                        const size_t oo = ((size_t)seq * S + q) * d + h * HD + c0;
+                        const size_t oo = blk_index(seq * S + q, h * HD + c0, d);
                         *reinterpret_cast<f16x4*>(a.Ohi + oo) = vh;
                         *reinterpret_cast<f16x4*>(a.Olo + oo) = vl;
                     } else {

@@ -44,6 +44,19 @@ struct RowMap {
     }
 };
 
+// Blocked ("panel") layout of an fp16 operand plane [rows, K] of the split-fp16 GEMMs: 128-row x 32-half tiles of
+// 8 KB stored contiguously, tile (rb, kb) at ((rb * K/32 + kb) * 4096) halfs.  Inside a tile, row r is a 64-byte line
+// whose four 16-byte chunks are XOR-swizzled (chunk c at c ^ ((r>>2)&3)): the memory image IS the bank-conflict-free
+// LDS image, so one global_load_lds wave-instruction moves 1 KB of fully contiguous, fully used cache lines.
+// Rows are padded to a multiple of 128 (padding rows only ever feed discarded output rows).
+__host__ __device__ __forceinline__ size_t blk_index(int row, int k, int K) {
+    const int rb = row >> 7, r = row & 127, kb = k >> 5, kk = k & 31;
+    return ((size_t)rb * (K >> 5) + kb) * 4096 + (size_t)(r * 32 + ((((kk >> 3) ^ ((r >> 2) & 3)) << 3) | (kk & 7)));
+}
+__host__ __device__ __forceinline__ size_t blk_plane_elems(size_t rows, int K) {
+    return ((rows + 127) / 128) * 128 * (size_t)K;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

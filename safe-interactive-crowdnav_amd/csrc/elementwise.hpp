@@ -20,7 +20,7 @@ struct EmbedArgs {
     float* X;            // [M, d]
     int M, d, hyp_ld, goff, boff;
     RowMap rmap;
-    half_t* Xh;          // optional hi/lo planes of X for the split-fp16 GEMMs (nullptr: not written)
+    half_t* Xh;          // optional hi/lo planes of X (blocked panel layout) for the split-fp16 GEMMs
     half_t* Xl;
 };
 
@@ -52,8 +52,9 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
                 vh[e] = hh;
                 vl[e] = ll;
             }
-            *reinterpret_cast<f16x4*>(a.Xh + (size_t)m * a.d + j) = vh;
-            *reinterpret_cast<f16x4*>(a.Xl + (size_t)m * a.d + j) = vl;
+            const size_t ob = blk_index(m, j, a.d);
+            *reinterpret_cast<f16x4*>(a.Xh + ob) = vh;
+            *reinterpret_cast<f16x4*>(a.Xl + ob) = vl;
         }
     }
 }
@@ -115,8 +116,9 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
                     vh[e] = hh;
                     vl[e] = ll;
                 }
-                *reinterpret_cast<f16x4*>(Xh + (size_t)row * d + c) = vh;
-                *reinterpret_cast<f16x4*>(Xl + (size_t)row * d + c) = vl;
+                const size_t ob = blk_index(row, c, d);
+                *reinterpret_cast<f16x4*>(Xh + ob) = vh;
+                *reinterpret_cast<f16x4*>(Xl + ob) = vl;
             }
         }
     }

@@ -36,12 +36,12 @@ enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 static int g_gemm_h_variant = 0;  // tuning knob (jmid_set_tuning)
 
 struct GemmHArgs {
-    const half_t *Ahi, *Alo;  // [M, K], row stride lda (elements)
-    const half_t *Whi, *Wlo;  // [N, K], row stride ldw
+    const half_t *Ahi, *Alo;  // [M, K] in the blocked panel layout (common.hpp::blk_index), rows padded to 128
+    const half_t *Whi, *Wlo;  // [N, K] blocked
     const float* bias;
-    int M, N, K, lda, ldw;
+    int M, N, K;
     float* C;                 // OUT_F32: [M, N] row stride ldc
-    half_t *Chi, *Clo;        // OUT_SPLIT: planes [M, N] row stride ldc ; OUT_QKV: Q planes [M, d]
+    half_t *Chi, *Clo;        // OUT_SPLIT: planes [M, N] blocked (operand of the next GEMM) ; OUT_QKV: Q planes [M, d] row-major
     int ldc;
     half_t *Khi, *Klo;        // OUT_QKV: K planes [M, d]
     half_t *Vthi, *Vtlo;      // OUT_QKV: V planes [M, d] (row-major; transposed afterwards by v_transpose_kernel)
@@ -132,8 +132,9 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     split_f32(v, h, l);
                     overflow |= !(fabsf(v) <= kHalfMax);
                     if (OUT == OUT_SPLIT) {
-                        g.Chi[(size_t)m * g.ldc + n] = h;
-                        g.Clo[(size_t)m * g.ldc + n] = l;
+                        const size_t o = blk_index(m, n, g.N);
+                        g.Chi[o] = h;
+                        g.Clo[o] = l;
                     } else {
                         if (part == 0) {
                             g.Chi[(size_t)m * g.d + nn] = h;
@@ -155,8 +156,9 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
 
 template <int WM, int WN, int EPI, int OUT>
 __device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN],
-                                                int m0, int n0, int wr, int wc, int l31, int hi) {
-    if (m0 + 64 * WM <= g.M && n0 + 64 * WN <= g.N)
+                                                int m0, int n0, int wr, int wc, int l31, int hi, int bm = 64 * WM,
+                                                int bn = 64 * WN) {
+    if (m0 + bm <= g.M && n0 + bn <= g.N)
         gemm_h_epilogue_impl<WM, WN, EPI, OUT, true>(g, accm, accc, m0, n0, wr, wc, l31, hi);
     else
         gemm_h_epilogue_impl<WM, WN, EPI, OUT, false>(g, accm, accc, m0, n0, wr, wc, l31, hi);
@@ -180,30 +182,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
     const int s_row = tid >> 2, s_c = tid & 3;
     const half_t *pah[NA], *pal[NA], *pwh[NB], *pwl[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        int r = m0 + s_row + 64 * i;
-        r = r < g.M ? r : g.M - 1;
-        pah[i] = g.Ahi + (size_t)r * g.lda + s_c * 8;
-        pal[i] = g.Alo + (size_t)r * g.lda + s_c * 8;
+    for (int i = 0; i < NA; ++i) {   // planes are padded to 128 rows: no clamping needed
+        const size_t o = blk_index(m0 + s_row + 64 * i, s_c * 8, g.K);
+        pah[i] = g.Ahi + o;
+        pal[i] = g.Alo + o;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        int r = n0 + s_row + 64 * i;
-        r = r < g.N ? r : g.N - 1;
-        pwh[i] = g.Whi + (size_t)r * g.ldw + s_c * 8;
-        pwl[i] = g.Wlo + (size_t)r * g.ldw + s_c * 8;
+        const size_t o = blk_index(n0 + s_row + 64 * i, s_c * 8, g.K);
+        pwh[i] = g.Whi + o;
+        pwl[i] = g.Wlo + o;
     }
     f16x8 rah[NA], ral[NA], rwh[NB], rwl[NB];
     auto gload = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            rah[i] = *reinterpret_cast<const f16x8*>(pah[i] + kt * GEMMH_BK);
-            ral[i] = *reinterpret_cast<const f16x8*>(pal[i] + kt * GEMMH_BK);
+            rah[i] = *reinterpret_cast<const f16x8*>(pah[i] + (size_t)kt * 4096);
+            ral[i] = *reinterpret_cast<const f16x8*>(pal[i] + (size_t)kt * 4096);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            rwh[i] = *reinterpret_cast<const f16x8*>(pwh[i] + kt * GEMMH_BK);
-            rwl[i] = *reinterpret_cast<const f16x8*>(pwl[i] + kt * GEMMH_BK);
+            rwh[i] = *reinterpret_cast<const f16x8*>(pwh[i] + (size_t)kt * 4096);
+            rwl[i] = *reinterpret_cast<const f16x8*>(pwl[i] + (size_t)kt * 4096);
         }
     };
     auto lstore = [&](int buf) {
@@ -316,29 +316,22 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
     const int tm = rem / NG, tn = grp * NG + (rem - tm * NG);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // DMA source addresses: round i (0..7): plane p = i>>1, rows 64*(i&1) + tid/4, stored chunk tid&3
-    const int d_row = tid >> 2, d_pc = tid & 3;
-    const half_t* src[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int p = i >> 1, row = 64 * (i & 1) + d_row;
-        const int c = d_pc ^ ((row >> 2) & 3);              // logical chunk held by this stored slot
-        if (p < 2) {
-            int r = m0 + row;
-            r = r < g.M ? r : g.M - 1;
-            src[i] = (p == 0 ? g.Ahi : g.Alo) + (size_t)r * g.lda + c * 8;
-        } else {
-            int r = n0 + row;
-            r = r < g.N ? r : g.N - 1;
-            src[i] = (p == 2 ? g.Whi : g.Wlo) + (size_t)r * g.ldw + c * 8;
-        }
-    }
+    // DMA sources: the operand planes are stored in the blocked panel layout, so K-tile kt of this block's A (W)
+    // panel is one contiguous 8 KB image per plane; round i (0..7) = plane i>>1, half i&1, and thread t copies the
+    // 16 bytes at offset (i&1)*4 KB + t*16 of that image - 1 KB of contiguous full cache lines per wave-instruction.
+    const int nk = g.K / GEMMH_BK;
+    const half_t* src[4];
+    src[0] = g.Ahi + (size_t)tm * nk * 4096 + tid * 8;
+    src[1] = g.Alo + (size_t)tm * nk * 4096 + tid * 8;
+    src[2] = g.Whi + (size_t)tn * nk * 4096 + tid * 8;
+    src[3] = g.Wlo + (size_t)tn * nk * 4096 + tid * 8;
     auto issue = [&](int kt) {
         half_t* st = lds + (kt & (DMA_STAGES - 1)) * DMA_STAGE + wid * 512;   // wave-uniform base (+ lane*16 B by HW)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * GEMMH_BK),
-                                             (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src[i >> 1] + (size_t)kt * 4096 + (i & 1) * 2048),
+                (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
     };
 
     f32x16 accm[WM][WN], accc[WM][WN];
@@ -352,7 +345,6 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
                 accc[i][j][r] = 0.f;
             }
 
-    const int nk = g.K / GEMMH_BK;
     issue(0);
     if (nk > 1) issue(1);
     if (nk > 2) issue(2);
@@ -412,14 +404,134 @@ inline hipError_t launch_gemm_h_dma(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 256x128 LDS-DMA variant: 8 waves (4 along M x 2 along N, two per SIMD so that one wave's MFMAs cover the other's
+// LDS-read latency and barrier skew), 48 KB stages, 3-stage ring (two K-tiles in flight), 144 KB of LDS.
+// 25 % fewer operand bytes per FLOP than the 128x128 tile.  Each DMA round copies one whole 8 KB panel image.
+constexpr int DMA2_STAGES = 3;
+constexpr int DMA2_STAGE = 6 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi, Wlo
+constexpr size_t DMA2_LDS_BYTES = size_t(DMA2_STAGES) * DMA2_STAGE * sizeof(half_t);
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, int ntm, int ntn) {
+    constexpr int WM = 2, WN = 2, BM = 256, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;                 // wr 0..3, wc 0..1
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int NG = (ntn % 4 == 0) ? 4 : (ntn % 3 == 0) ? 3 : (ntn % 2 == 0) ? 2 : 1;
+    const int per_group = ntm * NG;
+    const int grp = swz / per_group, rem = swz - grp * per_group;
+    const int tm = rem / NG, tn = grp * NG + (rem - tm * NG);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk = g.K / GEMMH_BK;
+    const int nrb = (g.M + 127) / 128;                     // allocated 128-row panels of A
+    const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
+    const half_t* src[6];
+    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[2] = g.Alo + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[3] = g.Alo + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[4] = g.Whi + (size_t)tn * nk * 4096 + tid * 8;
+    src[5] = g.Wlo + (size_t)tn * nk * 4096 + tid * 8;
+    auto issue = [&](int kt, int stage) {
+        half_t* st = lds + stage * DMA2_STAGE + wid * 512;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
+                                             (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
+    };
+
+    f32x16 accm[WM][WN], accc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[i][j][r] = 0.f;
+                accc[i][j][r] = 0.f;
+            }
+    // fragment read offsets (halfs).  A rows 0-127 live in image 0, rows 128-255 in image 1; lo planes 2 images later.
+    int offA[WM][2], offW[WN][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = wr * 64 + i * 32 + l31;            // 0..255
+        const int r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offA[i][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int row = wc * 64 + j * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offW[j][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
+    }
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (stage + 2) % 3
+        const half_t* st = lds + stage * DMA2_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
+                al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
+                wl[j] = *reinterpret_cast<const f16x8*>(st + 5 * DMA_PLANE + offW[j][ks]);
+            }
+            mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi, BM, BN);
+}
+
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
+    const int ntm = (g.M + 255) / 256, ntn = (g.N + 127) / 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<EPI, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA2_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn);
+    return hipGetLastError();
+}
+
 template <int EPI, int OUT>
 inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const int v = g_gemm_h_variant;   // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA
+    // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA
+    const int v = g_gemm_h_variant;
     if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
     if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT>(g, st);
-    if (v == 3 || (v == 0 && big >= 256)) return launch_gemm_h_dma<EPI, OUT>(g, st);
-    return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
+    if (v == 3) return launch_gemm_h_dma<EPI, OUT>(g, st);
+    if (v == 4) return launch_gemm_h_dma256<EPI, OUT>(g, st);
+    if (big < 256) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
+    // auto: 256x128 unless the coarser grid quantises badly onto the 256 CUs (one workgroup per CU)
+    const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+    auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };
+    if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT>(g, st);
+    return launch_gemm_h_dma<EPI, OUT>(g, st);
 }
 
 // fp32 -> hi/lo planes (weights at load time, activations produced by fp32-only kernels)
@@ -432,6 +544,23 @@ __global__ void split_planes_kernel(const float* in, half_t* hi, half_t* lo, siz
         overflow |= !(fabsf(v) <= kHalfMax);
         hi[i] = h;
         lo[i] = l;
+    }
+    if (overflow && range_flag) atomicOr(range_flag, 1);
+}
+
+// fp32 row-major [rows, K] -> hi/lo planes in the blocked panel layout (weights at load time, diagnostics)
+__global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K, int* range_flag) {
+    bool overflow = false;
+    const size_t n = (size_t)rows * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / K), k = (int)(i % K);
+        const float v = in[i];
+        half_t h, l;
+        split_f32(v, h, l);
+        overflow |= !(fabsf(v) <= kHalfMax);
+        const size_t o = blk_index(r, k, K);
+        hi[o] = h;
+        lo[o] = l;
     }
     if (overflow && range_flag) atomicOr(range_flag, 1);
 }
@@ -469,10 +598,13 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, cons
     }
 }
 
-// hi/lo planes -> fp32 (diagnostics)
-__global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (float)hi[i] + (float)lo[i] * kLoInv;
+// blocked hi/lo planes [rows, K] -> fp32 row-major (diagnostics)
+__global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* out, int rows, int K) {
+    const size_t n = (size_t)rows * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = blk_index((int)(i / K), (int)(i % K), K);
+        out[i] = (float)hi[o] + (float)lo[o] * kLoInv;
+    }
 }
 
 // packed fp32 QKV [M, 3d] -> Q/K planes [M, d] + V^T planes [nseq][nhead][hd][Spad] (diagnostics; the pipeline

@@ -318,8 +318,8 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
         s.H1 = c.take(Mc * h->ff);
         s.Y3 = c.take(Mc * h->dmid);
     } else {
-        s.Xh = take_half(c, Mc * h->d);
-        s.Xl = take_half(c, Mc * h->d);
+        s.Xh = take_half(c, blk_plane_elems(Mc, h->d));
+        s.Xl = take_half(c, blk_plane_elems(Mc, h->d));
         if (h->net_kind == JMID_NET_JMID) {
             s.Qh = take_half(c, Mc * h->d);
             s.Ql = take_half(c, Mc * h->d);
@@ -333,12 +333,12 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
         } else {
             s.QKV = c.take(Mc * 3 * h->d);  // iMID: sequences of T tokens, exact-fp32 attention kernel
         }
-        s.Ah = take_half(c, Mc * h->d);
-        s.Al = take_half(c, Mc * h->d);
-        s.H1h = take_half(c, Mc * h->ff);
-        s.H1l = take_half(c, Mc * h->ff);
-        s.Y3h = take_half(c, Mc * h->dmid);
-        s.Y3l = take_half(c, Mc * h->dmid);
+        s.Ah = take_half(c, blk_plane_elems(Mc, h->d));
+        s.Al = take_half(c, blk_plane_elems(Mc, h->d));
+        s.H1h = take_half(c, blk_plane_elems(Mc, h->ff));
+        s.H1l = take_half(c, blk_plane_elems(Mc, h->ff));
+        s.Y3h = take_half(c, blk_plane_elems(Mc, h->dmid));
+        s.Y3l = take_half(c, blk_plane_elems(Mc, h->dmid));
     }
     if (sb) *sb = s;
     return c.off;
@@ -411,7 +411,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             GemmHArgs g{};
             g.rmap = rm; g.M = M;
             const HalfPair& win = h->wsplit[p + ".self_attn.in_proj_weight"];
-            g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = win.hi; g.Wlo = win.lo; g.ldw = d;
+            g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = win.hi; g.Wlo = win.lo;
             g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
             if (joint) {
                 g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl; g.Vthi = sb.Vh; g.Vtlo = sb.Vl;
@@ -435,18 +435,18 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
             }
             const HalfPair& wout = h->wsplit[p + ".self_attn.out_proj.weight"];
-            g.Ahi = sb.Ah; g.Alo = sb.Al; g.lda = d; g.Whi = wout.hi; g.Wlo = wout.lo; g.ldw = d;
+            g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
             g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
             if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
             if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
                                     sb.Xl))
                 return rc;
             const HalfPair& w1 = h->wsplit[p + ".linear1.weight"];
-            g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = w1.hi; g.Wlo = w1.lo; g.ldw = d;
+            g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w1.hi; g.Wlo = w1.lo;
             g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
             if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
             const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
-            g.Ahi = sb.H1h; g.Alo = sb.H1l; g.lda = ff; g.Whi = w2.hi; g.Wlo = w2.lo; g.ldw = ff;
+            g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
             g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
             if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
             if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
@@ -456,12 +456,12 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
         const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
-        g.Ahi = sb.Xh; g.Alo = sb.Xl; g.lda = d; g.Whi = w3.hi; g.Wlo = w3.lo; g.ldw = d;
+        g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w3.hi; g.Wlo = w3.lo;
         g.bias = W(h, "concat3._layer.bias"); g.Chi = sb.Y3h; g.Clo = sb.Y3l; g.ldc = h->dmid; g.N = h->dmid; g.K = d;
         g.goff = h->hl.g3; g.boff = h->hl.b3;
         if (int rc = (run_gemm_h<EPI_CSL, OUT_SPLIT>(h, KC_GEMM_TAIL, g))) return rc;
         const HalfPair& w4 = h->wsplit["concat4._layer.weight"];
-        g.Ahi = sb.Y3h; g.Alo = sb.Y3l; g.lda = h->dmid; g.Whi = w4.hi; g.Wlo = w4.lo; g.ldw = h->dmid;
+        g.Ahi = sb.Y3h; g.Alo = sb.Y3l; g.Whi = w4.hi; g.Wlo = w4.lo;
         g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
         g.goff = h->hl.g4; g.boff = h->hl.b4;
         if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
@@ -479,8 +479,19 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
 
 int pick_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
     if (h->chunk_eps > 0) return std::min(E, h->chunk_eps);
-    const long target = 24576;  // tokens per pass: ~150 MB of fp32 activations, inside the 256 MiB Infinity Cache
-    long c = target / std::max(1, tokens_per_episode);
+    // Episodes per pass of the 50-step loop.  Large enough to fill the chip several times over per launch, and -
+    // for JMID - a whole number of "rounds" of the attention launch: that kernel runs 2 workgroups per CU (512
+    // slots) and one episode contributes nhead * ceil(S/128) workgroups, so a chunk of floor(k*512 / that) episodes
+    // leaves no partially filled last round (20 -> 51 episodes: +15 % attention throughput on BASELINE cfg3).
+    const long max_tokens = 65536;
+    if (h->net_kind == JMID_NET_JMID) {
+        const long bpe = (long)h->nhead * ((tokens_per_episode + 127) / 128);
+        for (int k = 4; k >= 1; --k) {
+            const long c = (k * 512L) / bpe;
+            if (c >= 1 && c * tokens_per_episode <= max_tokens) return (int)std::min<long>(c, E);
+        }
+    }
+    long c = max_tokens / std::max(1, tokens_per_episode);
     if (c < 1) c = 1;
     return (int)std::min<long>(c, E);
 }
@@ -814,11 +825,15 @@ int jmid_finalize_weights(jmid_handle_t h) {
         }
         for (const auto& nm : names) {
             const DevBuf& b = h->w[nm];
+            const std::vector<size_t>& shp = h->expected[nm];   // [N, K]
+            const size_t pe = blk_plane_elems(shp[0], (int)shp[1]);
             HalfPair hp;
-            HIPCHK(h, hipMalloc((void**)&hp.hi, b.n * sizeof(half_t)));
-            HIPCHK(h, hipMalloc((void**)&hp.lo, b.n * sizeof(half_t)));
-            hipLaunchKernelGGL(split_planes_kernel, dim3(256), dim3(256), 0, h->stream, b.p, hp.hi, hp.lo, b.n,
-                               h->range_flag);
+            HIPCHK(h, hipMalloc((void**)&hp.hi, pe * sizeof(half_t)));
+            HIPCHK(h, hipMalloc((void**)&hp.lo, pe * sizeof(half_t)));
+            HIPCHK(h, hipMemsetAsync(hp.hi, 0, pe * sizeof(half_t), h->stream));
+            HIPCHK(h, hipMemsetAsync(hp.lo, 0, pe * sizeof(half_t), h->stream));
+            hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(256), dim3(256), 0, h->stream, b.p, hp.hi, hp.lo,
+                               (int)shp[0], (int)shp[1], h->range_flag);
             HIPCHK(h, hipGetLastError());
             h->wsplit[nm] = hp;
         }
@@ -942,7 +957,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     if (!h || !key) return JMID_EINVAL;
     const std::string k(key);
     if (k == "gemm_h_variant") {
-        if (value < 0 || value > 3) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..3");
+        if (value < 0 || value > 4) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..4");
         g_gemm_h_variant = value;
         return JMID_OK;
     }
@@ -1033,16 +1048,19 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
         g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
         rc = relu ? run_gemm<EPI_BIAS_RELU>(h, KC_GEMM_QKV, g) : run_gemm<EPI_BIAS>(h, KC_GEMM_QKV, g);
     } else {
-        HIPCHK(h, hipMalloc((void**)&ah, (size_t)M * K * 2));
-        HIPCHK(h, hipMalloc((void**)&al, (size_t)M * K * 2));
-        HIPCHK(h, hipMalloc((void**)&wh, (size_t)N * K * 2));
-        HIPCHK(h, hipMalloc((void**)&wl, (size_t)N * K * 2));
-        hipLaunchKernelGGL(split_planes_kernel, dim3(256), dim3(256), 0, h->stream, dA, ah, al, (size_t)M * K,
+        const size_t pa = blk_plane_elems(M, K) * 2, pw = blk_plane_elems(N, K) * 2;
+        HIPCHK(h, hipMalloc((void**)&ah, pa));
+        HIPCHK(h, hipMalloc((void**)&al, pa));
+        HIPCHK(h, hipMalloc((void**)&wh, pw));
+        HIPCHK(h, hipMalloc((void**)&wl, pw));
+        for (auto pr : {std::make_pair(ah, pa), std::make_pair(al, pa), std::make_pair(wh, pw), std::make_pair(wl, pw)})
+            HIPCHK(h, hipMemsetAsync(pr.first, 0, pr.second, h->stream));
+        hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(512), dim3(256), 0, h->stream, dA, ah, al, M, K,
                            h->range_flag);
-        hipLaunchKernelGGL(split_planes_kernel, dim3(256), dim3(256), 0, h->stream, dW, wh, wl, (size_t)N * K,
+        hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(512), dim3(256), 0, h->stream, dW, wh, wl, N, K,
                            h->range_flag);
         GemmHArgs g{};
-        g.Ahi = ah; g.Alo = al; g.lda = K; g.Whi = wh; g.Wlo = wl; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N;
+        g.Ahi = ah; g.Alo = al; g.Whi = wh; g.Wlo = wl; g.bias = dB; g.C = dC; g.ldc = N;
         g.M = M; g.N = N; g.K = K;
         rc = relu ? run_gemm_h<EPI_BIAS_RELU, OUT_F32>(h, KC_GEMM_QKV, g) : run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g);
     }
@@ -1083,7 +1101,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
         const int Spad = (S + 7) / 8 * 8;
         const size_t vt = (size_t)nseq * d * Spad;
         half_t* b[8];
-        const size_t sz[8] = {Mt * d, Mt * d, Mt * d, Mt * d, vt, vt, Mt * d, Mt * d};
+        const size_t sz[8] = {Mt * d, Mt * d, Mt * d, Mt * d, vt, vt, blk_plane_elems(Mt, d), blk_plane_elems(Mt, d)};
         for (int i = 0; i < 8; ++i) {
             HIPCHK(h, hipMalloc((void**)&b[i], sz[i] * sizeof(half_t)));
             HIPCHK(h, hipMemsetAsync(b[i], 0, sz[i] * sizeof(half_t), h->stream));
@@ -1098,7 +1116,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
             hipError_t e = launch_attn_f16x3(aa, nseq, hd, h->stream);
             if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(merge_planes_kernel, dim3(512), dim3(256), 0, h->stream, b[6], b[7], dO, Mt * d);
+        hipLaunchKernelGGL(merge_planes_kernel, dim3(512), dim3(256), 0, h->stream, b[6], b[7], dO, (int)Mt, d);
     }
     if (!rc) {
         hipError_t e = hipStreamSynchronize(h->stream);

@@ -1,0 +1,59 @@
+// MFMA issue-rate probe: how fast does v_mfma_f32_32x32x16_f16 really go (independent vs dependent accumulators)?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NACC>
+__global__ __launch_bounds__(256) void k_f16(float* out, int iters) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(threadIdx.x * 0.001f + i); b[i] = (_Float16)(i * 0.5f); }
+    f32x16 acc[NACC];
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC>
+__global__ __launch_bounds__(256) void k_f32(float* out, int iters) {
+    float a = threadIdx.x * 0.001f, b = 0.5f;
+    f32x16 acc[NACC];
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int j = 0; j < NACC; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <typename K>
+void run(const char* name, K kern, int blocks, int threads, int iters, int nacc, double flop_per_mfma) {
+    float* d; hipMalloc(&d, (size_t)blocks * threads * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double nm = (double)blocks * (threads / 64) * iters * nacc;
+    printf("%-28s blocks=%d waves/blk=%d: %.3f ms  %.1f TFLOP/s  (%.1f cycles/MFMA/SIMD @2.4GHz if 1 wave/SIMD)\n", name, blocks,
+           threads / 64, ms, nm * flop_per_mfma / ms / 1e9, ms * 1e-3 * 2.4e9 / (iters * nacc * (threads / 256.0)));
+    hipFree(d);
+}
+int main() {
+    const double f16 = 2.0 * 32 * 32 * 16, f32 = 2.0 * 32 * 32 * 2;
+    run("f16 32x32x16 4acc 1w/SIMD", k_f16<4>, 256, 256, 20000, 4, f16);
+    run("f16 32x32x16 4acc 2w/SIMD", k_f16<4>, 512, 256, 20000, 4, f16);
+    run("f16 32x32x16 1acc 1w/SIMD", k_f16<1>, 256, 256, 40000, 1, f16);
+    run("f16 32x32x16 2acc 1w/SIMD", k_f16<2>, 256, 256, 40000, 2, f16);
+    run("f16 32x32x16 8acc 1w/SIMD", k_f16<8>, 256, 256, 10000, 8, f16);
+    run("f32 32x32x2  4acc 1w/SIMD", k_f32<4>, 256, 256, 20000, 4, f32);
+    return 0;
+}
