@@ -4,10 +4,13 @@
 //   S^T = K . Q^T      3 MFMAs per 16-deep step:  Khi.Qhi  (+ 2^-11 (Khi.Qlo + Klo.Qhi))
 //   O^T = V^T . P^T    P is split to hi/lo in registers straight from the S^T accumulators; V^T comes
 //                      key-contiguous from the QKV GEMM epilogue, so no transpose is needed on the way in.
-// The 2^-11-weighted correction terms go to a scratch accumulator that is folded into the fp32 state once per
-// key tile, which keeps the register cost of the split at 16 VGPRs instead of doubling the O accumulator.
+// Inside attention the lo planes are UNSCALED (lo = fp16(x - hi)): v_mfma_f32_32x32x16_f16 takes fp16 subnormal
+// inputs exactly (probed on gfx950, tools/mfma_denorm.hip), so hi.hi + hi.lo + lo.hi all accumulate into ONE fp32
+// accumulator with no correction accumulator and no fold (the pair carries x to max(2^-22 |x|, 2^-25) absolute,
+// which is what the O(1) Q/K/V/P values need).  Q arrives pre-multiplied by log2(e)/sqrt(head_dim) from the QKV GEMM
+// epilogue, so the scores are already in log2 units: softmax is one v_exp_f32 per element.
 //
-// Inputs : Qhi/Qlo, Khi/Klo [nseq*S, d] planes;  Vthi/Vtlo [nseq][nhead][hd][Spad] planes.
+// Inputs : Qhi/Qlo, Khi/Klo [nseq*S, d] planes;  Vthi/Vtlo [nseq][nhead][hd][Spad] planes (all lo unscaled).
 // Output : hi/lo planes [nseq*S, d] in the blocked panel layout (operand of the attention out-projection GEMM).
 #pragma once
 #include "common.hpp"
@@ -15,11 +18,30 @@
 
 namespace jmid {
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// two fp32 -> packed fp16 pair (round toward zero; the residual goes to the lo plane, so the mode does not matter)
+__device__ __forceinline__ unsigned int pk_f16(float a, float b) {
+    return __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// p[0..7] -> hi fragment and unscaled lo fragment (8 fp16 each)
+__device__ __forceinline__ void split8(const float* p, f16x8& hi, f16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const auto hp = __builtin_amdgcn_cvt_pkrtz(p[2 * i], p[2 * i + 1]);
+        h[i] = __builtin_bit_cast(unsigned int, hp);
+        l[i] = pk_f16(p[2 * i] - (float)hp[0], p[2 * i + 1] - (float)hp[1]);
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+
 struct AttnHArgs {
     const half_t *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;
     half_t *Ohi, *Olo;
     int S, Spad, d, nhead;
-    float scale;
+    float scale;       // unused by the kernels (Q is pre-scaled); kept for the diagnostics path
     int* range_flag;
 };
 
@@ -102,25 +124,22 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
         __syncthreads();
 
         // ---- S^T = K . Q^T  (rows = keys, cols = queries)
-        f32x16 sm, sc;
+        f32x16 sm;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sm[r] = 0.f;
-            sc[r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) sm[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const f16x8 kh = *reinterpret_cast<const f16x8*>(&Ksh[l31 * KLD + 16 * ks + 8 * hi]);
             const f16x8 kl = *reinterpret_cast<const f16x8*>(&Ksl[l31 * KLD + 16 * ks + 8 * hi]);
             sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sm, 0, 0, 0);
         }
         // ---- online softmax (fp32) over the 32 keys of this tile
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float s = fmaf(sc[r], kLoInv, sm[r]) * a.scale;
+            float s = sm[r];
             const int key = kt * KT + frag_row(r, hi);
             s = key < S ? s : -INFINITY;
             sm[r] = s;
@@ -128,11 +147,11 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sm[r] = expf(sm[r] - m_new);
+            sm[r] = __builtin_amdgcn_exp2f(sm[r] - m_new);
             psum += sm[r];
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -140,24 +159,18 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
         m_run = m_new;
         // P fragments (B operand of O^T): register r = 8*mf + j holds key frag_row(r, hi)
         f16x8 ph[2], pl[2];
+        {
+            float pv[16];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                half_t hh, ll;
-                split_f32(sm[8 * mf + j], hh, ll);
-                ph[mf][j] = hh;
-                pl[mf][j] = ll;
-            }
+            for (int r = 0; r < 16; ++r) pv[r] = sm[r];
+            split8(pv, ph[0], pl[0]);
+            split8(pv + 8, ph[1], pl[1]);
+        }
         // ---- O^T = alpha * O^T + V^T . P^T
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            f32x16 tc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                ot[n][r] *= alpha;
-                tc[r] = 0.f;
-            }
+            for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
             const int vrow = n * 32 + l31;
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
@@ -170,11 +183,9 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
                 const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
                 const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
-                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], tc, 0, 0, 0);
-                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], tc, 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], ot[n], 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], ot[n], 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[n][r] = fmaf(tc[r], kLoInv, ot[n][r]);
         }
     }
 
@@ -255,8 +266,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units
-    const float scale2 = a.scale * 1.4426950408889634f;   // softmax in base 2: one v_exp_f32 per element
+    float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units (Q is pre-scaled by log2(e)/sqrt(hd))
 
     // DMA sources.  K rounds 0-3: plane = i>>1, row = 16*(i&1) + tid/16, stored chunk tid&15.
     //               V rounds 4-7: plane = (i-4)>>1, row = 64*(i&1) + tid/4, stored chunk tid&3.
@@ -309,32 +319,28 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         const half_t* Vh = Kh + 2 * ATT_KPLANE;
         const half_t* Vl = Vh + ATT_VPLANE;
 
-        f32x16 sm, sc;
+        f32x16 sm;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            sm[r] = 0.f;
-            sc[r] = 0.f;
-        }
+        for (int r = 0; r < 16; ++r) sm[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int ok = kbase + (((2 * ks + hi) ^ kx) << 3);
             const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + ok);
             const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + ok);
             sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sc, 0, 0, 0);
-            sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sc, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sm, 0, 0, 0);
             // keep at most two steps of K fragments in flight: hoisting all 16 ds_reads costs 64 VGPRs and spills
             if (ks & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        float tmax = -INFINITY;
+        if (kt == ntiles - 1) {                  // only the last tile can hold keys past S
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = fmaf(sc[r], kLoInv, sm[r]) * scale2;
-            const int key = kt * KT + frag_row(r, hi);
-            s = key < S ? s : -INFINITY;
-            sm[r] = s;
-            tmax = fmaxf(tmax, s);
+            for (int r = 0; r < 16; ++r)
+                if (kt * KT + frag_row(r, hi) >= S) sm[r] = -INFINITY;
         }
+        float tmax = sm[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sm[r]);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -350,15 +356,13 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
         f16x8 ph[2], pl[2];
+        {
+            float pv[16];
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                half_t hh, ll;
-                split_f32(sm[8 * mf + j], hh, ll);
-                ph[mf][j] = hh;
-                pl[mf][j] = ll;
-            }
+            for (int r = 0; r < 16; ++r) pv[r] = sm[r];
+            split8(pv, ph[0], pl[0]);
+            split8(pv + 8, ph[1], pl[1]);
+        }
         if (rescale) {
 #pragma unroll
             for (int n = 0; n < NT; ++n)
@@ -367,9 +371,6 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            f32x16 tc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tc[r] = 0.f;
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 const f16x4 vh0 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][0]);
@@ -379,11 +380,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
                 const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
-                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], tc, 0, 0, 0);
-                tc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], tc, 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], ot[n], 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], ot[n], 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[n][r] = fmaf(tc[r], kLoInv, ot[n][r]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -30,6 +30,11 @@ __device__ __forceinline__ void split_f32(float v, half_t& hi, half_t& lo) {
     hi = (half_t)v;
     lo = (half_t)((v - (float)hi) * kLoScale);
 }
+// attention operands: residual kept unscaled (subnormal fp16 is exact in the MFMA; see attn_f16x3.hpp)
+__device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& lo) {
+    hi = (half_t)v;
+    lo = (half_t)(v - (float)hi);
+}
 
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
@@ -46,6 +51,7 @@ struct GemmHArgs {
     half_t *Khi, *Klo;        // OUT_QKV: K planes [M, d]
     half_t *Vthi, *Vtlo;      // OUT_QKV: V planes [M, d] (row-major; transposed afterwards by v_transpose_kernel)
     int d, hd, S, Spad;
+    float qscale;             // OUT_QKV: Q is stored pre-multiplied by log2(e)/sqrt(head_dim)
     const float* hyp;         // EPI_CSL (see gemm_f32.hpp)
     const float* thyp;
     int hyp_ld, goff, boff;
@@ -129,7 +135,12 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     g.C[(size_t)m * g.ldc + n] = v;
                 } else {
                     half_t h, l;
-                    split_f32(v, h, l);
+                    if (OUT == OUT_QKV) {
+                        if (part == 0) v *= g.qscale;
+                        split_f32_unscaled(v, h, l);
+                    } else {
+                        split_f32(v, h, l);
+                    }
                     overflow |= !(fabsf(v) <= kHalfMax);
                     if (OUT == OUT_SPLIT) {
                         const size_t o = blk_index(m, n, g.N);
@@ -610,17 +621,17 @@ __global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* o
 // packed fp32 QKV [M, 3d] -> Q/K planes [M, d] + V^T planes [nseq][nhead][hd][Spad] (diagnostics; the pipeline
 // gets these straight from the QKV GEMM epilogue)
 __global__ void qkv_to_planes_kernel(const float* qkv, half_t* qh, half_t* ql, half_t* kh, half_t* kl, half_t* vth,
-                                     half_t* vtl, size_t M, int d, int hd, int S, int Spad) {
+                                     half_t* vtl, size_t M, int d, int hd, int S, int Spad, float qscale) {
     const size_t n = M * d;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t m = i / d;
         const int c = (int)(i % d);
         half_t h, l;
-        split_f32(qkv[m * 3 * d + c], h, l);
+        split_f32_unscaled(qkv[m * 3 * d + c] * qscale, h, l);
         qh[i] = h; ql[i] = l;
-        split_f32(qkv[m * 3 * d + d + c], h, l);
+        split_f32_unscaled(qkv[m * 3 * d + d + c], h, l);
         kh[i] = h; kl[i] = l;
-        split_f32(qkv[m * 3 * d + 2 * d + c], h, l);
+        split_f32_unscaled(qkv[m * 3 * d + 2 * d + c], h, l);
         const size_t seq = m / S, key = m % S;
         const int head = c / hd, vc = c % hd;
         const size_t o = ((seq * (d / hd) + head) * hd + vc) * Spad + key;

@@ -415,7 +415,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
             if (joint) {
                 g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl; g.Vthi = sb.Vh; g.Vtlo = sb.Vl;
-                g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad;
+                g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad; g.qscale = att_scale * 1.4426950408889634f;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_QKV>(h, KC_GEMM_QKV, g))) return rc;
                 {
                     ProfScope ps(h, KC_VTRANS);
@@ -1108,7 +1108,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
             tmp.push_back(b[i]);
         }
         hipLaunchKernelGGL(qkv_to_planes_kernel, dim3(512), dim3(256), 0, h->stream, dQ, b[0], b[1], b[2], b[3], b[4],
-                           b[5], Mt, d, hd, S, Spad);
+                           b[5], Mt, d, hd, S, Spad, 1.4426950408889634f / sqrtf((float)hd));
         AttnHArgs aa{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], S, Spad, d, h->nhead, 1.0f / sqrtf((float)hd),
                      h->range_flag};
         {
