@@ -231,7 +231,7 @@ constexpr int ATT_VPLANE = 128 * 32;                        // halfs per V^T pla
 constexpr int ATT_STAGE = 2 * ATT_KPLANE + 2 * ATT_VPLANE;  // Kh, Kl, Vh, Vl = 32 KB
 constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 
-__global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt) {
+__global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char att_lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(att_lds_raw);
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                      // ... and everybody else's; stage (kt+1)&1 is free again
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < ntiles) issue(kt + 1);
-        const half_t* Kh = lds + (kt & 1) * ATT_STAGE;
+        if (kt + 1 < ntiles && !(abl & 1)) issue(kt + 1);   // abl: timing ablations (diagnostics only)
+        const half_t* Kh = lds + ((abl & 1) ? 0 : (kt & 1)) * ATT_STAGE;
         const half_t* Kl = Kh + ATT_KPLANE;
         const half_t* Vh = Kh + 2 * ATT_KPLANE;
         const half_t* Vl = Vh + ATT_VPLANE;
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         f32x16 sm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+        if (!(abl & 8))
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int ok = kbase + (((2 * ks + hi) ^ kx) << 3);
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             // keep at most two steps of K fragments in flight: hoisting all 16 ds_reads costs 64 VGPRs and spills
             if (ks & 1) __builtin_amdgcn_sched_barrier(0);
         }
+        if (!(abl & 2)) {
         if (kt == ntiles - 1) {                  // only the last tile can hold keys past S
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -355,6 +357,13 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         psum += __shfl_xor(psum, 32, 64);
         l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
+        if (rescale) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
+        }
+        }
         f16x8 ph[2], pl[2];
         {
             float pv[16];
@@ -363,12 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             split8(pv, ph[0], pl[0]);
             split8(pv + 8, ph[1], pl[1]);
         }
-        if (rescale) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
-        }
+        if (!(abl & 4))
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     }
 }
 
+static int g_attn_abl = 0;        // timing ablation bits (diagnostics)
 static int g_attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
 
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, hipStream_t st) {
@@ -426,7 +431,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
             attr_set = true;
         }
         const int nqt = (a.S + 127) / 128;
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel, dim3(nqt * a.nhead * nseq), dim3(256), ATT_DMA_LDS, st, a, nqt);
+        hipLaunchKernelGGL(attn_f16x3_dma_kernel, dim3(nqt * a.nhead * nseq), dim3(256), ATT_DMA_LDS, st, a, nqt, g_attn_abl);
         return hipGetLastError();
     }
     dim3 grid((a.S + 127) / 128, a.nhead, nseq);

@@ -39,6 +39,7 @@ __device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& 
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
 static int g_gemm_h_variant = 0;  // tuning knob (jmid_set_tuning)
+static int g_gemm_ng = 0;         // N-tiles per L2 group (0 = auto)
 
 struct GemmHArgs {
     const half_t *Ahi, *Alo;  // [M, K] in the blocked panel layout (common.hpp::blk_index), rows padded to 128
@@ -424,7 +425,7 @@ constexpr int DMA2_STAGE = 6 * DMA_PLANE;                 // Ahi(2 images), Alo(
 constexpr size_t DMA2_LDS_BYTES = size_t(DMA2_STAGES) * DMA2_STAGE * sizeof(half_t);
 
 template <int EPI, int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, int ntm, int ntn) {
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, int ntm, int ntn, int ng_req) {
     constexpr int WM = 2, WN = 2, BM = 256, BN = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
@@ -434,7 +435,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int NG = (ntn % 4 == 0) ? 4 : (ntn % 3 == 0) ? 3 : (ntn % 2 == 0) ? 2 : 1;
+    const int NG = (ng_req > 0 && ntn % ng_req == 0) ? ng_req
+                   : (ntn % 4 == 0) ? 4 : (ntn % 3 == 0) ? 3 : (ntn % 2 == 0) ? 2 : 1;
     const int per_group = ntm * NG;
     const int grp = swz / per_group, rem = swz - grp * per_group;
     const int tm = rem / NG, tn = grp * NG + (rem - tm * NG);
@@ -524,7 +526,8 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA2_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn);
+    hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn,
+                       g_gemm_ng);
     return hipGetLastError();
 }
 
@@ -578,6 +581,7 @@ __global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t*
 
 // V planes [nseq*S, d] (token-major, as the QKV GEMM emits them) -> V^T planes [nseq][nhead][hd][Spad]
 // (key-contiguous: the k-operand layout of the PV product).  64x64 tiles through LDS; both planes per block.
+// Within each aligned group of 8 keys, rows whose head-dim index has bit 4 set hold keys [4..7, 0..3].
 // grid = (ceil(S/64), d/64, nseq)
 __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, const half_t* vl, half_t* vth, half_t* vtl,
                                                           int S, int Spad, int d, int hd) {
@@ -600,10 +604,13 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, cons
         const int p = id >> 9, col = (id >> 3) & 63, kc = id & 7;
         const int key = k0 + kc * 8;
         if (key >= Spad) continue;
+        const int cg = c0 + col, head = cg / hd, vc = cg - head * hd;
+        // rows 16 apart would hit the same LDS bank in the PV fragment reads: rows with bit 4 set store the two
+        // 4-key halves of every 8-key chunk swapped (the readers apply the same XOR)
+        const int sw = ((vc >> 4) & 1) * 4;
         f16x8 v;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tile[p][kc * 8 + e][col];
-        const int cg = c0 + col, head = cg / hd, vc = cg - head * hd;
+        for (int e = 0; e < 8; ++e) v[e] = tile[p][kc * 8 + (e ^ sw)][col];
         const size_t o = (((size_t)seq * (d / hd) + head) * hd + vc) * Spad + key;
         *reinterpret_cast<f16x8*>((p ? vtl : vth) + o) = v;
     }
@@ -634,7 +641,7 @@ __global__ void qkv_to_planes_kernel(const float* qkv, half_t* qh, half_t* ql, h
         split_f32_unscaled(qkv[m * 3 * d + 2 * d + c], h, l);
         const size_t seq = m / S, key = m % S;
         const int head = c / hd, vc = c % hd;
-        const size_t o = ((seq * (d / hd) + head) * hd + vc) * Spad + key;
+        const size_t o = ((seq * (d / hd) + head) * hd + vc) * Spad + (key ^ (size_t)(((vc >> 4) & 1) * 4));
         vth[o] = h; vtl[o] = l;
     }
 }

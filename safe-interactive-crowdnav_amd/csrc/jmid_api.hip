@@ -961,6 +961,27 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         g_gemm_h_variant = value;
         return JMID_OK;
     }
+    if (k == "print_occupancy") {   // diagnostics: resident workgroups per CU of the main kernels
+        int n = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f16x3_dma_kernel, 256, ATT_DMA_LDS);
+        fprintf(stderr, "attn_f16x3_dma_kernel: %d workgroups/CU (LDS %zu B)\n", n, ATT_DMA_LDS);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16x3_dma256_kernel<EPI_BIAS, OUT_F32>, 512, DMA2_LDS_BYTES);
+        fprintf(stderr, "gemm_f16x3_dma256_kernel: %d workgroups/CU (LDS %zu B)\n", n, DMA2_LDS_BYTES);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16x3_kernel<2, 2, EPI_BIAS, OUT_F32>, 256,
+                                                     gemm_h_lds_bytes<2, 2>());
+        fprintf(stderr, "gemm_f16x3_kernel<2,2>: %d workgroups/CU (LDS %zu B)\n", n, gemm_h_lds_bytes<2, 2>());
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f32_kernel<128, 4>, 256, 0);
+        fprintf(stderr, "attn_f32_kernel<128,4>: %d workgroups/CU\n", n);
+        return JMID_OK;
+    }
+    if (k == "attn_abl") {     // timing ablations of the attention kernel (results are WRONG; tools/attn_abl.py)
+        g_attn_abl = value;
+        return JMID_OK;
+    }
+    if (k == "gemm_ng") {      // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
+        g_gemm_ng = value;
+        return JMID_OK;
+    }
     if (k == "attn_h_variant") {
         if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "attn_h_variant must be 0..2");
         g_attn_h_variant = value;
