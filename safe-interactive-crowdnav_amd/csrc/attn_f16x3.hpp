@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
                 // keys of this lane-half for MFMA mf: {16mf + 4hi + 0..3, 16mf + 8 + 4hi + 0..3}
-                const int c0 = vrow * VLD + 16 * mf + 4 * hi;
+                const int c0 = vrow * VLD + 16 * mf + 4 * (hi ^ ((vrow >> 4) & 1));
                 const f16x4 vh0 = *reinterpret_cast<const f16x4*>(&Vsh[c0]);
                 const f16x4 vh1 = *reinterpret_cast<const f16x4*>(&Vsh[c0 + 8]);
                 const f16x4 vl0 = *reinterpret_cast<const f16x4*>(&Vsl[c0]);
@@ -225,7 +225,8 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
 // 2-stage ring, the copy of tile t+1 overlapping the MFMAs of tile t (one raw s_barrier per tile, counted vmcnt).
 // LDS rows are unpadded; bank-conflict swizzles live on the DMA source address:
 //   K  tile [32 keys][16 chunks of 16 B]: chunk c of row r stored at c ^ (r & 15)      (conflict-free b128 reads)
-//   V^T tile [128 d][4 chunks of 16 B]  : chunk c of row r stored at c ^ ((r>>2) & 3)  (<= 2-way on the b64 reads)
+//   V^T tile [128 d][4 chunks of 16 B]  : chunk c of row r stored at c ^ ((r>>2) & 3); rows with bit 4 set hold the
+//                                         two 4-key halves of a chunk swapped (v_transpose_kernel) -> conflict-free b64
 constexpr int ATT_KPLANE = 32 * 128;                        // halfs per K plane per stage (8 KB)
 constexpr int ATT_VPLANE = 128 * 32;                        // halfs per V^T plane per stage (8 KB)
 constexpr int ATT_STAGE = 2 * ATT_KPLANE + 2 * ATT_VPLANE;  // Kh, Kl, Vh, Vl = 32 KB
@@ -305,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc) vbase[mf][pc] = l31 * 32 + (((2 * mf + pc) ^ ((l31 >> 2) & 3)) * 8) + 4 * hi;
+        for (int pc = 0; pc < 2; ++pc)
+            vbase[mf][pc] = l31 * 32 + (((2 * mf + pc) ^ ((l31 >> 2) & 3)) * 8) + 4 * (hi ^ ((l31 >> 4) & 1));
 
     const int ntiles = (S + KT - 1) / KT;
     issue(0);
