@@ -185,8 +185,18 @@ def main():
             per[cls] = {"launches": n, "avg_ms": ms / n, "total_ms": ms, "tflops": total_flops / (ms * 1e-3) / 1e12}
         dom = max(per, key=lambda c: per[c]["total_ms"])
         peak = PEAK_TFLOPS[args.precision]
+        traffic = None
+        try:   # PMC-measured HBM bytes per launch of this kernel class (separate rocprofv3 --pmc passes, profiles/)
+            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
+            if dom in pmc and args.precision == "f16x3":
+                launches_per_step = per[dom]["launches"] / (steps50 * args.steps * dims.tf_layer)   # chunks per step
+                tokens_per_launch = E * A * K * H / launches_per_step
+                traffic = pmc[dom]["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(per[dom]["tflops"], 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(per[dom]["tflops"] / peak, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(per[dom]["tflops"] / peak, 4), "traffic": traffic,
+                           "frac_of_split_peak": round(per[dom]["tflops"] * MFMA_PASSES[args.precision] / peak, 4),
                            "mfma_passes_per_product": MFMA_PASSES[args.precision],
                            "flops_per_launch": fl[dom] * steps50 * args.steps / per[dom]["launches"],
                            "avg_launch_ms": round(per[dom]["avg_ms"], 4)}
