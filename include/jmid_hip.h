@@ -137,7 +137,7 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
 /* Implementation knobs for experiments (never needed for correctness).  Keys:
  *   "gemm_h_variant"  F16X3 GEMM kernel: 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged,
- *                     3 = 128x128 LDS-DMA ring, 4 = 256x128 LDS-DMA ring
+ *                     3 = 128x128 LDS-DMA ring, 4 = 256x128 LDS-DMA ring, 5 = 64x64 LDS-DMA ring
  *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
  * Unknown keys return JMID_EINVAL. */
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value);

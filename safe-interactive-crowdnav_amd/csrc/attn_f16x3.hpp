@@ -14,6 +14,8 @@
 // Output : hi/lo planes [nseq*S, d] in the blocked panel layout (operand of the attention out-projection GEMM).
 #pragma once
 #include "common.hpp"
+#include <algorithm>
+
 #include "gemm_f16x3.hpp"
 
 namespace jmid {
@@ -43,6 +45,11 @@ struct AttnHArgs {
     int S, Spad, d, nhead;
     float scale;       // unused by the kernels (Q is pre-scaled); kept for the diagnostics path
     int* range_flag;
+    // split-KV (few sequences, e.g. one scene): the key range is divided over nsplit workgroups per q-tile; each
+    // writes an un-normalised partial O plus its (max, sum) and attn_combine_kernel merges them
+    int nsplit;
+    float* Opart;      // [nsplit][nseq*S][d] fp32
+    float* MLpart;     // [nsplit][nseq*S][nhead][2]
 };
 
 template <int HD>
@@ -242,7 +249,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int qt = swz % nqt, sh = swz / nqt;
+    const int qt = swz % nqt, sh0 = swz / nqt;
+    const int split = sh0 % a.nsplit, sh = sh0 / a.nsplit;
     const int h = sh % a.nhead, seq = sh / a.nhead;
     const int S = a.S, d = a.d;
     const size_t tok0 = (size_t)seq * S;
@@ -309,9 +317,11 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         for (int pc = 0; pc < 2; ++pc)
             vbase[mf][pc] = l31 * 32 + (((2 * mf + pc) ^ ((l31 >> 2) & 3)) * 8) + 4 * (hi ^ ((l31 >> 4) & 1));
 
-    const int ntiles = (S + KT - 1) / KT;
-    issue(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
+    const int ntiles_all = (S + KT - 1) / KT;
+    const int kt_begin = (int)((long)split * ntiles_all / a.nsplit);
+    const int ntiles = (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
+    issue(kt_begin);
+    for (int kt = kt_begin; kt < ntiles; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
         __builtin_amdgcn_s_barrier();                      // ... and everybody else's; stage (kt+1)&1 is free again
         __builtin_amdgcn_sched_barrier(0);
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             if (ks & 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (!(abl & 2)) {
-        if (kt == ntiles - 1) {                  // only the last tile can hold keys past S
+        if (kt == ntiles_all - 1) {              // only the last tile can hold keys past S
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (kt * KT + frag_row(r, hi) >= S) sm[r] = -INFINITY;
@@ -393,6 +403,27 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
     }
 
+    if (a.nsplit > 1) {
+        if (q < S) {
+            const size_t Mtot = (size_t)(gridDim.x / (nqt * a.nhead * a.nsplit)) * S;   // nseq * S
+            const size_t tok = tok0 + q;
+            float* op = a.Opart + ((size_t)split * Mtot + tok) * d + h * HD;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int c0 = n * 32 + 8 * r4 + 4 * hi;
+                    *reinterpret_cast<f32x4*>(op + c0) =
+                        f32x4{ot[n][4 * r4 + 0], ot[n][4 * r4 + 1], ot[n][4 * r4 + 2], ot[n][4 * r4 + 3]};
+                }
+            if (hi == 0) {
+                float* ml = a.MLpart + (((size_t)split * Mtot + tok) * a.nhead + h) * 2;
+                ml[0] = m_run;
+                ml[1] = l_run;
+            }
+        }
+        return;
+    }
     if (q < S) {
         const float inv = 1.0f / l_run;
         const int orow = (int)tok0 + q;
@@ -421,6 +452,52 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     }
 }
 
+// merge the nsplit partial results of the split-KV launch: O = sum_i 2^(m_i - M) O_i / sum_i 2^(m_i - M) l_i
+__global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t Mtot, int HD) {
+    const int d = a.d, d4 = d >> 2;
+    const size_t total = Mtot * d4;
+    bool overflow = false;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t tok = idx / d4;
+        const int c = (int)(idx % d4) * 4, h = c / HD;
+        float M = -INFINITY;
+        for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, a.MLpart[(((size_t)i * Mtot + tok) * a.nhead + h) * 2]);
+        float L = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < a.nsplit; ++i) {
+            const float* ml = a.MLpart + (((size_t)i * Mtot + tok) * a.nhead + h) * 2;
+            const float w = __builtin_amdgcn_exp2f(ml[0] - M);
+            L = fmaf(w, ml[1], L);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(a.Opart + ((size_t)i * Mtot + tok) * d + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(w, p[e], o[e]);
+        }
+        const float inv = 1.0f / L;
+        f16x4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = o[e] * inv;
+            half_t hh, ll;
+            split_f32(v, hh, ll);
+            overflow |= !(fabsf(v) <= kHalfMax);
+            vh[e] = hh;
+            vl[e] = ll;
+        }
+        const size_t ob = blk_index((int)tok, c, d);
+        *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
+        *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;
+    }
+    if (overflow) atomicOr(a.range_flag, 1);
+}
+
+// number of key-range splits for a launch with `base_blocks` workgroups: fill ~2 workgroups per CU, >= 4 tiles each
+inline int attn_pick_nsplit(int base_blocks, int S) {
+    const int ntiles = (S + 31) / 32;
+    int ns = 1;
+    while (ns < 8 && base_blocks * ns * 2 <= 512 && ntiles / (ns * 2) >= 4) ns *= 2;
+    return ns;
+}
+
 static int g_attn_abl = 0;        // timing ablation bits (diagnostics)
 static int g_attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
 
@@ -433,7 +510,13 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
             attr_set = true;
         }
         const int nqt = (a.S + 127) / 128;
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel, dim3(nqt * a.nhead * nseq), dim3(256), ATT_DMA_LDS, st, a, nqt, g_attn_abl);
+        hipLaunchKernelGGL(attn_f16x3_dma_kernel, dim3(nqt * a.nhead * nseq * a.nsplit), dim3(256), ATT_DMA_LDS, st, a,
+                           nqt, g_attn_abl);
+        if (a.nsplit > 1) {
+            const size_t Mtot = (size_t)nseq * a.S;
+            const int blocks = (int)std::min<size_t>((Mtot * (a.d / 4) + 255) / 256, 2048);
+            hipLaunchKernelGGL(attn_combine_kernel, dim3(blocks), dim3(256), 0, st, a, Mtot, 128);
+        }
         return hipGetLastError();
     }
     dim3 grid((a.S + 127) / 128, a.nhead, nseq);

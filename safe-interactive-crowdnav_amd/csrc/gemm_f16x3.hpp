@@ -531,16 +531,103 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 64x64 LDS-DMA variant for small M (one scene: M = 1200 tokens): the K loop of a small tile is pure latency, so the
+// 4-stage ring (three 16 KB K-tiles in flight, 64 KB of LDS, two workgroups per CU) matters more here than anywhere.
+// A 64-row half of a 128-row panel image is a contiguous 4 KB piece: one DMA round per plane.
+constexpr int DMA64_PLANE = 64 * 32;
+constexpr int DMA64_STAGE = 4 * DMA64_PLANE;
+constexpr size_t DMA64_LDS_BYTES = size_t(4) * DMA64_STAGE * sizeof(half_t);
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, int ntm, int ntn) {
+    constexpr int WM = 1, WN = 1, BM = 64, BN = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    // consecutive workgroups share the A row-panel (N fastest); XCD-contiguous ranges
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int tm = swz / ntn, tn = swz - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = g.K / GEMMH_BK;
+    const half_t* src[4];
+    src[0] = g.Ahi + ((size_t)(tm >> 1) * nk) * 4096 + (tm & 1) * 2048 + tid * 8;
+    src[1] = g.Alo + ((size_t)(tm >> 1) * nk) * 4096 + (tm & 1) * 2048 + tid * 8;
+    src[2] = g.Whi + ((size_t)(tn >> 1) * nk) * 4096 + (tn & 1) * 2048 + tid * 8;
+    src[3] = g.Wlo + ((size_t)(tn >> 1) * nk) * 4096 + (tn & 1) * 2048 + tid * 8;
+    auto issue = [&](int kt) {
+        half_t* st = lds + (kt & 3) * DMA64_STAGE + wid * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
+                                             (__attribute__((address_space(3))) void*)(st + i * DMA64_PLANE), 16, 0, 0);
+    };
+    f32x16 accm[1][1], accc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accm[0][0][r] = 0.f;
+        accc[0][0][r] = 0.f;
+    }
+    const int rowA = wr * 32 + l31, rowW = wc * 32 + l31;
+    int offA[2], offW[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        offA[ks] = rowA * 32 + (((ks * 2 + hi) ^ ((rowA >> 2) & 3)) * 8);
+        offW[ks] = rowW * 32 + (((ks * 2 + hi) ^ ((rowW >> 2) & 3)) * 8);
+    }
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 3 < nk) issue(kt + 3);
+        const half_t* st = lds + (kt & 3) * DMA64_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[1], al[1], wh[1], wl[1];
+            ah[0] = *reinterpret_cast<const f16x8*>(st + offA[ks]);
+            al[0] = *reinterpret_cast<const f16x8*>(st + DMA64_PLANE + offA[ks]);
+            wh[0] = *reinterpret_cast<const f16x8*>(st + 2 * DMA64_PLANE + offW[ks]);
+            wl[0] = *reinterpret_cast<const f16x8*>(st + 3 * DMA64_PLANE + offW[ks]);
+            mfma3<1, 1>(ah, al, wh, wl, accm, accc);
+        }
+    }
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi, BM, BN);
+}
+
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_h_dma64(const GemmHArgs& g, hipStream_t st) {
+    const int ntm = (g.M + 63) / 64, ntn = (g.N + 63) / 64;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma64_kernel<EPI, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA64_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x3_dma64_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(256), DMA64_LDS_BYTES, st, g, ntm, ntn);
+    return hipGetLastError();
+}
+
 template <int EPI, int OUT>
 inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA
+    // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA,
+    // 5 = 64x64 LDS-DMA
     const int v = g_gemm_h_variant;
     if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
     if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT>(g, st);
     if (v == 3) return launch_gemm_h_dma<EPI, OUT>(g, st);
     if (v == 4) return launch_gemm_h_dma256<EPI, OUT>(g, st);
-    if (big < 256) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
+    if (v == 5) return launch_gemm_h_dma64<EPI, OUT>(g, st);
+    if (big < 256) return launch_gemm_h_dma64<EPI, OUT>(g, st);
     // auto: 256x128 unless the coarser grid quantises badly onto the 256 CUs (one workgroup per CU)
     const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };

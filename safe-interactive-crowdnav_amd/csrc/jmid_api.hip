@@ -290,6 +290,8 @@ struct StepBuffers {
     // F16X3 path: hi/lo planes
     half_t *Xh, *Xl, *Qh, *Ql, *Kh, *Kl, *Vh, *Vl, *Vth, *Vtl, *Ah, *Al, *H1h, *H1l, *Y3h, *Y3l;
     size_t vt_elems;
+    int attn_nsplit;          // split-KV factor of the attention launch (1 = off)
+    float *Opart, *MLpart;
 };
 
 half_t* take_half(Carver& c, size_t n) { return reinterpret_cast<half_t*>(c.take((n + 1) / 2)); }
@@ -330,6 +332,15 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
             s.vt_elems = (size_t)sg.nseq * h->d * sg.Spad;
             s.Vth = take_half(c, s.vt_elems);
             s.Vtl = take_half(c, s.vt_elems);
+            s.attn_nsplit = 1;
+            if (h->d / h->nhead == 128) {
+                const int base_blocks = ((sg.S + 127) / 128) * h->nhead * sg.nseq;
+                s.attn_nsplit = attn_pick_nsplit(base_blocks, sg.S);
+            }
+            if (s.attn_nsplit > 1) {
+                s.Opart = c.take((size_t)s.attn_nsplit * Mc * h->d);
+                s.MLpart = c.take((size_t)s.attn_nsplit * Mc * h->nhead * 2);
+            }
         } else {
             s.QKV = c.take(Mc * 3 * h->d);  // iMID: sequences of T tokens, exact-fp32 attention kernel
         }
@@ -424,8 +435,11 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                     HIPCHK(h, hipGetLastError());
                 }
                 ProfScope ps(h, KC_ATTN);
+                int ns = 1;
+                if (hd == 128) ns = attn_pick_nsplit(((S + 127) / 128) * h->nhead * nseq, S);
+                if (ns > sb.attn_nsplit) ns = sb.attn_nsplit;   // workspace was sized for the full chunk
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
-                             att_scale, h->range_flag};
+                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart};
                 HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
             } else {
                 g.C = sb.QKV; g.ldc = 3 * d;
@@ -957,7 +971,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     if (!h || !key) return JMID_EINVAL;
     const std::string k(key);
     if (k == "gemm_h_variant") {
-        if (value < 0 || value > 4) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..4");
+        if (value < 0 || value > 5) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..5");
         g_gemm_h_variant = value;
         return JMID_OK;
     }
@@ -1130,8 +1144,17 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
         }
         hipLaunchKernelGGL(qkv_to_planes_kernel, dim3(512), dim3(256), 0, h->stream, dQ, b[0], b[1], b[2], b[3], b[4],
                            b[5], Mt, d, hd, S, Spad, 1.4426950408889634f / sqrtf((float)hd));
+        int ns = 1;
+        float *opart = nullptr, *mlpart = nullptr;
+        if (hd == 128) ns = attn_pick_nsplit(((S + 127) / 128) * h->nhead * nseq, S);
+        if (ns > 1) {
+            HIPCHK(h, hipMalloc((void**)&opart, (size_t)ns * Mt * d * 4));
+            HIPCHK(h, hipMalloc((void**)&mlpart, (size_t)ns * Mt * h->nhead * 2 * 4));
+            tmp.push_back(reinterpret_cast<half_t*>(opart));
+            tmp.push_back(reinterpret_cast<half_t*>(mlpart));
+        }
         AttnHArgs aa{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], S, Spad, d, h->nhead, 1.0f / sqrtf((float)hd),
-                     h->range_flag};
+                     h->range_flag, ns, opart, mlpart};
         {
             ProfScope ps(h, KC_ATTN);
             hipError_t e = launch_attn_f16x3(aa, nseq, hd, h->stream);

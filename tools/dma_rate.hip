@@ -8,7 +8,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(const char* src, size_t bytes_pe
     const int tid = threadIdx.x, wid = tid >> 6;
     const char* base = src + (size_t)blockIdx.x * bytes_per_block;
     const size_t tile = (size_t)WAVES * 8 * 1024;
-    const int ntile = (int)(bytes_per_block / tile);
+    const int ntile = bytes_per_block ? (int)(bytes_per_block / tile) : 2;
     auto issue = [&](int t) {
         const char* s = base + (size_t)(t % ntile) * tile + wid * 8192 + (tid & 63) * 16;
         char* d = lds + ((t % (INFLIGHT + 1)) * WAVES + wid) * 8192;
@@ -47,6 +47,9 @@ int main() {
     char* buf; size_t total = (size_t)2 << 30; hipMalloc(&buf, total); hipMemset(buf, 1, total);
     // L2-resident: every block re-reads the same small region (64 KB / block -> 16 MB total for 256 blocks)
     run<4, 2>("4 waves, 2 tiles in flight, 64 KB/block (L2)", buf, 65536, 256, 4000);
+    // every workgroup streams the SAME region (stride 0): the GEMM's W panel / attention's K,V pattern
+    run<4, 2>("SHARED 64 KB region, all 256 blocks", buf, 0, 256, 4000);
+    run<4, 2>("SHARED 64 KB region, 512 blocks", buf, 0, 512, 4000);
     run<4, 3>("4 waves, 3 tiles in flight, 64 KB/block (L2)", buf, 65536, 256, 4000);
     run<8, 2>("8 waves, 2 tiles in flight, 128 KB/block (L2)", buf, 131072, 256, 2000);
     run<4, 2>("4 waves x2 blocks/CU, 64 KB/block (L2)", buf, 65536, 512, 4000);
