@@ -213,6 +213,71 @@ def build_scene(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float, ho
                       cv_forecasts=cv, robot_in_cluster=bool(in_mask[0]))
 
 
+# --------------------------------------------------------------------------------------------- batched builder
+def build_scenes_batched(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float,
+                         force_all_in_cluster: bool = False) -> Dict[str, np.ndarray]:
+    """``build_scene`` for E independent episodes at once (no Python loop over episodes): the feed of the
+    256-4096-episode evaluation sweeps.
+
+    human_xy [E, F, N, 2], robot_xy [E, F, 2].  Every pedestrian gets a row; ``in_cluster`` [E, N] tells which rows
+    the reference would have sent through the network (the others get constant-velocity forecasts there).
+    Returns x, x_st [E, N, F, 6], nbr_sum [E, N, 2, F, 6], edge_mask [E, N, 2], p0 [E, N, 2] (all float32),
+    in_cluster [E, N] bool, robot_in_cluster [E] bool.  Rows outside the cluster are computed as if they had no
+    neighbours in the graph (they are not graph nodes in the reference).  Bit-identical to ``build_scene`` per episode.
+    """
+    E, F, N, _ = human_xy.shape
+    dt = time_step
+    pos = np.concatenate([robot_xy[:, :, None, :], human_xy], axis=2)              # [E, F, N+1, 2], robot first
+    last = pos[:, -1]                                                              # [E, N+1, 2]
+    d_last = np.sqrt(np.square(last[:, :, None] - last[:, None, :]).sum(-1))
+    near = d_last < ATTENTION_RADIUS
+    if force_all_in_cluster:
+        inc = np.ones((E, N + 1), dtype=bool)
+    else:
+        means = (near.astype(np.float64) @ last) / near.sum(axis=2, keepdims=True)
+        rdist = np.linalg.norm(means - last[:, :1], axis=2)
+        chosen = np.argmin(rdist[:, 1:], axis=1) + 1
+        inc = near[np.arange(E), chosen]                                           # [E, N+1]
+    # node states [E, N+1, F, 6] by first differences (first element duplicated)
+    P = pos.transpose(0, 2, 1, 3)                                                  # [E, N+1, F, 2]
+
+    def deriv(a):
+        dd = np.diff(a, axis=2) / dt
+        return np.concatenate([dd[:, :, :1], dd], axis=2)
+
+    V = deriv(P)
+    A_ = deriv(V)
+    S = np.concatenate([P, V, A_], axis=3)                                         # [E, N+1, F, 6]
+    # temporal scene graph over the last three frames, in-cluster nodes only
+    P3 = P[:, :, F - 3:F].transpose(0, 2, 1, 3)                                    # [E, 3, N+1, 2]
+    d3 = np.sqrt(np.square(P3[:, :, :, None] - P3[:, :, None, :]).sum(-1))         # [E, 3, n, n]
+    types = np.full(N + 1, float(TYPE_VALUE_PED))
+    types[0] = float(TYPE_VALUE_ROBOT)
+    tmat = np.tile(types[None, :], (N + 1, 1))
+    np.fill_diagonal(tmat, 0)
+    pair_in = (inc[:, :, None] & inc[:, None, :]).astype(np.float64)               # [E, n, n]
+    adj3 = (d3 <= ATTENTION_RADIUS).astype(np.float64) * tmat[None, None] * pair_in[:, None]
+    f = EDGE_ADDITION_FILTER
+    scal = np.minimum(f[0] * adj3[:, 2] + f[1] * adj3[:, 1] + f[2] * adj3[:, 0], 1.0)
+    scal = np.where(adj3[:, 2] == 0, 0.0, scal)                                    # [E, n, n]
+    conn = scal > 1e-2
+    xs = S[:, 1:]                                                                   # pedestrians [E, N, F, 6]
+    rel = np.zeros((E, N, 1, 6))
+    rel[:, :, 0, 0:2] = xs[:, :, -1, 0:2]
+    x_st = (xs - rel) / STATE_STD
+    em = np.minimum((scal[:, 1:] * conn[:, 1:]).astype(np.float32).sum(axis=2, dtype=np.float32), np.float32(1.0))
+    edge_mask = np.repeat(em[:, :, None], 2, axis=2).astype(np.float32)
+    nbr_sum = np.zeros((E, N, 2, F, 6), dtype=np.float32)
+    ego_now = xs[:, :, -1:, :]                                                      # [E, N, 1, 6]
+    for j in range(N + 1):                                                          # neighbours in node order
+        relj = ((S[:, j][:, None] - ego_now) / STATE_STD).astype(np.float32)        # [E, N, F, 6]
+        w = conn[:, 1:, j].astype(np.float32)[:, :, None, None]
+        e_idx = 1 if j == 0 else 0                                                  # robot -> edge type PED->ROBOT
+        nbr_sum[:, :, e_idx] = nbr_sum[:, :, e_idx] + relj * w
+    return dict(x=xs.astype(np.float32), x_st=x_st.astype(np.float32), nbr_sum=nbr_sum, edge_mask=edge_mask,
+                p0=xs[:, :, -1, 0:2].astype(np.float32), in_cluster=inc[:, 1:], robot_in_cluster=inc[:, 0])
+
+
 # --------------------------------------------------------------------------------------------- synthetic feeds
 def synthetic_episodes(E: int, N: int, seed: int, time_step: float = 0.25, num_hist_frames: int = 6,
                        horizon: int = 12) -> Dict[str, np.ndarray]:
@@ -220,17 +285,13 @@ def synthetic_episodes(E: int, N: int, seed: int, time_step: float = 0.25, num_h
     vel ~ U(-0.5,0.5)^2 m/s, 7 frames at dt (6 kept), robot at (0,-3) + 0.2 t y; all agents forced into the
     cluster (A = N).  Returns stacked encoder inputs and the constant-velocity ground truth."""
     rng = np.random.default_rng(seed)
-    xs, xst, nb, em, p0, gt = [], [], [], [], [], []
-    for _ in range(E):
-        pos0 = rng.uniform(-2.0, 2.0, (N, 2))
-        vel = rng.uniform(-0.5, 0.5, (N, 2))
-        t = np.arange(num_hist_frames + 1) * time_step
-        hum = pos0[None] + vel[None] * t[:, None, None]
-        rob = np.array([0.0, -3.0])[None] + np.array([0.0, 0.2])[None] * t[:, None]
-        sb = build_scene(hum[-num_hist_frames:], rob[-num_hist_frames:], time_step, horizon, num_hist_frames,
-                         force_all_in_cluster=True)
-        xs.append(sb.x); xst.append(sb.x_st); nb.append(sb.nbr_sum); em.append(sb.edge_mask); p0.append(sb.p0)
-        steps = (np.arange(horizon) + 1)[None, :, None] * time_step
-        gt.append((hum[-1][:, None, :] + vel[:, None, :] * steps).astype(np.float32))
-    return dict(x=np.stack(xs), x_st=np.stack(xst), nbr_sum=np.stack(nb), edge_mask=np.stack(em),
-                p0=np.stack(p0), gt=np.stack(gt))
+    pos0 = rng.uniform(-2.0, 2.0, (E, N, 2))
+    vel = rng.uniform(-0.5, 0.5, (E, N, 2))
+    t = np.arange(num_hist_frames + 1) * time_step
+    hum = pos0[:, None] + vel[:, None] * t[None, :, None, None]                    # [E, F+1, N, 2]
+    rob = np.array([0.0, -3.0])[None, None] + np.array([0.0, 0.2])[None, None] * t[None, :, None]
+    rob = np.broadcast_to(rob, (E, num_hist_frames + 1, 2))
+    b = build_scenes_batched(hum[:, -num_hist_frames:], rob[:, -num_hist_frames:], time_step, force_all_in_cluster=True)
+    steps = (np.arange(horizon) + 1)[None, None, :, None] * time_step
+    gt = (hum[:, -1][:, :, None, :] + vel[:, :, None, :] * steps).astype(np.float32)
+    return dict(x=b["x"], x_st=b["x_st"], nbr_sum=b["nbr_sum"], edge_mask=b["edge_mask"], p0=b["p0"], gt=gt)

@@ -72,3 +72,25 @@ def test_reference_state_import():
         mods[name] = m
     w2 = JMIDWeights.from_reference_state(dims, net_state, mods)
     assert w2.checksum() == w.checksum()
+
+
+def test_mpc_glue_matches_caller_arithmetic():
+    """same arithmetic as SICNavAcados.predict (sicnav_acados.py:1644-1667), written there with
+    einops and per-human loops."""
+    import einops
+    from safe_interactive_crowdnav_amd.mpc_glue import mpc_forecast_inputs
+
+    rng = np.random.default_rng(0)
+    N, k, H, horiz, dt = 3, 15, 8, 5, 0.25
+    top = rng.standard_normal((N, k, H + 1, 2))
+    w = np.log(rng.dirichlet(np.ones(k)))[None].repeat(N, axis=0)
+    out = mpc_forecast_inputs(top, w, horiz, dt, joint=True)
+    forecasts = top[:, :, 1:, :]
+    np.testing.assert_array_equal(out.samples_by_stage,
+                                  einops.rearrange(forecasts, "h s t d -> t (h s) d")[: horiz + 1, :, :])
+    np.testing.assert_array_equal(out.init_weights, w[0, :])
+    for h in range(N):
+        assert out.goal_xy[h, 0] == pytest.approx(np.mean(forecasts[h, :, 0, 0]))
+        assert out.goal_xy[h, 1] == pytest.approx(np.mean(forecasts[h, :, 0, 1]))
+        assert out.v_pref[h] == pytest.approx(np.max(np.linalg.norm(np.diff(forecasts[h], axis=1), axis=2) / dt))
+    assert mpc_forecast_inputs(top, w, horiz, dt, joint=False).init_weights.shape == (N, k)

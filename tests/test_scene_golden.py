@@ -61,3 +61,37 @@ def test_short_history_raises():
     h, r, _ = SC.frame_table(prev, rob, 0.25, 6)
     with pytest.raises(SC.HistoryTooShortError):
         SC.build_scene(h, r, 0.25, 12, 6)
+
+
+@pytest.mark.parametrize("force", [True, False])
+def test_batched_builder_matches_per_episode_builder(force):
+    """the vectorised multi-episode builder is bit-identical to build_scene per episode
+    (which is itself pinned to the reference captures above)."""
+    rng = np.random.default_rng(7)
+    E, F, N = 40, 6, 5
+    pos0 = rng.uniform(-3.5, 3.5, (E, N, 2))
+    vel = rng.uniform(-1.0, 1.0, (E, N, 2))
+    t = np.arange(F) * 0.25
+    hum = pos0[:, None] + vel[:, None] * t[None, :, None, None] + 0.01 * rng.standard_normal((E, F, N, 2))
+    rob = rng.uniform(-3, 3, (E, 1, 2)) + np.array([0.0, 0.2])[None, None] * t[None, :, None]
+    b = SC.build_scenes_batched(hum, rob, 0.25, force_all_in_cluster=force)
+    n_checked = 0
+    for e in range(E):
+        sb = SC.build_scene(hum[e], rob[e], 0.25, 12, F, force_all_in_cluster=force)
+        ids = sb.ids_in
+        np.testing.assert_array_equal(np.nonzero(b["in_cluster"][e])[0], ids)
+        assert bool(b["robot_in_cluster"][e]) == sb.robot_in_cluster
+        for key in ("x", "x_st", "nbr_sum", "edge_mask", "p0"):
+            np.testing.assert_array_equal(b[key][e][ids], getattr(sb, key), err_msg=f"episode {e} {key}")
+        n_checked += len(ids)
+    assert n_checked > E            # clusters are non-trivial
+
+
+def test_synthetic_episodes_shapes_and_determinism():
+    a = SC.synthetic_episodes(6, 5, seed=3)
+    b = SC.synthetic_episodes(6, 5, seed=3)
+    assert a["x_st"].shape == (6, 5, 6, 6) and a["nbr_sum"].shape == (6, 5, 2, 6, 6) and a["gt"].shape == (6, 5, 12, 2)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    # constant-velocity histories: ground truth continues the last frame
+    np.testing.assert_allclose(a["gt"][:, :, 0] - a["p0"], (a["x"][:, :, -1, 2:4] * 0.25), atol=1e-5)
