@@ -155,3 +155,21 @@ def test_f16x3_reports_range_overflow_instead_of_garbage():
     assert ei.value.code == -5
     vel, _ = eng.denoise(x_T.numpy(), ctx.numpy(), precision="f32", want_pos=False)   # fp32 path still answers
     assert np.isfinite(vel).all()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_dense_crowd_shape_matches_oracle(precision):
+    """BASELINE configs[3] geometry (N=25 humans) at a sample count the oracle finishes quickly (K=6 -> one JMID
+    sequence of 1800 tokens), ragged against every tile size (1800 = 14*128 + 8), 5 DDIM steps."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(5)
+    E, A, K, T = 2, 25, 6, 12
+    g = torch.Generator().manual_seed(11)
+    ctx = torch.randn([E, A, 256], generator=g)
+    x_T = torch.randn([E, K * A, T, 2], generator=g)
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx, x_T, sample=K, step=5, joint=True)
+    vel, _ = eng.denoise(x_T.numpy(), ctx.numpy(), precision=precision, want_pos=False)
+    a = ade(vel, ref.numpy())
+    print(f"dense crowd [{precision}] mean ADE vs oracle = {a:.3e}")
+    assert a <= ADE_GATE
