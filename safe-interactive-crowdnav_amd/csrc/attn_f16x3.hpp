@@ -334,17 +334,26 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         f32x16 sm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
-        if (!(abl & 8))
+        if (!(abl & 8)) {
+            // software-pipelined fragment reads: the K fragments of step ks+1 are requested before the MFMAs of step
+            // ks issue, so the LDS latency hides under 96 cycles of MFMA instead of stalling the pipe every step
+            f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + kbase + (((0 + hi) ^ kx) << 3));
+            f16x8 kl_c = *reinterpret_cast<const f16x8*>(Kl + kbase + (((0 + hi) ^ kx) << 3));
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            const int ok = kbase + (((2 * ks + hi) ^ kx) << 3);
-            const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + ok);
-            const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + ok);
-            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], sm, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], sm, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], sm, 0, 0, 0);
-            // keep at most two steps of K fragments in flight: hoisting all 16 ds_reads costs 64 VGPRs and spills
-            if (ks & 1) __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < NKS; ++ks) {
+                f16x8 kh_n = kh_c, kl_n = kl_c;
+                if (ks + 1 < NKS) {
+                    const int ok = kbase + (((2 * (ks + 1) + hi) ^ kx) << 3);
+                    kh_n = *reinterpret_cast<const f16x8*>(Kh + ok);
+                    kl_n = *reinterpret_cast<const f16x8*>(Kl + ok);
+                }
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[ks], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_c, qh[ks], sm, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                kh_c = kh_n;
+                kl_c = kl_n;
+            }
         }
         if (!(abl & 2)) {
         if (kt == ntiles_all - 1) {              // only the last tile can hold keys past S
@@ -384,22 +393,31 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             split8(pv, ph[0], pl[0]);
             split8(pv + 8, ph[1], pl[1]);
         }
-        if (!(abl & 4))
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-#pragma unroll
-            for (int mf = 0; mf < 2; ++mf) {
+        if (!(abl & 4)) {
+            // same pipelining for the V^T fragments: step = (n, mf), 8 steps of three MFMAs
+            auto vload = [&](int step, f16x8& vh, f16x8& vl) {
+                const int n = step >> 1, mf = step & 1;
                 const f16x4 vh0 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][0]);
                 const f16x4 vh1 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][1]);
                 const f16x4 vl0 = *reinterpret_cast<const f16x4*>(Vl + n * 1024 + vbase[mf][0]);
                 const f16x4 vl1 = *reinterpret_cast<const f16x4*>(Vl + n * 1024 + vbase[mf][1]);
-                const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-                const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], ot[n], 0, 0, 0);
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], ot[n], 0, 0, 0);
+                vh = f16x8{vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+                vl = f16x8{vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+            };
+            f16x8 vh_c, vl_c;
+            vload(0, vh_c, vl_c);
+#pragma unroll
+            for (int step = 0; step < 2 * NT; ++step) {
+                f16x8 vh_n = vh_c, vl_n = vl_c;
+                if (step + 1 < 2 * NT) vload(step + 1, vh_n, vl_n);
+                const int n = step >> 1, mf = step & 1;
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, ph[mf], ot[n], 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                vh_c = vh_n;
+                vl_c = vl_n;
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     }
 

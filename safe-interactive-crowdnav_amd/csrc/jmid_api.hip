@@ -926,6 +926,7 @@ int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, con
                   int precision, float* e_out, int mem) {
     if (!h) return JMID_EINVAL;
     if (!e_out) return fail(h, JMID_EINVAL, "null e_out");
+    if (int rc = check_ready(h)) return rc;
     if (step_idx < 0 || step_idx >= (int)h->beta.size()) return fail(h, JMID_EINVAL, "step_idx out of range");
     return run_network(h, E, A, K, T, x, ctx, nullptr, 0.f, precision, step_idx, nullptr, nullptr, e_out, mem);
 }

@@ -1,0 +1,99 @@
+"""C-ABI behaviour on the GPU: sweep metrics kernel, device-pointer encode, error codes, handle lifetime."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from safe_interactive_crowdnav_amd import _lib
+from safe_interactive_crowdnav_amd.engine import JmidEngine, JmidError
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=32), 3), joint=True, step=2)
+    yield e
+    e.close()
+
+
+def test_episode_metrics_match_numpy(eng):
+    rng = np.random.default_rng(0)
+    E, K, A, T = 7, 20, 5, 12
+    pos = rng.standard_normal((E, K, A, T, 2)).astype(np.float32)
+    gt = rng.standard_normal((E, A, T, 2)).astype(np.float32)
+    out = eng.episode_metrics(pos, gt)
+    d = np.linalg.norm(pos.astype(np.float64) - gt[:, None].astype(np.float64), axis=-1)     # [E,K,A,T]
+    ade = d.mean(axis=(2, 3))            # per sample, agent-and-time mean (evaluation.py:20-26 per element)
+    fde = d[..., -1].mean(axis=2)
+    ref = np.stack([ade.mean(1), ade.min(1), fde.mean(1), fde.min(1)], axis=1)
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-6)
+    out_d = eng.episode_metrics(torch.from_numpy(pos).cuda(), torch.from_numpy(gt).cuda())
+    eng.synchronize()
+    np.testing.assert_array_equal(out_d.cpu().numpy(), out)
+
+
+def test_encode_device_pointers_match_host(eng):
+    g = torch.Generator().manual_seed(2)
+    x_st = torch.randn([11, 6, 6], generator=g)
+    nbr = torch.randn([11, 2, 6, 6], generator=g)
+    em = torch.rand([11, 2], generator=g)
+    a = eng.encode(x_st.numpy(), nbr.numpy(), em.numpy())
+    b = eng.encode(x_st.cuda(), nbr.cuda(), em.cuda())
+    eng.synchronize()
+    np.testing.assert_array_equal(b.cpu().numpy(), a)
+
+
+def test_error_codes(eng):
+    ctx = np.zeros((1, 2, 32), np.float32)
+    with pytest.raises(JmidError) as ei:       # T beyond the positional-encoding table (max_len = 24)
+        eng.denoise(np.zeros((1, 4, 25, 2), np.float32), ctx, want_pos=False)
+    assert ei.value.code == -1 and "max_len" in str(ei.value)
+    with pytest.raises(JmidError) as ei:
+        eng.net_eval(np.zeros((1, 4, 4, 2), np.float32), ctx, step_idx=99)
+    assert ei.value.code == -1
+    with pytest.raises(ValueError):
+        eng.denoise(np.zeros((1, 5, 4, 2), np.float32), ctx)          # 5 rows is not a multiple of A = 2
+    with pytest.raises(JmidError):
+        eng.set_tuning("no_such_knob", 1)
+    lib = _lib.load_library()
+    h = _lib.Handle()
+    assert lib.jmid_create(C.byref(h), 0, 7, 32, 3, 4, 6) == -1       # bad net_kind
+    assert lib.jmid_create(C.byref(h), 0, 1, 48, 3, 4, 6) == -1       # ctx_dim not a multiple of 32
+    assert lib.jmid_create(C.byref(h), 99, 1, 32, 3, 4, 6) == -1      # no such device
+
+
+def test_unfinalized_engine_refuses_to_compute():
+    lib = _lib.load_library()
+    h = _lib.Handle()
+    assert lib.jmid_create(C.byref(h), 0, 1, 32, 3, 4, 6) == 0
+    x = np.zeros((1, 2, 4, 2), np.float32)
+    ctx = np.zeros((1, 1, 32), np.float32)
+    out = np.zeros_like(x)
+    rc = lib.jmid_net_eval(h, 1, 1, 2, 4, 0, x.ctypes.data_as(C.c_void_p), ctx.ctypes.data_as(C.c_void_p), 0,
+                           out.ctypes.data_as(C.c_void_p), 0)
+    assert rc == -2 and b"finalize" in lib.jmid_last_error(h)
+    w = np.zeros(5, np.float32)
+    assert lib.jmid_load_weight(h, b"concat1._layer.bias", w.ctypes.data_as(C.c_void_p), 5) == -1    # wrong size
+    assert lib.jmid_load_weight(h, b"nonsense", w.ctypes.data_as(C.c_void_p), 5) == -1
+    assert lib.jmid_finalize_weights(h) == -2                                                        # weights missing
+    assert lib.jmid_destroy(h) == 0
+
+
+def test_two_engines_coexist():
+    """Two handles (e.g. iMID and JMID predictors of two policies) keep separate weights and streams."""
+    w1 = JMIDWeights.from_seed(NetDims(ctx_dim=32), 1)
+    w2 = JMIDWeights.from_seed(NetDims(ctx_dim=32), 2)
+    e1, e2 = JmidEngine(w1, joint=True, step=2), JmidEngine(w2, joint=False, step=2)
+    g = torch.Generator().manual_seed(0)
+    ctx = torch.randn([1, 2, 32], generator=g).numpy()
+    x = torch.randn([1, 6, 4, 2], generator=g).numpy()
+    a1, _ = e1.denoise(x, ctx, want_pos=False)
+    b, _ = e2.denoise(x, ctx, want_pos=False)
+    a2, _ = e1.denoise(x, ctx, want_pos=False)
+    np.testing.assert_array_equal(a1, a2)
+    assert np.abs(a1 - b).max() > 1e-3
+    e1.close()
+    e2.close()
