@@ -92,6 +92,13 @@ int jmid_finalize_weights(jmid_handle_t h);
 int jmid_set_ddim_table(jmid_handle_t h, int n_steps, const float* beta, const float* c_e, const float* c_x,
                         const float* n_x, const float* n_e);
 
+/* DDPM variant of the step table (sampling="ddpm", MID/models/diffusion.py:509-522, flexibility 0):
+ *   c0[i] = 1/sqrt(alpha_t)   c1[i] = (1-alpha_t)/sqrt(1-abar_t)   sigma[i] = sigmas_inflex[t]
+ *   use_noise[i] = (t > 1)    so that  x <- c0*(x - c1*e) + sigma*z   (z = 0 where use_noise is 0).
+ * Installing it switches the handle to DDPM until jmid_set_ddim_table is called again. */
+int jmid_set_ddpm_table(jmid_handle_t h, int n_steps, const float* beta, const float* c0, const float* c1,
+                        const float* sigma, const int* use_noise);
+
 /* Context encoder: Trajectron.get_latent in PREDICT mode
  * (MID/models/trajectron.py:416-454 -> MID/models/encoders/mgcvae.py:505-880).
  *   n_agents   total rows (episodes * agents), any order
@@ -119,6 +126,11 @@ int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* n
  * JMID attention spans all (t, s, a) tokens of ONE episode (block-diagonal over episodes). */
 int jmid_denoise(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, const float* ctx,
                  const float* p0, float dt, int precision, float* vel_out, float* pos_out, int mem);
+
+/* DDPM sampling loop: as jmid_denoise, plus the per-step normal draws the reference takes from the torch generator
+ * after x_T (diffusion.py:509): z [n_steps, E, K*A, T, 2] (the host draws them so the RNG contract is kept). */
+int jmid_denoise_ddpm(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, const float* z, const float* ctx,
+                      const float* p0, float dt, int precision, float* vel_out, float* pos_out, int mem);
 
 /* One evaluation of the denoising net e_theta([x, ctx], beta) for step-table entry `step_idx`
  * (diffusion.py:520); used by the parity tests.  x [E, K*A, T, 2] -> e_out same shape. */

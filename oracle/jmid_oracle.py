@@ -136,8 +136,10 @@ def net_forward(w: Mapping[str, Tensor], x: Tensor, context: Tensor, beta: Tenso
 # --------------------------------------------------------------------------- sampler
 def denoise(w: Mapping[str, Tensor], context: Tensor, x_T: Tensor, *, sample: int, step: int, joint: bool,
             tf_layer: int = 3, nhead: int = 4, sched: Optional[Dict[str, Tensor]] = None,
-            episodes: int = 1) -> Tensor:
-    """DiffusionTraj.sample_sicnav_inference, sampling="ddim" (MID/models/diffusion.py:478-541).
+            episodes: int = 1, sampling: str = "ddim", z: Optional[Tensor] = None) -> Tensor:
+    """DiffusionTraj.sample_sicnav_inference (MID/models/diffusion.py:478-541), sampling="ddim" (:524-528) or
+    "ddpm" (:521-522, flexibility 0: sigma = sigmas_inflex[t]; ``z`` [n_steps, rows, T, 2] are the per-step normal
+    draws of :509, zeros are used for t == 1).
 
     context [A, ctx] (A = agents, or episodes*A_per_episode rows episode-major), x_T [sample*A, T, 2]
     with row r = s*A + a (``context.repeat(sample, 1)``, diffusion.py:496).
@@ -164,14 +166,24 @@ def denoise(w: Mapping[str, Tensor], context: Tensor, x_T: Tensor, *, sample: in
         groups = 1
     batch_size = sample_context.shape[0]
     stride = int(100 / step)
+    step_i = 0
     for t in range(num_steps, 0, -stride):
         alpha_bar = alpha_bars[t]
         alpha_bar_next = alpha_bars[t - stride]
         beta = betas[[t] * batch_size]
         e_theta = net_forward(w, x_t, sample_context, beta, joint=joint, tf_layer=tf_layer, nhead=nhead,
                               seq_groups=groups)
-        x0_t = (x_t - e_theta * (1 - alpha_bar).sqrt()) / alpha_bar.sqrt()
-        x_t = alpha_bar_next.sqrt() * x0_t + (1 - alpha_bar_next).sqrt() * e_theta
+        if sampling == "ddim":
+            x0_t = (x_t - e_theta * (1 - alpha_bar).sqrt()) / alpha_bar.sqrt()
+            x_t = alpha_bar_next.sqrt() * x0_t + (1 - alpha_bar_next).sqrt() * e_theta
+        else:
+            alpha = sched["alphas"].to(dt)[t]
+            sigma = sched["sigmas_inflex"].to(dt)[t]
+            c0 = 1.0 / torch.sqrt(alpha)
+            c1 = (1 - alpha) / torch.sqrt(1 - alpha_bar)
+            zi = z[step_i].reshape(x_t.shape) if t > 1 else torch.zeros_like(x_t)
+            x_t = c0 * (x_t - c1 * e_theta) + sigma * zi
+        step_i += 1
     if multi:
         return x_t.reshape(E, sample, A, -1, 2)
     return x_t.reshape(sample, A, -1, 2)

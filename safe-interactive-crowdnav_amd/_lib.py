@@ -27,6 +27,9 @@ SIGNATURES = {
     "jmid_load_weight": (C.c_int, [Handle, C.c_char_p, C.c_void_p, C.c_size_t]),
     "jmid_finalize_weights": (C.c_int, [Handle]),
     "jmid_set_ddim_table": (C.c_int, [Handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jmid_set_ddpm_table": (C.c_int, [Handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "jmid_denoise_ddpm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "jmid_encode": (C.c_int, [Handle, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "jmid_denoise": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),

@@ -136,6 +136,10 @@ struct OutArgs {
     int M, dl, hyp_ld, goff, boff;
     float c_e, c_x, n_x, n_e;
     RowMap rmap;
+    // DDPM (diffusion.py:521-522): x <- c0*(x - c1*e) + sigma*z ; z == nullptr -> DDIM update above
+    const float* z;      // [M, 2] normal draws of this step (nullptr for t == 1: zeros)
+    int ddpm;
+    float c0, c1, sigma;
 };
 
 // one wave per token
@@ -163,9 +167,15 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a) {
         } else {
             // x0 = (x - e*sqrt(1-abar_t))/sqrt(abar_t) ; x <- sqrt(abar_next)*x0 + sqrt(1-abar_next)*e
             const float x0 = a.x[2 * (size_t)m], x1 = a.x[2 * (size_t)m + 1];
-            const float p0 = (x0 - e0 * a.c_e) / a.c_x, p1 = (x1 - e1 * a.c_e) / a.c_x;
-            a.x[2 * (size_t)m] = a.n_x * p0 + a.n_e * e0;
-            a.x[2 * (size_t)m + 1] = a.n_x * p1 + a.n_e * e1;
+            if (a.ddpm) {
+                const float z0 = a.z ? a.z[2 * (size_t)m] : 0.f, z1 = a.z ? a.z[2 * (size_t)m + 1] : 0.f;
+                a.x[2 * (size_t)m] = a.c0 * (x0 - a.c1 * e0) + a.sigma * z0;
+                a.x[2 * (size_t)m + 1] = a.c0 * (x1 - a.c1 * e1) + a.sigma * z1;
+            } else {
+                const float p0 = (x0 - e0 * a.c_e) / a.c_x, p1 = (x1 - e1 * a.c_e) / a.c_x;
+                a.x[2 * (size_t)m] = a.n_x * p0 + a.n_e * e0;
+                a.x[2 * (size_t)m + 1] = a.n_x * p1 + a.n_e * e1;
+            }
         }
     }
 }

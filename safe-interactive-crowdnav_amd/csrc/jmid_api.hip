@@ -81,8 +81,11 @@ struct jmid_ctx {
     float* lstmT[3][3] = {{nullptr}};  // [hist, edge_ped, edge_robot] x [WihT, WhhT, b]
     float* attW1T = nullptr;
     float* attW2T = nullptr;
-    // ddim table (host)
+    // sampler step table (host): DDIM coefficients, or DDPM ones when ddpm is set
     std::vector<float> beta, c_e, c_x, n_x, n_e;
+    bool ddpm = false;
+    std::vector<float> p_c0, p_c1, p_sigma;
+    std::vector<int> p_noise;
     // workspace arena
     char* arena = nullptr;
     size_t arena_bytes = 0;
@@ -357,7 +360,7 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
 
 // one evaluation of the net on a chunk of whole episodes + (optionally) the DDIM update
 int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, int step_idx, float* x_chunk,
-             const float* hyp_chunk, float* e_out, int precision) {
+             const float* hyp_chunk, float* e_out, int precision, const float* z_chunk = nullptr) {
     const bool split = precision != JMID_PREC_F32;
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
@@ -484,7 +487,15 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         ProfScope ps(h, KC_OUT_DDIM);
         OutArgs oa{sb.Y4, W(h, "linear._layer.weight"), W(h, "linear._layer.bias"), hyp_chunk, thyp, x_chunk, e_out,
                    M, h->dlow, h->hl.total, h->hl.go, h->hl.bo,
-                   h->c_e[step_idx], h->c_x[step_idx], h->n_x[step_idx], h->n_e[step_idx], rm};
+                   h->c_e[step_idx], h->c_x[step_idx], h->n_x[step_idx], h->n_e[step_idx], rm,
+                   nullptr, 0, 0.f, 0.f, 0.f};
+        if (h->ddpm && !e_out) {
+            oa.ddpm = 1;
+            oa.z = h->p_noise[step_idx] ? z_chunk : nullptr;
+            oa.c0 = h->p_c0[step_idx];
+            oa.c1 = h->p_c1[step_idx];
+            oa.sigma = h->p_sigma[step_idx];
+        }
         hipLaunchKernelGGL(out_ddim_kernel, dim3((M + 3) / 4), dim3(256), 0, h->stream, oa);
         HIPCHK(h, hipGetLastError());
     }
@@ -518,7 +529,8 @@ int check_ready(jmid_ctx* h) {
 }
 
 int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, const float* ctx, const float* p0, float dt,
-                int precision, int single_step, float* vel_out, float* pos_out, float* e_out, int mem) {
+                int precision, int single_step, float* vel_out, float* pos_out, float* e_out, int mem,
+                const float* z_in = nullptr) {
     if (int rc = check_ready(h)) return rc;
     if (E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "E, A, K, T must be positive");
     if (T > 24) return fail(h, JMID_EINVAL, "T exceeds the positional-encoding table (max_len=24, diffusion.py:116-118)");
@@ -528,6 +540,8 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         return fail(h, JMID_ERANGE, "a weight exceeds the fp16 range: use JMID_PREC_F32");
     if (!x_in || !ctx) return fail(h, JMID_EINVAL, "null input");
     if (pos_out && !p0) return fail(h, JMID_EINVAL, "pos_out requested without p0");
+    if (single_step < 0 && h->ddpm && !z_in) return fail(h, JMID_EINVAL, "DDPM table installed: use jmid_denoise_ddpm (needs z)");
+    if (single_step < 0 && !h->ddpm && z_in) return fail(h, JMID_EINVAL, "jmid_denoise_ddpm needs jmid_set_ddpm_table");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t R = (size_t)E * K * A, M = R * T, EA = (size_t)E * A;
     const int Ec = pick_chunk(h, E, K * A * T);
@@ -541,6 +555,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         c.take(EA * h->hl.total);      // hyp
         c.take(EA * 2);                // p0
         c.take(M * 2);                 // e / pos staging
+        if (z_in && mem == JMID_MEM_HOST) c.take(M * 2 * h->beta.size());   // DDPM noise
         io_off = c.off;
     }
     const SeqGeom sg_full = seq_geom(h, Ec, A, K, T);
@@ -552,6 +567,12 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     float* hyp = c.take(EA * h->hl.total);
     float* p0_d = c.take(EA * 2);
     float* stage = c.take(M * 2);
+    const float* z_use = z_in;
+    if (z_in && mem == JMID_MEM_HOST) {
+        float* zd = c.take(M * 2 * h->beta.size());
+        HIPCHK(h, hipMemcpyAsync(zd, z_in, M * 2 * h->beta.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        z_use = zd;
+    }
     StepBuffers sb;
     step_ws_floats(h, Mc, precision, sg_full, &sb, h->arena + io_off);
     if (precision == JMID_PREC_F16X3) {
@@ -591,8 +612,10 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
             float* eo = stage + (size_t)e0 * K * A * T * 2;
             if (int rc = net_step(h, sb, ec, A, K, T, single_step, xc, hc, eo, precision)) return rc;
         } else {
-            for (int i = 0; i < n_steps; ++i)
-                if (int rc = net_step(h, sb, ec, A, K, T, i, xc, hc, nullptr, precision)) return rc;
+            for (int i = 0; i < n_steps; ++i) {
+                const float* zc = z_use ? z_use + ((size_t)i * M + (size_t)e0 * K * A * T) * 2 : nullptr;
+                if (int rc = net_step(h, sb, ec, A, K, T, i, xc, hc, nullptr, precision, zc)) return rc;
+            }
         }
     }
     if (single_step >= 0) {
@@ -869,8 +892,33 @@ int jmid_set_ddim_table(jmid_handle_t h, int n_steps, const float* beta, const f
     h->c_x.assign(c_x, c_x + n_steps);
     h->n_x.assign(n_x, n_x + n_steps);
     h->n_e.assign(n_e, n_e + n_steps);
+    h->ddpm = false;
     HIPCHK(h, hipSetDevice(h->device));
     return upload_time_table(h);
+}
+
+int jmid_set_ddpm_table(jmid_handle_t h, int n_steps, const float* beta, const float* c0, const float* c1,
+                        const float* sigma, const int* use_noise) {
+    if (!h || n_steps <= 0 || !beta || !c0 || !c1 || !sigma || !use_noise) return fail(h, JMID_EINVAL, "bad ddpm table");
+    h->beta.assign(beta, beta + n_steps);
+    h->p_c0.assign(c0, c0 + n_steps);
+    h->p_c1.assign(c1, c1 + n_steps);
+    h->p_sigma.assign(sigma, sigma + n_steps);
+    h->p_noise.assign(use_noise, use_noise + n_steps);
+    h->c_e.assign(n_steps, 0.f);
+    h->c_x.assign(n_steps, 1.f);
+    h->n_x.assign(n_steps, 1.f);
+    h->n_e.assign(n_steps, 0.f);
+    h->ddpm = true;
+    HIPCHK(h, hipSetDevice(h->device));
+    return upload_time_table(h);
+}
+
+int jmid_denoise_ddpm(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, const float* z, const float* ctx,
+                      const float* p0, float dt, int precision, float* vel_out, float* pos_out, int mem) {
+    if (!h) return JMID_EINVAL;
+    if (!z) return fail(h, JMID_EINVAL, "null z");
+    return run_network(h, E, A, K, T, x_T, ctx, p0, dt, precision, -1, vel_out, pos_out, nullptr, mem, z);
 }
 
 int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* nbr_sum, const float* edge_mask,

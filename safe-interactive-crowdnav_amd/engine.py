@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import JmidError
-from .schedule import VarianceSchedule, ddim_steps
+from .schedule import VarianceSchedule, ddim_steps, ddpm_steps
 from .weights import JMIDWeights
 
 try:  # torch is optional plumbing here (device tensors in / out)
@@ -85,14 +85,23 @@ class JmidEngine:
         except Exception:
             pass
 
-    def set_step(self, step: int) -> None:
-        """``step`` = the reference's ``step_size`` yaml key: number of DDIM iterations out of 100
-        (stride = int(100/step), MID/models/diffusion.py:507)."""
-        tab = ddim_steps(self.schedule, step)
-        self.step = step
+    def set_step(self, step: int, sampling: str = "ddim") -> None:
+        """``step`` = the reference's ``step_size`` yaml key: number of reverse iterations out of 100
+        (stride = int(100/step), MID/models/diffusion.py:507); ``sampling`` = "ddim" (what the predictor uses,
+        MID/mid.py:333) or "ddpm"."""
+        self.step, self.sampling = step, sampling
+        if sampling == "ddim":
+            tab = ddim_steps(self.schedule, step)
+            cols = [np.array([getattr(s, k) for s in tab], dtype=np.float32) for k in ("beta", "c_e", "c_x", "n_x", "n_e")]
+            self._check(self._lib.jmid_set_ddim_table(self._h, len(tab), *[C.c_void_p(c.ctypes.data) for c in cols]))
+        elif sampling == "ddpm":
+            tab = ddpm_steps(self.schedule, step)
+            cols = [np.array([getattr(s, k) for s in tab], dtype=np.float32) for k in ("beta", "c0", "c1", "sigma")]
+            cols.append(np.array([int(s.noise) for s in tab], dtype=np.int32))
+            self._check(self._lib.jmid_set_ddpm_table(self._h, len(tab), *[C.c_void_p(c.ctypes.data) for c in cols]))
+        else:
+            raise ValueError("sampling must be 'ddim' or 'ddpm'")
         self.n_steps = len(tab)
-        cols = [np.array([getattr(s, k) for s in tab], dtype=np.float32) for k in ("beta", "c_e", "c_x", "n_x", "n_e")]
-        self._check(self._lib.jmid_set_ddim_table(self._h, len(tab), *[C.c_void_p(c.ctypes.data) for c in cols]))
 
     def set_chunk_episodes(self, n: int) -> None:
         self._check(self._lib.jmid_set_chunk_episodes(self._h, int(n)))
@@ -132,8 +141,9 @@ class JmidEngine:
         return E, A, KA // A, T
 
     def denoise(self, x_T: ArrayLike, ctx: ArrayLike, p0: Optional[ArrayLike] = None, dt: float = 0.25,
-                precision: str = "f32", want_vel: bool = True, want_pos: bool = True):
+                precision: str = "f32", want_vel: bool = True, want_pos: bool = True, z: Optional[ArrayLike] = None):
         """Batched reverse-denoising loop.  x_T [E, K*A, T, 2], ctx [E, A, ctx_dim], p0 [E, A, 2].
+        ``z`` [n_steps, E, K*A, T, 2]: per-step normal draws, required when the DDPM table is installed.
         Returns (vel [E,K,A,T,2] or None, pos [E,K,A,T,2] or None)."""
         dev = _is_cuda(x_T)
         E, A, K, T = self._shapes(x_T, ctx)
@@ -151,9 +161,17 @@ class JmidEngine:
 
         vel, vptr = alloc() if want_vel else (None, None)
         pos, pptr = alloc() if want_pos else (None, None)
-        self._check(self._lib.jmid_denoise(self._h, E, A, K, T, bx.ptr, bc.ptr, bp.ptr if bp else None, float(dt),
-                                           _lib.PRECISIONS[precision], vptr, pptr,
-                                           _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        if z is not None:
+            if tuple(z.shape) != (self.n_steps, E, K * A, T, 2):
+                raise ValueError("z must be [n_steps, E, K*A, T, 2]")
+            bz = _Buf(z, dev)
+            self._check(self._lib.jmid_denoise_ddpm(self._h, E, A, K, T, bx.ptr, bz.ptr, bc.ptr, bp.ptr if bp else None,
+                                                    float(dt), _lib.PRECISIONS[precision], vptr, pptr,
+                                                    _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+        else:
+            self._check(self._lib.jmid_denoise(self._h, E, A, K, T, bx.ptr, bc.ptr, bp.ptr if bp else None, float(dt),
+                                               _lib.PRECISIONS[precision], vptr, pptr,
+                                               _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
         return vel, pos
 
     def net_eval(self, x: ArrayLike, ctx: ArrayLike, step_idx: int = 0, precision: str = "f32"):

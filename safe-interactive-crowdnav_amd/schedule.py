@@ -23,6 +23,7 @@ class VarianceSchedule:
     alphas: np.ndarray       # [num_steps+1] f32
     alpha_bars: np.ndarray   # [num_steps+1] f32
     num_steps: int
+    sigmas_inflex: np.ndarray = None   # [num_steps+1] f32 (DDPM, flexibility 0; diffusion.py:41-47)
 
     @classmethod
     def linear(cls, num_steps: int = 100, beta_1: float = 1e-4, beta_T: float = 5e-2) -> "VarianceSchedule":
@@ -33,7 +34,12 @@ class VarianceSchedule:
         for i in range(1, log_alphas.size(0)):
             log_alphas[i] += log_alphas[i - 1]
         alpha_bars = log_alphas.exp()
-        return cls(betas.numpy().copy(), alphas.numpy().copy(), alpha_bars.numpy().copy(), num_steps)
+        sigmas_inflex = torch.zeros_like(betas)
+        for i in range(1, betas.size(0)):
+            sigmas_inflex[i] = ((1 - alpha_bars[i - 1]) / (1 - alpha_bars[i])) * betas[i]
+        sigmas_inflex = torch.sqrt(sigmas_inflex)
+        return cls(betas.numpy().copy(), alphas.numpy().copy(), alpha_bars.numpy().copy(), num_steps,
+                   sigmas_inflex.numpy().copy())
 
 
 @dataclass(frozen=True)
@@ -77,4 +83,30 @@ def ddim_steps(sched: VarianceSchedule, step: int) -> List[DDIMStep]:
                 n_e=np.float32((1 - a_n).sqrt().item()),
             )
         )
+    return out
+
+
+@dataclass(frozen=True)
+class DDPMStep:
+    t: int
+    beta: np.float32
+    c0: np.float32       # 1/sqrt(alpha_t)
+    c1: np.float32       # (1 - alpha_t)/sqrt(1 - abar_t)
+    sigma: np.float32    # sigmas_inflex[t] (flexibility 0)
+    noise: bool          # z ~ N(0,1) is used (t > 1), else zeros     (diffusion.py:509)
+
+
+def ddpm_steps(sched: VarianceSchedule, step: int) -> List[DDPMStep]:
+    """x_next = c0*(x - c1*e) + sigma*z  (``sampling="ddpm"``, diffusion.py:509-522), same step enumeration as DDIM."""
+    if step <= 0:
+        raise ValueError("step must be positive")
+    stride = int(100 / step)
+    if stride <= 0 or sched.num_steps % stride != 0:
+        raise ValueError(f"step={step}: stride {stride} does not divide num_steps={sched.num_steps}")
+    al, ab, sg = (torch.from_numpy(a) for a in (sched.alphas, sched.alpha_bars, sched.sigmas_inflex))
+    out = []
+    for t in range(sched.num_steps, 0, -stride):
+        out.append(DDPMStep(t=t, beta=np.float32(sched.betas[t]), c0=np.float32((1.0 / torch.sqrt(al[t])).item()),
+                            c1=np.float32(((1 - al[t]) / torch.sqrt(1 - ab[t])).item()), sigma=np.float32(sg[t].item()),
+                            noise=t > 1))
     return out

@@ -17,6 +17,7 @@ Fixtures written:
   net_*.npz             one net evaluation + full DDIM loop outputs     (diffusion.py:133-209, 478-541)
   wrapper_*.npz         update_state_hists x n -> batch tensors, ctx (mgcvae.py:505-880), sampled
                         velocities and the predict_ret_best() result            (mid_sim_wrapper.py:198-510)
+  ddpm_*.npz            DDPM sampling branch of the same loop                  (diffusion.py:509-522)
   kde_*.npz             get_most_likely_samples                         (mid_sim_wrapper.py:14-169)
 """
 import collections
@@ -204,6 +205,24 @@ def scenario(kind, N, n_frames, rng, time_step=0.25):
     return out
 
 
+def gen_ddpm_case(tag, ctx_dim, A, K, T, step, joint, wseed, dseed):
+    """sampling="ddpm" (diffusion.py:509-522): the per-step z draws follow x_T on the global CPU generator."""
+    dims = NetDims(ctx_dim=ctx_dim)
+    weights = JMIDWeights.from_seed(dims, wseed)
+    sampler = build_ref_sampler(weights, joint)
+    g = torch.Generator().manual_seed(dseed)
+    ctx = torch.randn([A, ctx_dim], generator=g)
+    torch.manual_seed(dseed)
+    x_T = torch.randn([K * A, T, 2])
+    stride = int(100 / step)
+    zs = [torch.randn_like(x_T) if t > 1 else torch.zeros_like(x_T) for t in range(100, 0, -stride)]
+    torch.manual_seed(dseed)
+    with torch.no_grad():
+        vel, _ = sampler.sample_sicnav_inference(T, ctx, K, True, sampling="ddpm", step=step, with_constraints=False)
+    save(f"ddpm_{tag}.npz", ctx_dim=ctx_dim, A=A, K=K, T=T, step=step, joint=int(joint), wseed=wseed,
+         wsum=weights.checksum(), ctx=np32(ctx), x_T=np32(x_T), z=np32(torch.stack(zs)), vel=np32(vel))
+
+
 def gen_wrapper_case(tag, kind, joint, ctx_dim, N, K, k_ret, H, step, wseed, dseed, n_frames=7,
                      time_jitter=0.0, drop_frame=None):
     f, weights = make_forecaster(joint, ctx_dim, N, K, k_ret, H, step, wseed)
@@ -324,6 +343,9 @@ def main():
         gen_wrapper_case(*c)
     gen_wrapper_case("jmid_jitter", "together", True, 256, 4, 8, 8, 12, 2, 35, 308, n_frames=9, time_jitter=0.04)
     gen_wrapper_case("jmid_gap", "together", True, 256, 4, 8, 8, 12, 2, 35, 309, n_frames=9, drop_frame=6)
+    gen_ddpm_case("jmid_w32_a2k3t4_s10", 32, 2, 3, 4, 10, True, 41, 501)
+    gen_ddpm_case("imid_w32_a3k4t6_s100", 32, 3, 4, 6, 100, False, 42, 502)     # stride 1: last step t = 1 uses z = 0
+    gen_ddpm_case("jmid_w256_a5k20t12_s10", 256, 5, 20, 12, 10, True, 43, 503)
     gen_kde_case("k100_a3_h8", 100, 3, 8, 15, 401)
     gen_kde_case("k40_a5_h12", 40, 5, 12, 10, 402)
 

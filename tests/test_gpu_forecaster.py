@@ -83,3 +83,26 @@ def test_returned_arrays_are_fresh(tmp_path):
     keep = a.copy()
     b, _ = f.predict_ret_best()
     assert a is not b and np.array_equal(a, keep)    # caller-owned results (sicnav_acados.py:1652 stores them)
+
+
+def test_forecaster_falls_back_to_fp32_when_fp16_range_is_exceeded(tmp_path):
+    """Histories a kilometre-scale apart push the standardized inputs and hence activations... not the fp16 range by
+    themselves; force it with weights whose first layer is scaled up, and check that predict_ret_best() still answers
+    (exact-fp32 retry) and equals a forecaster that was asked for fp32 from the start."""
+    z = np.load(os.path.join(GOLDEN, "wrapper_jmid_w32_spread50.npz"))
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=32), int(z["wseed"]))
+    t = dict(w.tensors)
+    t["transformer_encoder.layers.0.linear1.weight"] = t["transformer_encoder.layers.0.linear1.weight"] * 4e4
+    t["transformer_encoder.layers.0.linear2.weight"] = t["transformer_encoder.layers.0.linear2.weight"] / 4e4
+    wbig = JMIDWeights(w.dims, t)
+    outs = []
+    for prec in ("f16x3", "f32"):
+        env, ypath = write_configs(str(tmp_path / prec), joint=True, ctx_dim=32, N=int(z["N"]), K=int(z["K"]),
+                                   k_ret=int(z["k_ret"]), H=int(z["H"]), step=2)
+        f = HumanTrajectoryForecasterSim(env, ypath, weights=wbig, precision=prec)
+        for r, h, tt in zip(z["robot_xy"], z["human_xy"], z["stamps"]):
+            f.update_state_hists(State(r), [State(p) for p in h], float(tt))
+        torch.manual_seed(1)
+        outs.append(f.predict_ret_best()[0])
+    assert np.isfinite(outs[0]).all()
+    np.testing.assert_array_equal(outs[0], outs[1])

@@ -173,3 +173,22 @@ def test_dense_crowd_shape_matches_oracle(precision):
     a = ade(vel, ref.numpy())
     print(f"dense crowd [{precision}] mean ADE vs oracle = {a:.3e}")
     assert a <= ADE_GATE
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "ddpm_*.npz"))))
+def test_ddpm_sampling_matches_reference_golden(case, precision):
+    """sampling="ddpm" (MID/models/diffusion.py:509-522): x <- c0 (x - c1 e) + sigma z with the reference's z draws."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    assert w.checksum() == str(z["wsum"])
+    eng.set_step(int(z["step"]), "ddpm")
+    try:
+        vel, _ = eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False, z=z["z"][:, None])
+        with pytest.raises(Exception):
+            eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False)   # DDPM needs z
+    finally:
+        eng.set_step(int(z["step"]), "ddim")
+    a = ade(vel[0], z["vel"])
+    print(f"{case} [{precision}] DDPM mean ADE vs reference = {a:.3e}")
+    assert a <= ADE_GATE

@@ -95,3 +95,16 @@ def test_kde_topk_matches_reference(case):
     top, lw = O.most_likely_samples(torch.from_numpy(z["forecasts"]), int(z["k_ret"]))
     np.testing.assert_allclose(top.numpy(), z["top"], rtol=0, atol=0)
     np.testing.assert_allclose(lw.numpy(), z["logw"], rtol=1e-5, atol=1e-5)
+
+
+DDPM_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "ddpm_*.npz")))
+
+
+@pytest.mark.parametrize("case", DDPM_CASES)
+def test_ddpm_sampling_matches_reference(case):
+    z = np.load(os.path.join(GOLDEN, case))
+    w = _weights(z).tensors
+    with torch.no_grad():
+        vel = O.denoise(w, torch.from_numpy(z["ctx"]), torch.from_numpy(z["x_T"]), sample=int(z["K"]), step=int(z["step"]),
+                        joint=bool(z["joint"]), sampling="ddpm", z=torch.from_numpy(z["z"]))
+    assert np.linalg.norm(vel.numpy() - z["vel"], axis=-1).mean() <= 5e-6
