@@ -40,6 +40,7 @@ enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
 static int g_gemm_h_variant = 0;  // tuning knob (jmid_set_tuning)
 static int g_gemm_ng = 0;         // N-tiles per L2 group (0 = auto)
+static int g_gemm_abl = 0;        // timing ablation bits of the 256x128 kernel (diagnostics)
 
 struct GemmHArgs {
     const half_t *Ahi, *Alo;  // [M, K] in the blocked panel layout (common.hpp::blk_index), rows padded to 128
@@ -425,7 +426,7 @@ constexpr int DMA2_STAGE = 6 * DMA_PLANE;                 // Ahi(2 images), Alo(
 constexpr size_t DMA2_LDS_BYTES = size_t(DMA2_STAGES) * DMA2_STAGE * sizeof(half_t);
 
 template <int EPI, int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, int ntm, int ntn, int ng_req) {
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, int ntm, int ntn, int ng_req, int abl) {
     constexpr int WM = 2, WN = 2, BM = 256, BN = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
@@ -487,16 +488,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
         for (int ks = 0; ks < 2; ++ks) offW[j][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
     }
 
+    // abl: timing ablations (diagnostics, results wrong): 1 = no fragment reads / MFMA, 2 = fragment reads but no MFMA,
+    //      4 = no DMA after the first two tiles
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (kt + 1 < nk && !(abl & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (stage + 2) % 3
+        if (kt + 2 < nk && !(abl & 4)) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (stage + 2) % 3
         const half_t* st = lds + stage * DMA2_STAGE;
+        if (!(abl & 1))
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 ah[WM], al[WM], wh[WN], wl[WN];
@@ -510,7 +514,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
                 wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
                 wl[j] = *reinterpret_cast<const f16x8*>(st + 5 * DMA_PLANE + offW[j][ks]);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+            if (abl & 2) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(wh[i]), "v"(wl[i]));
+            } else {
+                mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+            }
         }
         stage = stage == 2 ? 0 : stage + 1;
     }
@@ -527,7 +536,7 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn,
-                       g_gemm_ng);
+                       g_gemm_ng, g_gemm_abl);
     return hipGetLastError();
 }
 

@@ -1041,6 +1041,10 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         g_attn_abl = value;
         return JMID_OK;
     }
+    if (k == "gemm_abl") {
+        g_gemm_abl = value;
+        return JMID_OK;
+    }
     if (k == "gemm_ng") {      // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         g_gemm_ng = value;
         return JMID_OK;
