@@ -239,8 +239,24 @@ constexpr int ATT_VPLANE = 128 * 32;                        // halfs per V^T pla
 constexpr int ATT_STAGE = 2 * ATT_KPLANE + 2 * ATT_VPLANE;  // Kh, Kl, Vh, Vl = 32 KB
 constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 
-__global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl) {
+// TRACE (tools/attn_trace.hip only): every wave accumulates s_memtime deltas per phase of the key-tile loop into trace[].
+#define ATT_STAMP(i)                                                  \
+    if (TRACE) {                                                      \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        tacc[i] += now_ - tprev;                                      \
+        tprev = now_;                                                 \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    }
+template <bool TRACE>
+__global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
+    unsigned long long rt0 = 0;
+    if (TRACE) {
+        tstart = tprev = __builtin_amdgcn_s_memtime();
+        rt0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char att_lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(att_lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -285,18 +301,17 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int k_row = tid >> 4, k_c = (tid & 15) ^ (k_row & 15);             // rows 0-15 (+16 for odd rounds)
     const int v_row = tid >> 2, v_c = (tid & 3) ^ ((v_row >> 2) & 3);       // rows 0-63 (+64 for odd rounds)
     const int last_vchunk = a.Spad / 8 - 1;
-    auto issue = [&](int kt) {
+    // one of the 8 DMA wave-instructions of key tile kt (i < 4: K planes, else V^T planes)
+    auto issue_one = [&](int kt, int i) {
         half_t* st = lds + (kt & 1) * ATT_STAGE + wid * 512;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        if (i < 4) {
             int key = kt * KT + 16 * (i & 1) + k_row;
             key = key < S ? key : S - 1;
             const half_t* src = ((i >> 1) ? kl_g : kh_g) + (size_t)key * d + k_c * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        } else {
+            i -= 4;
             const int row = 64 * (i & 1) + v_row;
             int kc = kt * 4 + v_c;
             kc = kc < last_vchunk ? kc : last_vchunk;
@@ -305,6 +320,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                                              (__attribute__((address_space(3))) void*)(st + 2 * ATT_KPLANE + i * 2048), 16,
                                              0, 0);
         }
+    };
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_one(kt, i);
     };
     // fragment read offsets (halfs), kept to a handful of registers:
     //   K : row l31, chunk (2ks+hi) ^ (l31&15)                        -> kbase + (((2ks+hi) ^ kx) << 3)
@@ -321,11 +340,18 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int kt_begin = (int)((long)split * ntiles_all / a.nsplit);
     const int ntiles = (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
     issue(kt_begin);
+    ATT_STAMP(0)   // prologue: Q loads, first DMA issue
     for (int kt = kt_begin; kt < ntiles; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
+        ATT_STAMP(1)
         __builtin_amdgcn_s_barrier();                      // ... and everybody else's; stage (kt+1)&1 is free again
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < ntiles && !(abl & 1)) issue(kt + 1);   // abl: timing ablations (diagnostics only)
+        ATT_STAMP(2)
+        // the DMA of tile kt+1 is issued one wave-instruction per QK^T step below, behind that step's MFMAs: a burst of
+        // 8 right here stalls the wave ~850 cycles per tile in the CU's address path (tools/attn_trace.hip)
+        const bool more = kt + 1 < ntiles && !(abl & 1);    // abl: timing ablations (diagnostics only)
+        if (more && (abl & 16)) issue(kt + 1);
+        ATT_STAMP(3)
         const half_t* Kh = lds + ((abl & 1) ? 0 : (kt & 1)) * ATT_STAGE;
         const half_t* Kl = Kh + ATT_KPLANE;
         const half_t* Vh = Kh + 2 * ATT_KPLANE;
@@ -350,11 +376,13 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[ks], sm, 0, 0, 0);
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_c, qh[ks], sm, 0, 0, 0);
+                if (more && !(abl & 16)) issue_one(kt + 1, ks);
                 __builtin_amdgcn_sched_barrier(0);
                 kh_c = kh_n;
                 kl_c = kl_n;
             }
         }
+        ATT_STAMP(4)
         if (!(abl & 2)) {
         if (kt == ntiles_all - 1) {              // only the last tile can hold keys past S
 #pragma unroll
@@ -393,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             split8(pv, ph[0], pl[0]);
             split8(pv + 8, ph[1], pl[1]);
         }
+        ATT_STAMP(5)
         if (!(abl & 4)) {
             // same pipelining for the V^T fragments: step = (n, mf), 8 steps of three MFMAs
             auto vload = [&](int step, f16x8& vh, f16x8& vl) {
@@ -418,6 +447,19 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 vh_c = vh_n;
                 vl_c = vl_n;
             }
+        }
+        ATT_STAMP(6)
+    }
+    if (TRACE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            unsigned long long* t = trace + ((size_t)blockIdx.x * 4 + wid) * 12;
+            t[10] = rt0;
+            t[11] = __builtin_amdgcn_s_memrealtime();
+            for (int i = 0; i < 7; ++i) t[i] = tacc[i];
+            t[7] = tstart;
+            t[8] = tprev;
+            t[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         }
     }
 
@@ -523,13 +565,13 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
     if (head_dim == 128 && g_attn_h_variant != 1) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
             attr_set = true;
         }
         const int nqt = (a.S + 127) / 128;
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel, dim3(nqt * a.nhead * nseq * a.nsplit), dim3(256), ATT_DMA_LDS, st, a,
-                           nqt, g_attn_abl);
+        hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nqt * a.nhead * nseq * a.nsplit), dim3(256), ATT_DMA_LDS, st,
+                           a, nqt, g_attn_abl, (unsigned long long*)nullptr);
         if (a.nsplit > 1) {
             const size_t Mtot = (size_t)nseq * a.S;
             const int blocks = (int)std::min<size_t>((Mtot * (a.d / 4) + 255) / 256, 2048);

@@ -1026,7 +1026,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     }
     if (k == "print_occupancy") {   // diagnostics: resident workgroups per CU of the main kernels
         int n = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f16x3_dma_kernel, 256, ATT_DMA_LDS);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f16x3_dma_kernel<false>, 256, ATT_DMA_LDS);
         fprintf(stderr, "attn_f16x3_dma_kernel: %d workgroups/CU (LDS %zu B)\n", n, ATT_DMA_LDS);
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f16x3_dma256_kernel<EPI_BIAS, OUT_F32>, 512, DMA2_LDS_BYTES);
         fprintf(stderr, "gemm_f16x3_dma256_kernel: %d workgroups/CU (LDS %zu B)\n", n, DMA2_LDS_BYTES);
