@@ -136,9 +136,10 @@ def net_forward(w: Mapping[str, Tensor], x: Tensor, context: Tensor, beta: Tenso
 # --------------------------------------------------------------------------- sampler
 def denoise(w: Mapping[str, Tensor], context: Tensor, x_T: Tensor, *, sample: int, step: int, joint: bool,
             tf_layer: int = 3, nhead: int = 4, sched: Optional[Dict[str, Tensor]] = None,
-            episodes: int = 1, sampling: str = "ddim", z: Optional[Tensor] = None) -> Tensor:
+            episodes: int = 1, sampling: str = "ddim", z: Optional[Tensor] = None,
+            flexibility: float = 0.0) -> Tensor:
     """DiffusionTraj.sample_sicnav_inference (MID/models/diffusion.py:478-541), sampling="ddim" (:524-528) or
-    "ddpm" (:521-522, flexibility 0: sigma = sigmas_inflex[t]; ``z`` [n_steps, rows, T, 2] are the per-step normal
+    "ddpm" (:521-522, sigma = get_sigmas(t, flexibility) :59-64; ``z`` [n_steps, rows, T, 2] are the per-step normal
     draws of :509, zeros are used for t == 1).
 
     context [A, ctx] (A = agents, or episodes*A_per_episode rows episode-major), x_T [sample*A, T, 2]
@@ -178,7 +179,7 @@ def denoise(w: Mapping[str, Tensor], context: Tensor, x_T: Tensor, *, sample: in
             x_t = alpha_bar_next.sqrt() * x0_t + (1 - alpha_bar_next).sqrt() * e_theta
         else:
             alpha = sched["alphas"].to(dt)[t]
-            sigma = sched["sigmas_inflex"].to(dt)[t]
+            sigma = (sched["sigmas_flex"][t] * flexibility + sched["sigmas_inflex"][t] * (1 - flexibility)).to(dt)
             c0 = 1.0 / torch.sqrt(alpha)
             c1 = (1 - alpha) / torch.sqrt(1 - alpha_bar)
             zi = z[step_i].reshape(x_t.shape) if t > 1 else torch.zeros_like(x_t)
@@ -187,6 +188,30 @@ def denoise(w: Mapping[str, Tensor], context: Tensor, x_T: Tensor, *, sample: in
     if multi:
         return x_t.reshape(E, sample, A, -1, 2)
     return x_t.reshape(sample, A, -1, 2)
+
+
+def sample_offline(w: Mapping[str, Tensor], context: Tensor, num_points: int, sample: int, bestof: bool, *,
+                   step: int, joint: bool, sampling: str = "ddpm", flexibility: float = 0.0, tf_layer: int = 3,
+                   nhead: int = 4, sched: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """DiffusionTraj.sample (MID/models/diffusion.py:544-613), the per-sample loop used by offline evaluation
+    (AutoEncoder.generate, MID/models/autoencoder.py:50-103): every sample is denoised on its own with the
+    ``context`` rows [B, ctx] as the batch (for JMID one attention sequence of B*T tokens per sample, not the
+    K*B*T of sample_sicnav_inference).  Draws from the global torch CPU generator in the reference's order:
+    per sample ``x_T`` (zeros when not ``bestof``, :559-566), then one ``z`` per step (zeros at t == 1, :571;
+    drawn for "ddim" too).  Returns [sample, B, num_points, 2] (``torch.stack(traj_list)``, :603)."""
+    if sched is None:
+        sched = variance_schedule()
+    B = context.shape[0]
+    num_steps = sched["betas"].numel() - 1
+    stride = int(100 / step)
+    out = []
+    for _ in range(sample):
+        x_T = torch.randn([B, num_points, 2]) if bestof else torch.zeros([B, num_points, 2])
+        zs = [torch.randn_like(x_T) if t > 1 else torch.zeros_like(x_T) for t in range(num_steps, 0, -stride)]
+        v = denoise(w, context, x_T.to(context.dtype), sample=1, step=step, joint=joint, tf_layer=tf_layer, nhead=nhead,
+                    sched=sched, sampling=sampling, z=torch.stack(zs).to(context.dtype), flexibility=flexibility)
+        out.append(v[0])
+    return torch.stack(out)
 
 
 def integrate(vel: Tensor, p0: Tensor, dt: float) -> Tensor:

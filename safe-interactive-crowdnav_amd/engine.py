@@ -85,17 +85,17 @@ class JmidEngine:
         except Exception:
             pass
 
-    def set_step(self, step: int, sampling: str = "ddim") -> None:
+    def set_step(self, step: int, sampling: str = "ddim", flexibility: float = 0.0) -> None:
         """``step`` = the reference's ``step_size`` yaml key: number of reverse iterations out of 100
         (stride = int(100/step), MID/models/diffusion.py:507); ``sampling`` = "ddim" (what the predictor uses,
-        MID/mid.py:333) or "ddpm"."""
+        MID/mid.py:333) or "ddpm" with ``flexibility`` (``get_sigmas``, diffusion.py:59-64)."""
         self.step, self.sampling = step, sampling
         if sampling == "ddim":
             tab = ddim_steps(self.schedule, step)
             cols = [np.array([getattr(s, k) for s in tab], dtype=np.float32) for k in ("beta", "c_e", "c_x", "n_x", "n_e")]
             self._check(self._lib.jmid_set_ddim_table(self._h, len(tab), *[C.c_void_p(c.ctypes.data) for c in cols]))
         elif sampling == "ddpm":
-            tab = ddpm_steps(self.schedule, step)
+            tab = ddpm_steps(self.schedule, step, flexibility)
             cols = [np.array([getattr(s, k) for s in tab], dtype=np.float32) for k in ("beta", "c0", "c1", "sigma")]
             cols.append(np.array([int(s.noise) for s in tab], dtype=np.int32))
             self._check(self._lib.jmid_set_ddpm_table(self._h, len(tab), *[C.c_void_p(c.ctypes.data) for c in cols]))

@@ -24,6 +24,7 @@ class VarianceSchedule:
     alpha_bars: np.ndarray   # [num_steps+1] f32
     num_steps: int
     sigmas_inflex: np.ndarray = None   # [num_steps+1] f32 (DDPM, flexibility 0; diffusion.py:41-47)
+    sigmas_flex: np.ndarray = None     # [num_steps+1] f32 = sqrt(betas) (flexibility 1; diffusion.py:41)
 
     @classmethod
     def linear(cls, num_steps: int = 100, beta_1: float = 1e-4, beta_T: float = 5e-2) -> "VarianceSchedule":
@@ -34,12 +35,13 @@ class VarianceSchedule:
         for i in range(1, log_alphas.size(0)):
             log_alphas[i] += log_alphas[i - 1]
         alpha_bars = log_alphas.exp()
+        sigmas_flex = torch.sqrt(betas)
         sigmas_inflex = torch.zeros_like(betas)
         for i in range(1, betas.size(0)):
             sigmas_inflex[i] = ((1 - alpha_bars[i - 1]) / (1 - alpha_bars[i])) * betas[i]
         sigmas_inflex = torch.sqrt(sigmas_inflex)
         return cls(betas.numpy().copy(), alphas.numpy().copy(), alpha_bars.numpy().copy(), num_steps,
-                   sigmas_inflex.numpy().copy())
+                   sigmas_inflex.numpy().copy(), sigmas_flex.numpy().copy())
 
 
 @dataclass(frozen=True)
@@ -92,18 +94,22 @@ class DDPMStep:
     beta: np.float32
     c0: np.float32       # 1/sqrt(alpha_t)
     c1: np.float32       # (1 - alpha_t)/sqrt(1 - abar_t)
-    sigma: np.float32    # sigmas_inflex[t] (flexibility 0)
+    sigma: np.float32    # get_sigmas(t, flexibility) (diffusion.py:59-64)
     noise: bool          # z ~ N(0,1) is used (t > 1), else zeros     (diffusion.py:509)
 
 
-def ddpm_steps(sched: VarianceSchedule, step: int) -> List[DDPMStep]:
-    """x_next = c0*(x - c1*e) + sigma*z  (``sampling="ddpm"``, diffusion.py:509-522), same step enumeration as DDIM."""
+def ddpm_steps(sched: VarianceSchedule, step: int, flexibility: float = 0.0) -> List[DDPMStep]:
+    """x_next = c0*(x - c1*e) + sigma*z  (``sampling="ddpm"``, diffusion.py:509-522), same step enumeration as DDIM;
+    sigma = sigmas_flex[t]*flexibility + sigmas_inflex[t]*(1 - flexibility) (``get_sigmas``, diffusion.py:59-64)."""
+    if not 0.0 <= flexibility <= 1.0:
+        raise ValueError("flexibility must be in [0, 1]")
     if step <= 0:
         raise ValueError("step must be positive")
     stride = int(100 / step)
     if stride <= 0 or sched.num_steps % stride != 0:
         raise ValueError(f"step={step}: stride {stride} does not divide num_steps={sched.num_steps}")
-    al, ab, sg = (torch.from_numpy(a) for a in (sched.alphas, sched.alpha_bars, sched.sigmas_inflex))
+    al, ab = torch.from_numpy(sched.alphas), torch.from_numpy(sched.alpha_bars)
+    sg = torch.from_numpy(sched.sigmas_flex) * flexibility + torch.from_numpy(sched.sigmas_inflex) * (1 - flexibility)
     out = []
     for t in range(sched.num_steps, 0, -stride):
         out.append(DDPMStep(t=t, beta=np.float32(sched.betas[t]), c0=np.float32((1.0 / torch.sqrt(al[t])).item()),

@@ -19,6 +19,9 @@ Fixtures written:
                         velocities and the predict_ret_best() result            (mid_sim_wrapper.py:198-510)
   ddpm_*.npz            DDPM sampling branch of the same loop                  (diffusion.py:509-522)
   kde_*.npz             get_most_likely_samples                         (mid_sim_wrapper.py:14-169)
+  sample_*.npz          per-sample DiffusionTraj.sample of the offline evaluation      (diffusion.py:544-613)
+
+``python tests/golden/make_golden.py sample`` regenerates only the fixtures whose file name starts with "sample".
 """
 import collections
 import collections.abc
@@ -87,7 +90,12 @@ from sicnav_diffusion.JMID.MID.models import diffusion as ref_diffusion  # noqa:
 torch.set_num_threads(8)
 
 
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
+
+
 def save(name, **arrays):
+    if ONLY and not name.startswith(ONLY):
+        return
     path = os.path.join(HERE, name)
     np.savez_compressed(path, **arrays)
     print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KB")
@@ -223,6 +231,22 @@ def gen_ddpm_case(tag, ctx_dim, A, K, T, step, joint, wseed, dseed):
          wsum=weights.checksum(), ctx=np32(ctx), x_T=np32(x_T), z=np32(torch.stack(zs)), vel=np32(vel))
 
 
+def gen_sample_case(tag, ctx_dim, B, n_sample, T, step, joint, sampling, bestof, flexibility, wseed, dseed):
+    """DiffusionTraj.sample (diffusion.py:544-613): the per-sample loop of the offline evaluation."""
+    weights = JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), wseed)
+    sampler = build_ref_sampler(weights, joint)
+    g = torch.Generator().manual_seed(dseed)
+    ctx = torch.randn([B, ctx_dim], generator=g)
+    torch.manual_seed(dseed)
+    with torch.no_grad():
+        out = sampler.sample(T, ctx, n_sample, bestof, flexibility=flexibility, sampling=sampling, step=step)
+    vel, nsteps = out[0], out[1]
+    assert tuple(vel.shape) == (n_sample, B, T, 2) and tuple(out[2:]) == (0, 0, 0)
+    save(f"sample_{tag}.npz", ctx_dim=ctx_dim, B=B, n_sample=n_sample, T=T, step=step, joint=int(joint),
+         sampling=sampling, bestof=int(bestof), flexibility=flexibility, wseed=wseed, dseed=dseed,
+         wsum=weights.checksum(), ctx=np32(ctx), vel=np32(vel), nsteps=nsteps)
+
+
 def gen_wrapper_case(tag, kind, joint, ctx_dim, N, K, k_ret, H, step, wseed, dseed, n_frames=7,
                      time_jitter=0.0, drop_frame=None):
     f, weights = make_forecaster(joint, ctx_dim, N, K, k_ret, H, step, wseed)
@@ -346,6 +370,12 @@ def main():
     gen_ddpm_case("jmid_w32_a2k3t4_s10", 32, 2, 3, 4, 10, True, 41, 501)
     gen_ddpm_case("imid_w32_a3k4t6_s100", 32, 3, 4, 6, 100, False, 42, 502)     # stride 1: last step t = 1 uses z = 0
     gen_ddpm_case("jmid_w256_a5k20t12_s10", 256, 5, 20, 12, 10, True, 43, 503)
+    # (tag, ctx_dim, B, n_sample, T, step, joint, sampling, bestof, flexibility, wseed, dseed)
+    gen_sample_case("jmid_w32_b3n4t6_ddpm", 32, 3, 4, 6, 10, True, "ddpm", True, 0.0, 51, 601)
+    gen_sample_case("jmid_w32_b3n4t6_flex", 32, 3, 4, 6, 10, True, "ddpm", True, 0.3, 51, 602)
+    gen_sample_case("imid_w32_b4n3t5_ddim", 32, 4, 3, 5, 20, False, "ddim", True, 0.0, 52, 603)
+    gen_sample_case("jmid_w32_b2n2t4_zero", 32, 2, 2, 4, 100, True, "ddpm", False, 1.0, 53, 604)   # x_T = 0, stride 1
+    gen_sample_case("jmid_w256_b5n6t12_ddpm", 256, 5, 6, 12, 10, True, "ddpm", True, 0.0, 54, 605)
     gen_kde_case("k100_a3_h8", 100, 3, 8, 15, 401)
     gen_kde_case("k40_a5_h12", 40, 5, 12, 10, 402)
 

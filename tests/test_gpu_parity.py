@@ -192,3 +192,25 @@ def test_ddpm_sampling_matches_reference_golden(case, precision):
     a = ade(vel[0], z["vel"])
     print(f"{case} [{precision}] DDPM mean ADE vs reference = {a:.3e}")
     assert a <= ADE_GATE
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "sample_*.npz"))))
+def test_offline_sample_matches_reference_golden(case, precision):
+    """offline.sample == DiffusionTraj.sample (MID/models/diffusion.py:544-613) on the reference's RNG draws."""
+    from safe_interactive_crowdnav_amd import offline
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    assert w.checksum() == str(z["wsum"])
+    step0, samp0 = eng.step, eng.sampling
+    torch.manual_seed(int(z["dseed"]))
+    try:
+        vel, nsteps, a, b, c = offline.sample(eng, int(z["T"]), z["ctx"], int(z["n_sample"]), bool(z["bestof"]),
+                                              flexibility=float(z["flexibility"]), sampling=str(z["sampling"]),
+                                              step=int(z["step"]), precision=precision)
+    finally:
+        eng.set_step(step0, samp0)
+    assert vel.shape == z["vel"].shape and nsteps == int(z["nsteps"]) and (a, b, c) == (0, 0, 0)
+    d = ade(vel, z["vel"])
+    print(f"{case} [{precision}] offline sample mean ADE vs reference = {d:.3e}")
+    assert d <= ADE_GATE

@@ -26,6 +26,22 @@ def test_schedule_matches_reference_buffers():
     s = VarianceSchedule.linear()
     np.testing.assert_array_equal(s.betas, z["betas"])
     np.testing.assert_array_equal(s.alpha_bars, z["alpha_bars"])
+    np.testing.assert_array_equal(s.sigmas_inflex, z["sigmas_inflex"])
+    np.testing.assert_array_equal(s.sigmas_flex, z["sigmas_flex"])
+
+
+def test_ddpm_table_flexibility():
+    """get_sigmas (diffusion.py:59-64): sigma = flex * sigmas_flex[t] + (1 - flex) * sigmas_inflex[t]."""
+    from safe_interactive_crowdnav_amd.schedule import ddpm_steps
+    s = VarianceSchedule.linear()
+    t0, t1, th = ddpm_steps(s, 10, 0.0), ddpm_steps(s, 10, 1.0), ddpm_steps(s, 10, 0.5)
+    assert [x.t for x in t0] == list(range(100, 0, -10)) and all(x.noise for x in t0)
+    assert [x.sigma for x in t0] == [s.sigmas_inflex[x.t] for x in t0]
+    assert [x.sigma for x in t1] == [s.sigmas_flex[x.t] for x in t1]
+    assert all(min(a.sigma, b.sigma) <= h.sigma <= max(a.sigma, b.sigma) for a, b, h in zip(t0, t1, th))
+    assert not ddpm_steps(s, 100)[-1].noise            # t == 1: z = 0 (diffusion.py:571)
+    with pytest.raises(ValueError):
+        ddpm_steps(s, 10, 1.5)
 
 
 def test_ddim_table():

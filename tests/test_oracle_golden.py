@@ -108,3 +108,20 @@ def test_ddpm_sampling_matches_reference(case):
         vel = O.denoise(w, torch.from_numpy(z["ctx"]), torch.from_numpy(z["x_T"]), sample=int(z["K"]), step=int(z["step"]),
                         joint=bool(z["joint"]), sampling="ddpm", z=torch.from_numpy(z["z"]))
     assert np.linalg.norm(vel.numpy() - z["vel"], axis=-1).mean() <= 5e-6
+
+
+SAMPLE_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "sample_*.npz")))
+
+
+@pytest.mark.parametrize("case", SAMPLE_CASES)
+def test_offline_sample_matches_reference(case):
+    """DiffusionTraj.sample (diffusion.py:544-613): per-sample loop, global-generator draws, flexibility."""
+    z = np.load(os.path.join(GOLDEN, case))
+    w = _weights(z).tensors
+    torch.manual_seed(int(z["dseed"]))
+    with torch.no_grad():
+        vel = O.sample_offline(w, torch.from_numpy(z["ctx"]), int(z["T"]), int(z["n_sample"]), bool(z["bestof"]),
+                               step=int(z["step"]), joint=bool(z["joint"]), sampling=str(z["sampling"]),
+                               flexibility=float(z["flexibility"]))
+    assert vel.shape == z["vel"].shape
+    assert np.linalg.norm(vel.numpy() - z["vel"], axis=-1).mean() <= 5e-6
