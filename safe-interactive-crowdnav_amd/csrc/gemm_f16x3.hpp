@@ -41,6 +41,7 @@ enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 static int g_gemm_h_variant = 0;  // tuning knob (jmid_set_tuning)
 static int g_gemm_ng = 0;         // N-tiles per L2 group (0 = auto)
 static int g_gemm_abl = 0;        // timing ablation bits of the 256x128 kernel (diagnostics)
+static int g_no_vt_direct = 0;    // 1: V row-major + v_transpose_kernel even when the fused V^T epilogue applies
 
 struct GemmHArgs {
     const half_t *Ahi, *Alo;  // [M, K] in the blocked panel layout (common.hpp::blk_index), rows padded to 128
@@ -51,8 +52,10 @@ struct GemmHArgs {
     half_t *Chi, *Clo;        // OUT_SPLIT: planes [M, N] blocked (operand of the next GEMM) ; OUT_QKV: Q planes [M, d] row-major
     int ldc;
     half_t *Khi, *Klo;        // OUT_QKV: K planes [M, d]
-    half_t *Vthi, *Vtlo;      // OUT_QKV: V planes [M, d] (row-major; transposed afterwards by v_transpose_kernel)
+    half_t *Vthi, *Vtlo;      // OUT_QKV: V planes [M, d] (row-major; transposed afterwards by v_transpose_kernel), or
+                              // with vt_direct the final V^T planes [nseq][nhead][hd][Spad] (see v_transpose_kernel)
     int d, hd, S, Spad;
+    int vt_direct;            // OUT_QKV, needs S % 4 == 0: the epilogue writes V^T itself, 4 keys (8 bytes) per store
     float qscale;             // OUT_QKV: Q is stored pre-multiplied by log2(e)/sqrt(head_dim)
     const float* hyp;         // EPI_CSL (see gemm_f32.hpp)
     const float* thyp;
@@ -120,6 +123,35 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
         if (OUT == OUT_QKV) {
             part = n / g.d;
             nn = n - part * g.d;
+        }
+        if (OUT == OUT_QKV && part == 2 && g.vt_direct) {
+            // V^T straight from the accumulators: registers 4q..4q+3 of a lane are 4 consecutive tokens (= keys) of
+            // column nn, i.e. one 8-byte granule of V^T row (head, nn % hd).  Granules never straddle a sequence
+            // (S % 4 == 0).  Same layout as v_transpose_kernel, including the swapped halves of rows with bit 4 set.
+            const int head = nn / g.hd, vc = nn - head * g.hd, sw = ((vc >> 4) & 1) * 4, nh = g.d / g.hd;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m = m0 + wr * WM * 32 + i * 32 + 8 * q + 4 * hi;
+                    if (!FULL && m >= g.M) continue;
+                    f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaf(accc[i][j][4 * q + e], kLoInv, accm[i][j][4 * q + e]) + bv[j];
+                        half_t hh, ll;
+                        split_f32_unscaled(v, hh, ll);
+                        overflow |= !(fabsf(v) <= kHalfMax);
+                        vh[e] = hh;
+                        vl[e] = ll;
+                    }
+                    const int seq = m / g.S, key = m - seq * g.S;
+                    const size_t o = (((size_t)seq * nh + head) * g.hd + vc) * g.Spad + (key & ~7) + ((key & 7) ^ sw);
+                    *reinterpret_cast<f16x4*>(g.Vthi + o) = vh;
+                    *reinterpret_cast<f16x4*>(g.Vtlo + o) = vl;
+                }
+            }
+            continue;
         }
 #pragma unroll
         for (int i = 0; i < WM; ++i) {

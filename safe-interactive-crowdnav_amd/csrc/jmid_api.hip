@@ -428,10 +428,13 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = win.hi; g.Wlo = win.lo;
             g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
             if (joint) {
-                g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl; g.Vthi = sb.Vh; g.Vtlo = sb.Vl;
+                // S % 4 == 0: the QKV epilogue writes V^T itself; otherwise V row-major + v_transpose_kernel
+                const bool vt_direct = (S % 4 == 0) && !g_no_vt_direct;
+                g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl;
+                g.Vthi = vt_direct ? sb.Vth : sb.Vh; g.Vtlo = vt_direct ? sb.Vtl : sb.Vl; g.vt_direct = vt_direct;
                 g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad; g.qscale = att_scale * 1.4426950408889634f;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_QKV>(h, KC_GEMM_QKV, g))) return rc;
-                {
+                if (!vt_direct) {
                     ProfScope ps(h, KC_VTRANS);
                     hipLaunchKernelGGL(v_transpose_kernel, dim3((S + 63) / 64, d / 64, nseq), dim3(256), 0, h->stream,
                                        sb.Vh, sb.Vl, sb.Vth, sb.Vtl, S, sg.Spad, d, hd);
@@ -1035,6 +1038,10 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         fprintf(stderr, "gemm_f16x3_kernel<2,2>: %d workgroups/CU (LDS %zu B)\n", n, gemm_h_lds_bytes<2, 2>());
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f32_kernel<128, 4>, 256, 0);
         fprintf(stderr, "attn_f32_kernel<128,4>: %d workgroups/CU\n", n);
+        return JMID_OK;
+    }
+    if (k == "no_vt_direct") {   // 1: always V row-major + v_transpose_kernel (A/B of the fused V^T epilogue)
+        g_no_vt_direct = value;
         return JMID_OK;
     }
     if (k == "attn_abl") {     // timing ablations of the attention kernel (results are WRONG; tools/attn_abl.py)

@@ -201,9 +201,18 @@ def scenario(kind, N, n_frames, rng, time_step=0.25):
         p0 = rng.uniform(-0.8, 0.8, (N, 2))
         p0[-1] = np.array([3.6, 0.0])
         rob0 = np.array([0.0, -2.0])
+    elif kind == "singleton":   # everybody > 3 m from everybody: the chosen cluster is ONE human (A = 1)
+        p0 = np.array([[4.5 * i, 0.3 * (i % 2)] for i in range(N)], float)
+        rob0 = np.array([4.5 * (N - 1) - 0.5, -2.0])          # nearest to the LAST track id
+    elif kind == "far_ids":     # two groups, the robot stands next to the one holding the HIGH track ids
+        p0 = rng.uniform(-1.0, 1.0, (N, 2))
+        p0[N // 2:] += np.array([7.0, 5.0])
+        rob0 = np.array([7.5, 3.0])
     else:
         raise ValueError(kind)
     v = rng.uniform(-0.5, 0.5, (N, 2))
+    if kind == "singleton":
+        v *= 0.3
     if kind == "entering":
         v[-1] = np.array([-1.2, 0.0])
     out = []
@@ -365,6 +374,10 @@ def main():
     ]
     for c in wrapper_cases:
         gen_wrapper_case(*c)
+    gen_wrapper_case("jmid_singleton", "singleton", True, 256, 4, 8, 8, 12, 2, 36, 310)
+    gen_wrapper_case("jmid_one_human", "together", True, 256, 1, 8, 8, 12, 2, 36, 311)
+    gen_wrapper_case("jmid_far_ids", "far_ids", True, 256, 5, 8, 8, 12, 2, 36, 312)
+    gen_wrapper_case("imid_singleton", "singleton", False, 256, 3, 8, 8, 12, 2, 37, 313)
     gen_wrapper_case("jmid_jitter", "together", True, 256, 4, 8, 8, 12, 2, 35, 308, n_frames=9, time_jitter=0.04)
     gen_wrapper_case("jmid_gap", "together", True, 256, 4, 8, 8, 12, 2, 35, 309, n_frames=9, drop_frame=6)
     gen_ddpm_case("jmid_w32_a2k3t4_s10", 32, 2, 3, 4, 10, True, 41, 501)

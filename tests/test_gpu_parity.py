@@ -214,3 +214,21 @@ def test_offline_sample_matches_reference_golden(case, precision):
     d = ade(vel, z["vel"])
     print(f"{case} [{precision}] offline sample mean ADE vs reference = {d:.3e}")
     assert d <= ADE_GATE
+
+
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w32_a5k20t12_s50.npz"])
+def test_fused_vt_epilogue_equals_transpose_kernel(case):
+    """The QKV epilogue that writes V^T itself (S % 4 == 0) and the row-major V + v_transpose_kernel path hold the
+    same values: bit-identical trajectories, and both at reference parity."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), True)
+    eng.set_step(int(z["step"]))
+    out = []
+    try:
+        for off in (0, 1):
+            eng.set_tuning("no_vt_direct", off)
+            out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16x3", want_pos=False)[0][0])
+    finally:
+        eng.set_tuning("no_vt_direct", 0)
+    np.testing.assert_array_equal(out[0], out[1])
+    assert ade(out[0], z["vel"]) <= ADE_GATE
