@@ -17,7 +17,7 @@ struct EmbedArgs {
     const float* pe;     // [max_len, d]
     const float* hyp;    // [EA, hyp_ld]
     const float* thyp;   // [hyp_ld]
-    float* X;            // [M, d]
+    float* X;            // [M, d] fp32, or nullptr when only the planes are wanted (split-fp16 mode)
     int M, d, hyp_ld, goff, boff;
     RowMap rmap;
     half_t* Xh;          // optional hi/lo planes of X (blocked panel layout) for the split-fp16 GEMMs
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
             const float bias = hrow[a.boff + c] + a.thyp[a.boff + c];
             o[e] = lin * gate + bias + a.pe[(size_t)t * a.d + c];
         }
-        *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
+        if (a.X) *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
         if (a.Xh) {
             f16x4 vh, vl;
 #pragma unroll
@@ -61,13 +61,16 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ add + LayerNorm
 // X[m,:] = LN(X[m,:] + Y[m,:]) * gamma + beta ; one wave per row, d <= 64*4*VPL
-template <int VPL>  // float4 vectors per lane
+// PLANES: the residual stream X lives ONLY in its hi/lo planes (blocked panel layout, hi + lo*2^-11 carries x to
+// ~1 fp32 ulp): they are read for the residual and rewritten, the fp32 X array is not touched - one fp32 stream less
+// through HBM per LayerNorm.
+template <int VPL, bool PLANES>  // float4 vectors per lane
 __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, const float* gamma, const float* beta,
                                                      int M, int d, float eps, half_t* Xh, half_t* Xl) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
-    float* xr = X + (size_t)row * d;
+    float* xr = PLANES ? nullptr : X + (size_t)row * d;
     const float* yr = Y + (size_t)row * d;
     f32x4 v[VPL];
     float s = 0.f;
@@ -75,7 +78,16 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < d) {
-            f32x4 a = *reinterpret_cast<const f32x4*>(xr + c);
+            f32x4 a;
+            if (PLANES) {
+                const size_t ob = blk_index(row, c, d);
+                const f16x4 ph = *reinterpret_cast<const f16x4*>(Xh + ob);
+                const f16x4 pl = *reinterpret_cast<const f16x4*>(Xl + ob);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaf((float)pl[e], kLoInv, (float)ph[e]);
+            } else {
+                a = *reinterpret_cast<const f32x4*>(xr + c);
+            }
             f32x4 b = *reinterpret_cast<const f32x4*>(yr + c);
             v[i] = a + b;
             s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
-            *reinterpret_cast<f32x4*>(xr + c) = o;
+            if (!PLANES) *reinterpret_cast<f32x4*>(xr + c) = o;
             if (Xh) {
                 f16x4 vh, vl;
 #pragma unroll

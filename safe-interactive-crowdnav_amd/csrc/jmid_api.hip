@@ -277,13 +277,18 @@ int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const flo
     const int rows_per_block = 4;
     dim3 grid((M + rows_per_block - 1) / rows_per_block);
     const int vpl = (d + 255) / 256;
+    const bool planes = Xh != nullptr;   // split-fp16 mode: the residual stream lives only in its planes
+#define JMID_LN(V)                                                                                                    \
+    if (planes) hipLaunchKernelGGL((add_ln_kernel<V, true>), grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); \
+    else hipLaunchKernelGGL((add_ln_kernel<V, false>), grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl);
     switch (vpl) {
-        case 1: hipLaunchKernelGGL(add_ln_kernel<1>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); break;
-        case 2: hipLaunchKernelGGL(add_ln_kernel<2>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); break;
+        case 1: JMID_LN(1) break;
+        case 2: JMID_LN(2) break;
         case 3:
-        case 4: hipLaunchKernelGGL(add_ln_kernel<4>, grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); break;
+        case 4: JMID_LN(4) break;
         default: return fail(h, JMID_EINVAL, "d_model too large for add_ln");
     }
+#undef JMID_LN
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -369,7 +374,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     {
         ProfScope ps(h, KC_EMBED);
         EmbedArgs ea{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, thyp,
-                     sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
+                     split ? nullptr : sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
                      split ? sb.Xl : nullptr};
         const long total = (long)M * (d / 4);
         int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
