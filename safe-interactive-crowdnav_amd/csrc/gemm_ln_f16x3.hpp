@@ -1,0 +1,249 @@
+// Row-complete split-fp16 GEMM with the residual add and the post-LayerNorm of nn.TransformerEncoderLayer fused in:
+//     X <- LayerNorm(X + A . W^T + b) * gamma + beta          (attention out-projection + norm1, linear2 + norm2)
+// A workgroup owns 64 full rows (BN = N = 512), so the row statistics never leave the chip and the GEMM output never
+// goes to HBM: per LayerNorm that is one fp32 [M, 512] write + read and one kernel launch less than GEMM + add_ln.
+//
+// 8 waves side by side along N (wave tile 64 x 64).  W is not shared between waves in this shape, A is shared by all:
+//   A ring: 4 stages of one k32 tile (hi + lo = 8 KB, ONE DMA wave-instruction per wave) -> 3 tiles of look-ahead,
+//           enough to cover an HBM miss (the A rows were just written by the previous kernel);
+//   W ring: 3 stages of one k16 slice (2 planes x 16 KB) from a k16-panel copy of the weight ([K/16][512][16] halfs,
+//           made at load time): each wave copies only its own 64 rows - four DMA instructions of 1 KB of contiguous
+//           lines - so the W ring is wave-private and only the A tiles (every other step) need a workgroup barrier.
+// All DMAs retire in order; the schedule below keeps exactly five wave-instructions in flight at every wait.
+// Epilogue: accumulators + bias -> fp32 tile in LDS (row stride 520 floats: conflict-free), then one wave per row does
+// the same arithmetic, in the same order, as add_ln_kernel<2, true> (elementwise.hpp) - the fused and the unfused
+// paths give bit-identical rows.
+#pragma once
+#include "gemm_f16x3.hpp"
+
+namespace jmid {
+
+constexpr int GLN_BM = 64, GLN_BN = 512;
+constexpr int GLN_W_STAGE = 2 * GLN_BN * 16;     // halfs per W stage (hi plane then lo plane)
+constexpr int GLN_A_STAGE = 2 * GLN_BM * 32;     // halfs per A stage
+constexpr int GLN_W_OFF = 0;
+constexpr int GLN_A_OFF = 3 * GLN_W_STAGE;
+constexpr int GLN_SCRATCH_OFF = GLN_A_OFF + 4 * GLN_A_STAGE;
+constexpr size_t GLN_LDS_BYTES = size_t(GLN_SCRATCH_OFF + GLN_A_STAGE) * sizeof(half_t);   // 136 KB
+constexpr int GLN_TILE_LD = GLN_BN + 8;          // floats per row of the epilogue tile
+static_assert(size_t(GLN_BM) * GLN_TILE_LD * sizeof(float) <= GLN_LDS_BYTES, "epilogue tile must fit the ring");
+
+static int g_ln_fuse = 0;   // tuning knob: 0 auto, 1 always, 2 never (jmid_set_tuning "ln_fuse")
+
+struct GemmLnArgs {
+    const half_t *Ahi, *Alo;      // [M, K] blocked panel layout (common.hpp::blk_index)
+    const half_t *W16hi, *W16lo;  // [K/16][512][16]
+    const float* bias;            // [512]
+    const float *gamma, *beta;    // LayerNorm affine [512]
+    half_t *Xh, *Xl;              // residual stream planes [M, 512] blocked: read, then overwritten with the result
+    int M, K;
+    float eps;
+    int* range_flag;
+};
+
+// fp32 row-major [512, K] -> k16-panel hi/lo planes
+__global__ void split_planes_k16_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K) {
+    const size_t n = (size_t)rows * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / K), k = (int)(i % K);
+        half_t h, l;
+        split_f32(in[i], h, l);
+        const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + (k & 15);
+        hi[o] = h;
+        lo[o] = l;
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int ntm) {
+    constexpr int WM = 2, WN = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wid;
+    // XCD-contiguous ranges of row tiles: the tiles an XCD works on concurrently stream the same W slices through its L2
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int m0 = tm * GLN_BM;
+    const int nk = g.K / 32, nsteps = 2 * nk;
+
+    const half_t* a_src = (tid < 256 ? g.Ahi : g.Alo) + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + (tid & 255) * 8;
+    const int a_dst = (tid < 256 ? 0 : 2048) + (wid & 3) * 512;
+    auto issueA = [&](int ka) {     // one wave-instruction; past the end: the last tile again, into the scratch stage
+        const bool live = ka < nk;
+        const int kk = live ? ka : nk - 1;
+        half_t* dst = lds + (live ? GLN_A_OFF + (ka & 3) * GLN_A_STAGE : GLN_SCRATCH_OFF) + a_dst;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)kk * 4096),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // W is private to a wave in this shape: every wave copies and reads only its own 64 rows of the slice (four
+    // wave-instructions of 1 KB: hi rows 0-31, hi 32-63, lo 0-31, lo 32-63), so W needs no workgroup barrier - only A does
+    auto issueW = [&](int s, int stage) {
+        half_t* st = lds + GLN_W_OFF + stage * GLN_W_STAGE + wc * 64 * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const half_t* src = ((q >> 1) ? g.W16lo : g.W16hi) + ((size_t)s * GLN_BN + wc * 64 + (q & 1) * 32) * 16 + lane * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + (q >> 1) * GLN_BN * 16 + (q & 1) * 512),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16 accm[WM][WN], accc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                accm[i][j][r] = 0.f;
+                accc[i][j][r] = 0.f;
+            }
+    int offA[WM][2], offW[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = i * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offA[i][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) offW[j] = (wc * 64 + j * 32 + l31) * 16 + hi * 8;
+
+    // issue order A0 A1 W0 A2 W1, then per step W(s+2) [+ A(s/2+3) on even steps]: at the top of step s the
+    // instructions younger than W(s) are always one A and one W slice = 5.
+    issueA(0);
+    issueA(1);
+    issueW(0, 0);
+    issueA(2);
+    issueW(1, 1);
+    int wst = 0;
+    // one k16 step; ks (which half of the A tile) is a literal at both call sites so every LDS offset stays in a register
+    auto step = [&](const int s, const int ks) {
+        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ks == 0) __builtin_amdgcn_s_barrier();   // A tile s/2 landed for everybody; A stage (s/2 - 1) is free again
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nsteps) issueW(s + 2, wst == 0 ? 2 : wst - 1);   // (wst + 2) % 3
+        if (ks == 0) issueA((s >> 1) + 3);
+        const half_t* stA = lds + GLN_A_OFF + ((s >> 1) & 3) * GLN_A_STAGE;
+        const half_t* stW = lds + GLN_W_OFF + wst * GLN_W_STAGE;
+        f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(stA + offA[i][ks]);
+            al[i] = *reinterpret_cast<const f16x8*>(stA + 2048 + offA[i][ks]);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
+            wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
+        }
+        mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+        wst = wst == 2 ? 0 : wst + 1;
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, 0);
+        step(s + 1, 1);
+    }
+
+    // ---- epilogue.  The residual rows (8 per wave) are requested first: their HBM latency hides under the tile
+    // write.  Rows past M exist in the padded panels, so the loads need no guard (the stores do).
+    constexpr int d = GLN_BN;
+    f16x4 rph[8][2], rpl[8][2];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t ob = blk_index(m0 + wid * 8 + rr, (i * 64 + lane) * 4, d);
+            rph[rr][i] = *reinterpret_cast<const f16x4*>(g.Xh + ob);
+            rpl[rr][i] = *reinterpret_cast<const f16x4*>(g.Xl + ob);
+        }
+    f32x4 gm[2], bt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gm[i] = *reinterpret_cast<const f32x4*>(g.gamma + (i * 64 + lane) * 4);
+        bt[i] = *reinterpret_cast<const f32x4*>(g.beta + (i * 64 + lane) * 4);
+    }
+    // Y tile (fp32, + bias) into LDS
+    __builtin_amdgcn_s_barrier();          // everybody is done with the rings (all DMAs have landed: vmcnt(0) above)
+    float* tile = reinterpret_cast<float*>(lds_raw);
+    {
+        float bv[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bv[j] = g.bias[wc * 64 + j * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(i * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
+                        fmaf(accc[i][j][r], kLoInv, accm[i][j][r]) + bv[j];
+    }
+    __syncthreads();
+    // residual + LayerNorm, one wave per row, 8 rows per wave (the arithmetic of add_ln_kernel<2, true>)
+    bool overflow = false;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int trow = wid * 8 + rr, row = m0 + trow;
+        f32x4 v[2];
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaf((float)rpl[rr][i][e], kLoInv, (float)rph[rr][i][e]);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
+            v[i] = a + y;
+            sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum(sacc) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)d + g.eps);
+        if (row < g.M) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                f16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                    half_t hh, ll;
+                    split_f32(o, hh, ll);
+                    overflow |= !(fabsf(o) <= kHalfMax);
+                    vh[e] = hh;
+                    vl[e] = ll;
+                }
+                const size_t ob = blk_index(row, c, d);
+                *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
+                *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
+            }
+        }
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
+}
+
+inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_f16x3_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN_LDS_BYTES);
+        attr_set = true;
+    }
+    const int ntm = (g.M + GLN_BM - 1) / GLN_BM;
+    hipLaunchKernelGGL(gemm_ln_f16x3_kernel, dim3(ntm), dim3(512), GLN_LDS_BYTES, st, g, ntm);
+    return hipGetLastError();
+}
+
+}  // namespace jmid

@@ -17,6 +17,7 @@
 #include "elementwise.hpp"
 #include "encoder.hpp"
 #include "gemm_f16x3.hpp"
+#include "gemm_ln_f16x3.hpp"
 #include "gemm_f32.hpp"
 
 using namespace jmid;
@@ -69,6 +70,7 @@ struct jmid_ctx {
     std::map<std::string, std::vector<size_t>> expected;  // name -> shape
     std::map<std::string, DevBuf> w;
     std::map<std::string, HalfPair> wsplit;  // hi/lo fp16 planes of the GEMM weights (F16X3 path)
+    std::map<std::string, HalfPair> w16;     // k16-panel copies of out_proj / linear2 for the fused GEMM + LayerNorm
     int* range_flag = nullptr;               // device word: an fp16 operand left the fp16 range
     bool weights_in_half_range = true;
     bool finalized = false;
@@ -459,24 +461,43 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 AttnArgs aa{sb.QKV, nullptr, S, d, h->nhead, att_scale, sb.Ah, sb.Al};
                 HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
             }
-            const HalfPair& wout = h->wsplit[p + ".self_attn.out_proj.weight"];
-            g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
-            g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
-            if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
-            if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
-                                    sb.Xl))
-                return rc;
+            // row-complete GEMM with residual + LayerNorm fused in (gemm_ln_f16x3.hpp) once there are enough 64-row
+            // tiles to fill the chip; otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
+            const bool ln_fused = d == GLN_BN && g_ln_fuse != 2 && (g_ln_fuse == 1 || M >= 16384);
+            if (ln_fused) {
+                const HalfPair& w16 = h->w16[p + ".self_attn.out_proj.weight"];
+                GemmLnArgs gl{sb.Ah, sb.Al, w16.hi, w16.lo, W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"),
+                              W(h, p + ".norm1.bias"), sb.Xh, sb.Xl, M, d, 1e-5f, h->range_flag};
+                ProfScope ps(h, KC_GEMM_OUT);
+                HIPCHK(h, launch_gemm_ln(gl, h->stream));
+            } else {
+                const HalfPair& wout = h->wsplit[p + ".self_attn.out_proj.weight"];
+                g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
+                g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+                if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
+                if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
+                                        sb.Xl))
+                    return rc;
+            }
             const HalfPair& w1 = h->wsplit[p + ".linear1.weight"];
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w1.hi; g.Wlo = w1.lo;
             g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
             if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
-            const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
-            g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
-            g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
-            if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
-            if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
-                                    sb.Xl))
-                return rc;
+            if (ln_fused) {
+                const HalfPair& w16 = h->w16[p + ".linear2.weight"];
+                GemmLnArgs gl{sb.H1h, sb.H1l, w16.hi, w16.lo, W(h, p + ".linear2.bias"), W(h, p + ".norm2.weight"),
+                              W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag};
+                ProfScope ps(h, KC_GEMM_FF2);
+                HIPCHK(h, launch_gemm_ln(gl, h->stream));
+            } else {
+                const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
+                g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
+                g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
+                if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
+                if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
+                                        sb.Xl))
+                    return rc;
+            }
         }
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
@@ -856,6 +877,11 @@ int jmid_finalize_weights(jmid_handle_t h) {
             hipFree(kv.second.lo);
         }
         h->wsplit.clear();
+        for (auto& kv : h->w16) {
+            hipFree(kv.second.hi);
+            hipFree(kv.second.lo);
+        }
+        h->w16.clear();
         if (!h->range_flag) {
             HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
         }
@@ -881,6 +907,22 @@ int jmid_finalize_weights(jmid_handle_t h) {
                                (int)shp[0], (int)shp[1], h->range_flag);
             HIPCHK(h, hipGetLastError());
             h->wsplit[nm] = hp;
+        }
+        if (h->d == GLN_BN) {   // k16-panel copies for gemm_ln_f16x3_kernel (row-complete tiles need N == 512)
+            for (int l = 0; l < h->tf_layer; ++l) {
+                const std::string p = "transformer_encoder.layers." + std::to_string(l);
+                for (const std::string nm : {p + ".self_attn.out_proj.weight", p + ".linear2.weight"}) {
+                    const DevBuf& b = h->w[nm];
+                    const std::vector<size_t>& shp = h->expected[nm];   // [512, K]
+                    HalfPair hp;
+                    HIPCHK(h, hipMalloc((void**)&hp.hi, shp[0] * shp[1] * sizeof(half_t)));
+                    HIPCHK(h, hipMalloc((void**)&hp.lo, shp[0] * shp[1] * sizeof(half_t)));
+                    hipLaunchKernelGGL(split_planes_k16_kernel, dim3(256), dim3(256), 0, h->stream, b.p, hp.hi, hp.lo,
+                                       (int)shp[0], (int)shp[1]);
+                    HIPCHK(h, hipGetLastError());
+                    h->w16[nm] = hp;
+                }
+            }
         }
         HIPCHK(h, hipStreamSynchronize(h->stream));
         int flag = 0;
@@ -1043,6 +1085,11 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         fprintf(stderr, "gemm_f16x3_kernel<2,2>: %d workgroups/CU (LDS %zu B)\n", n, gemm_h_lds_bytes<2, 2>());
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f32_kernel<128, 4>, 256, 0);
         fprintf(stderr, "attn_f32_kernel<128,4>: %d workgroups/CU\n", n);
+        return JMID_OK;
+    }
+    if (k == "ln_fuse") {   // 0 auto (M >= 16384 tokens), 1 always, 2 never: fused GEMM + residual + LayerNorm
+        if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "ln_fuse must be 0..2");
+        g_ln_fuse = value;
         return JMID_OK;
     }
     if (k == "no_vt_direct") {   // 1: always V row-major + v_transpose_kernel (A/B of the fused V^T epilogue)

@@ -232,3 +232,22 @@ def test_fused_vt_epilogue_equals_transpose_kernel(case):
         eng.set_tuning("no_vt_direct", 0)
     np.testing.assert_array_equal(out[0], out[1])
     assert ade(out[0], z["vel"]) <= ADE_GATE
+
+
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz",
+                                  "net_jmid_w256_a7k9t24_s10.npz"])
+def test_fused_gemm_layernorm_equals_gemm_then_add_ln(case):
+    """gemm_ln_f16x3_kernel (row-complete GEMM + residual + LayerNorm) and GEMM -> fp32 Y -> add_ln do the same
+    arithmetic in the same order: bit-identical trajectories, whichever the token count selects."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    eng.set_step(int(z["step"]))
+    out = {}
+    try:
+        for mode in (1, 2):      # 1 = always fused, 2 = never
+            eng.set_tuning("ln_fuse", mode)
+            out[mode] = eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16x3", want_pos=False)[0][0]
+    finally:
+        eng.set_tuning("ln_fuse", 0)
+    np.testing.assert_array_equal(out[1], out[2])
+    assert ade(out[1], z["vel"]) <= ADE_GATE

@@ -1,0 +1,28 @@
+"""A/B of a tuning key inside one process (same box, same clocks): full 50-step denoise on one 51-episode chunk.
+   python tools/ab_tuning.py ln_fuse 2 1        -> alternates value 2 and value 1, prints ms per call of each"""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_interactive_crowdnav_amd.engine import JmidEngine
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+
+key, vals = sys.argv[1], [int(v) for v in sys.argv[2:]]
+E, N, K, H = int(os.environ.get("AB_EPISODES", "51")), 5, 20, 12
+dev = torch.device("cuda", 0)
+eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 0), joint=os.environ.get("AB_NET", "jmid") == "jmid", step=50)
+ctx = torch.randn([E, N, 256], generator=torch.Generator().manual_seed(1)).to(dev)
+x_T = torch.randn([E, K * N, H, 2], generator=torch.Generator().manual_seed(0)).to(dev)
+res = {v: [] for v in vals}
+for rep in range(4):
+    for v in vals:
+        eng.set_tuning(key, v)
+        eng.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.denoise(x_T, ctx, None, precision="f16x3", want_pos=False)
+        eng.synchronize()
+        if rep:
+            res[v].append(time.perf_counter() - t0)
+for v in vals:
+    ms = 1e3 * np.array(res[v])
+    print(f"{key}={v}: {ms.mean():8.2f} ms per call (min {ms.min():.2f})  {E*N*K/ms.mean()*1e3:9.0f} traj/s", flush=True)
