@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
-    ap.add_argument("--cpu-episodes", type=int, default=4, help="episodes timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-episodes", type=int, default=12, help="episodes timed on the host for cpu_baseline (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
