@@ -14,6 +14,7 @@
 // takes keys {k0, k0+4} straight from the registers - no cross-lane shuffle of P at all.
 #pragma once
 #include "common.hpp"
+#include <algorithm>
 #include "gemm_f16x3.hpp"
 
 namespace jmid {
@@ -170,8 +171,172 @@ __global__ __launch_bounds__(NWAVES * 64) void attn_f32_kernel(AttnArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Short sequences (iMID: S = T <= 16): G = several sequences share one wave's 32 x 32 score tile, block-diagonally
+// masked, and K / V tiles are private to the wave (no workgroup barrier; 4 waves of a workgroup = 4 heads).
+// The result of a sequence must not depend on which slot of the tile it lands in (chunking-invariance is tested
+// bit for bit), so slot s puts its local key k on accumulator register j = s*J + k/2 of lane-half hi = k%2
+// (J = ceil(S/2)): every slot then adds its keys in the same order, and the masked positions contribute exact zeros.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void attn_f32_packed_kernel(AttnArgs a, int nseq, int G, int J) {
+    constexpr int KLD = HD + 4;            // padded K / V row (floats)
+    constexpr int NT = (HD + 31) / 32;
+    constexpr int NG = HD / 8;
+    constexpr int F4 = HD / 4;             // float4 per row
+    constexpr int NLD = (32 * F4 + 63) / 64;   // float4 loads per lane and tile
+    extern __shared__ __attribute__((aligned(16))) float att_pk_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int h = blockIdx.y * 4 + wid;
+    if (h >= a.nhead) return;              // no workgroup barrier below: a whole wave may leave
+    float* Ks = att_pk_lds + wid * 32 * KLD;
+    const int S = a.S, d = a.d;
+    const size_t ld = (size_t)3 * d;
+    const int seq0 = blockIdx.x * G;
+    const int nvs = (nseq - seq0) < G ? (nseq - seq0) : G;      // sequences in this tile
+
+    // this lane's query: column l31 = slot sq, local token kq
+    const int sq = l31 / S, kq = l31 - sq * S;
+    const bool qvalid = sq < nvs;
+    const size_t qtok = (size_t)(seq0 + (qvalid ? sq : 0)) * S + (qvalid ? kq : 0);
+    f32x4 qreg[NG];
+    {
+        const float* qp = a.QKV + qtok * ld + h * HD + 4 * hi;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qreg[g] = *reinterpret_cast<const f32x4*>(qp + 8 * g) * a.scale;
+    }
+    // tile row rho holds key (slot, k): rho = frag_row(j, hh) with j = slot*J + k/2, hh = k%2
+    auto load_tile = [&](int col0, f32x4 (&regs)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = i * 64 + lane;
+            const int rho = idx / F4, c4 = idx - rho * F4;
+            const int j = ((rho >> 3) << 2) | (rho & 3), hh = (rho >> 2) & 1;
+            const int sl = j / J, k = (j - sl * J) * 2 + hh;
+            regs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < 32 * F4 && sl < nvs && k < S)
+                regs[i] = *reinterpret_cast<const f32x4*>(a.QKV + ((size_t)(seq0 + sl) * S + k) * ld + col0 + h * HD + c4 * 4);
+        }
+    };
+    auto store_tile = [&](const f32x4 (&regs)[NLD]) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = i * 64 + lane;
+            const int rho = idx / F4, c4 = idx - rho * F4;
+            if (idx < 32 * F4) *reinterpret_cast<f32x4*>(&Ks[rho * KLD + c4 * 4]) = regs[i];
+        }
+    };
+    f32x4 kreg[NLD], vreg[NLD];
+    load_tile(d, kreg);
+    store_tile(kreg);
+    load_tile(2 * d, vreg);               // in flight during the S^T MFMAs
+
+    // ---- S^T = K . Q^T
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    {
+        const float* kp = &Ks[l31 * KLD + 4 * hi];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            f32x4 kv = *reinterpret_cast<const f32x4*>(kp + 8 * g);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_32x32x2f32(kv[e], qreg[g][e], st, 0, 0, 0);
+        }
+    }
+    // ---- block-diagonal mask + softmax (single tile: no running state)
+    float tmax = -INFINITY;
+    {
+        int sl = 0, jj = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = qvalid && sl == sq && (jj * 2 + hi) < S;
+            if (!ok) st[r] = -INFINITY;
+            tmax = fmaxf(tmax, st[r]);
+            if (++jj == J) {
+                jj = 0;
+                ++sl;
+            }
+        }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if (tmax == -INFINITY) tmax = 0.f;    // column without a query: P = 0, nothing is stored
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        st[r] = expf(st[r] - tmax);
+        psum += st[r];
+    }
+    psum += __shfl_xor(psum, 32, 64);
+
+    // ---- O^T = V^T . P^T : V goes into the same LDS tile (the K reads above are complete: their values were used)
+    store_tile(vreg);
+    f32x16 ot[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int krow = (j & 3) + 8 * (j >> 2) + 4 * hi;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = n * 32 + l31;
+            const float v = (HD % 32 == 0 || col < HD) ? Ks[krow * KLD + (col < HD ? col : 0)] : 0.f;
+            ot[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, st[j], ot[n], 0, 0, 0);
+        }
+    }
+    if (qvalid) {
+        const float inv = 1.0f / psum;
+        float* op = a.OUT ? a.OUT + qtok * d + h * HD : nullptr;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int c0 = n * 32 + 8 * r4 + 4 * hi;
+                if (HD % 32 == 0 || c0 < HD) {
+                    f32x4 v = {ot[n][4 * r4 + 0] * inv, ot[n][4 * r4 + 1] * inv, ot[n][4 * r4 + 2] * inv,
+                               ot[n][4 * r4 + 3] * inv};
+                    if (a.Ohi) {
+                        f16x4 vh, vl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            half_t hh, ll;
+                            split_f32(v[e], hh, ll);
+                            vh[e] = hh;
+                            vl[e] = ll;
+                        }
+                        const size_t oo = blk_index((int)qtok, h * HD + c0, d);
+                        *reinterpret_cast<f16x4*>(a.Ohi + oo) = vh;
+                        *reinterpret_cast<f16x4*>(a.Olo + oo) = vl;
+                    } else {
+                        *reinterpret_cast<f32x4*>(op + c0) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int g_attn_pack = 1;   // tuning knob: 0 = one sequence per wave even when S <= 16 (A/B, jmid_set_tuning "attn_pack")
+
 template <int HD>
 inline hipError_t launch_attn_f32_hd(const AttnArgs& a, int nseq, hipStream_t st) {
+    if (a.S <= 16 && g_attn_pack) {
+        const int J = (a.S + 1) / 2;
+        const int G = std::min(32 / a.S, 16 / J);
+        const size_t lds = size_t(4) * 32 * (HD + 4) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_packed_kernel<HD>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        dim3 grid((nseq + G - 1) / G, (a.nhead + 3) / 4);
+        hipLaunchKernelGGL((attn_f32_packed_kernel<HD>), grid, dim3(256), lds, st, a, nseq, G, J);
+        return hipGetLastError();
+    }
     if (a.S > 32) {
         dim3 grid((a.S + 127) / 128, a.nhead, nseq);
         hipLaunchKernelGGL((attn_f32_kernel<HD, 4>), grid, dim3(256), 0, st, a);

@@ -1087,6 +1087,10 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         fprintf(stderr, "attn_f32_kernel<128,4>: %d workgroups/CU\n", n);
         return JMID_OK;
     }
+    if (k == "attn_pack") {   // 0: one short sequence per wave (old path), 1: packed short-sequence attention
+        g_attn_pack = value;
+        return JMID_OK;
+    }
     if (k == "ln_fuse") {   // 0 auto (M >= 16384 tokens), 1 always, 2 never: fused GEMM + residual + LayerNorm
         if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "ln_fuse must be 0..2");
         g_ln_fuse = value;

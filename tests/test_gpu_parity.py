@@ -251,3 +251,22 @@ def test_fused_gemm_layernorm_equals_gemm_then_add_ln(case):
         eng.set_tuning("ln_fuse", 0)
     np.testing.assert_array_equal(out[1], out[2])
     assert ade(out[1], z["vel"]) <= ADE_GATE
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", ["net_imid_w256_a5k20t12_s50.npz", "net_imid_w32_a2k3t4_s50.npz"])
+def test_packed_short_sequence_attention_matches_unpacked(case, precision):
+    """iMID sequences (S = T <= 16) share a wave's score tile (attn_f32_packed_kernel); one sequence per wave is the
+    old path.  Same math, different summation slots: both at reference parity and within 1e-5 of each other."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), False)
+    eng.set_step(int(z["step"]))
+    out = {}
+    try:
+        for mode in (1, 0):
+            eng.set_tuning("attn_pack", mode)
+            out[mode] = eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False)[0][0]
+    finally:
+        eng.set_tuning("attn_pack", 1)
+    assert ade(out[1], z["vel"]) <= ADE_GATE and ade(out[0], z["vel"]) <= ADE_GATE
+    assert ade(out[1], out[0]) <= 1e-5
