@@ -151,6 +151,11 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "gemm_h_variant"  F16X3 GEMM kernel: 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged,
  *                     3 = 128x128 LDS-DMA ring, 4 = 256x128 LDS-DMA ring, 5 = 64x64 LDS-DMA ring
  *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
+ *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 16384 tokens), 1 always, 2 never
+ *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
+ *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
+ *   "gemm_ng", "gemm_abl", "attn_abl", "print_occupancy"   diagnostics used by tools/ (ablations give WRONG results)
+ * All variants of a key compute the same values (bit-identical for ln_fuse and no_vt_direct).
  * Unknown keys return JMID_EINVAL. */
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream.
