@@ -270,3 +270,24 @@ def test_packed_short_sequence_attention_matches_unpacked(case, precision):
         eng.set_tuning("attn_pack", 1)
     assert ade(out[1], z["vel"]) <= ADE_GATE and ade(out[0], z["vel"]) <= ADE_GATE
     assert ade(out[1], out[0]) <= 1e-5
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("joint", [True, False])
+@pytest.mark.parametrize("shape", [(1, 1, 1, 1), (2, 3, 3, 5), (3, 2, 1, 24), (2, 5, 7, 3), (1, 4, 9, 17)])
+def test_edge_shapes_match_oracle(shape, joint, precision):
+    """Degenerate and ragged geometries at full width: a single token, odd sequence lengths (S % 4 != 0: the V^T
+    transpose kernel instead of the fused epilogue; partial packed-attention tiles), K = 1, T = max_len 24, T = 17
+    (iMID sequences longer than one packed slot)."""
+    E, A, K, T = shape
+    eng, w = get_engine(256, 23, joint)
+    eng.set_step(5)
+    g = torch.Generator().manual_seed(100 + E + 7 * A + 31 * K + 97 * T)
+    ctx = torch.randn([E, A, 256], generator=g)
+    x_T = torch.randn([E, K * A, T, 2], generator=g)
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx, x_T, sample=K, step=5, joint=joint)
+    vel, _ = eng.denoise(x_T.numpy(), ctx.numpy(), precision=precision, want_pos=False)
+    a = ade(vel, ref.numpy())
+    print(f"shape {shape} joint={joint} [{precision}] mean ADE vs oracle = {a:.3e}")
+    assert np.isfinite(vel).all() and a <= ADE_GATE
