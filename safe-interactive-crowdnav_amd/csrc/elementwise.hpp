@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 
 // ------------------------------------------------------------------------------------------------ add + LayerNorm
 // X[m,:] = LN(X[m,:] + Y[m,:]) * gamma + beta ; one wave per row, d <= 64*4*VPL
-// PLANES: the residual stream X lives ONLY in its hi/lo planes (blocked panel layout, hi + lo*2^-11 carries x to
+// PLANES: the residual stream X lives ONLY in its hi/lo planes (blocked panel layout, hi + lo carries x to
 // ~1 fp32 ulp): they are read for the residual and rewritten, the fp32 X array is not touched - one fp32 stream less
 // through HBM per LayerNorm.
 template <int VPL, bool PLANES>  // float4 vectors per lane
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
                 const f16x4 ph = *reinterpret_cast<const f16x4*>(Xh + ob);
                 const f16x4 pl = *reinterpret_cast<const f16x4*>(Xl + ob);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = fmaf((float)pl[e], kLoInv, (float)ph[e]);
+                for (int e = 0; e < 4; ++e) a[e] = (float)ph[e] + (float)pl[e];
             } else {
                 a = *reinterpret_cast<const f32x4*>(xr + c);
             }

@@ -1,11 +1,12 @@
 // "NT" GEMM with fp32-class accuracy at fp16 MFMA rate:  C[M,N] = A[M,K] . W[N,K]^T  (+ epilogue)
 //
-// Every fp32 operand x is carried as two fp16 planes  hi = fp16(x),  lo = fp16((x - hi) * 2^11)
-// (~22 significand bits; the 2^11 scale keeps the residual in the fp16 normal range).  A product is three
-// v_mfma_f32_32x32x16_f16 with fp32 accumulation in two accumulators:
-//     main += Ahi.Whi          corr += Ahi.Wlo + Alo.Whi          C = main + corr * 2^-11
-// (the lo.lo term is 2^-22 relative and dropped).  Peak is 1/3 of the dense fp16 MFMA rate = 833 TFLOP/s,
-// 5.3x the exact-fp32 MFMA path.
+// Every fp32 operand x is carried as two fp16 planes  hi = fp16(x),  lo = fp16(x - hi)  (~22 significand bits down
+// to 2^-25 absolute: v_mfma_f32_32x32x16_f16 takes fp16 subnormals exactly, tools/mfma_denorm.hip).  Weights are
+// multiplied by 2^8 before the split so that their residuals stay in the fp16 normal range (a weight of 0.04 would
+// otherwise keep only ~19 bits); the epilogue multiplies by 2^-8, which is exact.  A product is three MFMAs into
+// ONE fp32 accumulator:      acc += Ahi.Whi ; acc += Ahi.Wlo ; acc += Alo.Whi
+// (the lo.lo term is 2^-22 relative and dropped).  Operand representation error 8e-8 relative on a K = 512 product
+// (fp32 inputs: 6e-8).  Peak is 1/3 of the dense fp16 MFMA rate = 833 TFLOP/s, 5.3x the exact-fp32 MFMA path.
 //
 // Operand fragments are 8 consecutive k per lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15 of each 16-wide step);
 // A and W use the same per-lane k assignment, which is all the instruction requires.
@@ -22,19 +23,20 @@
 namespace jmid {
 
 typedef _Float16 half_t;
-constexpr float kLoScale = 2048.0f;
-constexpr float kLoInv = 1.0f / 2048.0f;
+constexpr float kWScale = 256.0f;           // weights are split as W * 2^8 ...
+constexpr float kWInv = 1.0f / 256.0f;      // ... and every GEMM epilogue scales the accumulator back (exact)
 constexpr float kHalfMax = 60000.0f;
 
 __device__ __forceinline__ void split_f32(float v, half_t& hi, half_t& lo) {
-    hi = (half_t)v;
-    lo = (half_t)((v - (float)hi) * kLoScale);
-}
-// attention operands: residual kept unscaled (subnormal fp16 is exact in the MFMA; see attn_f16x3.hpp)
-__device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& lo) {
+    // v must be an opaque fp32 value here: when v = a * b (or fma) hipcc fuses ONE of the two uses of fp16(v) into
+    // v_fma_mixlo_f16 (single rounding from the exact product) and converts the other from the rounded fp32 - the
+    // stored hi and the hi inside lo then differ by one fp16 ulp at near-ties (seen as 2^-12 errors in 1 of 25 000
+    // attention outputs)
+    asm("" : "+v"(v));
     hi = (half_t)v;
     lo = (half_t)(v - (float)hi);
 }
+__device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& lo) { split_f32(v, hi, lo); }
 
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
@@ -72,23 +74,23 @@ constexpr size_t gemm_h_lds_bytes() {
     return size_t(2) /*buffers*/ * 2 /*planes*/ * (64 * WM + 64 * WN) * GEMMH_LD * sizeof(half_t);
 }
 
-// three passes over the wave's tiles so that the two MFMAs into the same correction accumulator are WM*WN
-// instructions apart (a back-to-back dependent pair stalls for the MFMA latency)
+// three passes over the wave's tiles so that consecutive MFMAs into the same accumulator are WM*WN instructions
+// apart (a back-to-back dependent pair stalls for the MFMA latency)
 template <int WM, int WN>
 __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[WM], const f16x8 (&wh)[WN],
-                                      const f16x8 (&wl)[WN], f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN]) {
+                                      const f16x8 (&wl)[WN], f32x16 (&acc)[WM][WN]) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], accm[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], accc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) accc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], accc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
 }
 
 // Epilogue.  FULL = the whole block tile is inside [M, N] (block-uniform): no per-element predication, so the
@@ -96,7 +98,7 @@ __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[W
 // with an empty asm: otherwise hipcc re-waits `vmcnt(0)` before every use inside the store loop, and since stores
 // count on vmcnt too (CDNA4) every store would wait for the previous one to complete.
 template <int WM, int WN, int EPI, int OUT, bool FULL>
-__device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN],
+__device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 (&accm)[WM][WN],
                                                      int m0, int n0, int wr, int wc, int l31, int hi) {
     bool overflow = false;
     float bv[WN], tg[WN], tb[WN];
@@ -138,7 +140,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     f16x4 vh, vl;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float v = fmaf(accc[i][j][4 * q + e], kLoInv, accm[i][j][4 * q + e]) + bv[j];
+                        const float v = fmaf(accm[i][j][4 * q + e], kWInv, bv[j]);
                         half_t hh, ll;
                         split_f32_unscaled(v, hh, ll);
                         overflow |= !(fabsf(v) <= kHalfMax);
@@ -159,7 +161,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wr * WM * 32 + i * 32 + frag_row(r, hi);
                 if (!FULL && m >= g.M) continue;
-                float v = fmaf(accc[i][j][r], kLoInv, accm[i][j][r]) + bv[j];
+                float v = fmaf(accm[i][j][r], kWInv, bv[j]);
                 if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
                 if (EPI == EPI_CSL) {
                     const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
@@ -200,13 +202,13 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
 }
 
 template <int WM, int WN, int EPI, int OUT>
-__device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&accm)[WM][WN], f32x16 (&accc)[WM][WN],
+__device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&accm)[WM][WN],
                                                 int m0, int n0, int wr, int wc, int l31, int hi, int bm = 64 * WM,
                                                 int bn = 64 * WN) {
     if (m0 + bm <= g.M && n0 + bn <= g.N)
-        gemm_h_epilogue_impl<WM, WN, EPI, OUT, true>(g, accm, accc, m0, n0, wr, wc, l31, hi);
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, true>(g, accm, m0, n0, wr, wc, l31, hi);
     else
-        gemm_h_epilogue_impl<WM, WN, EPI, OUT, false>(g, accm, accc, m0, n0, wr, wc, l31, hi);
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, false>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
 template <int WM, int WN, int EPI, int OUT>
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
         }
     };
 
-    f32x16 accm[WM][WN], accc[WM][WN];
+    f32x16 accm[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -275,7 +277,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 accm[i][j][r] = 0.f;
-                accc[i][j][r] = 0.f;
             }
 
     const int nk = g.K / GEMMH_BK;
@@ -303,13 +304,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
                 wh[j] = *reinterpret_cast<const f16x8*>(Wh + j * 32 * LD + ks * 16);
                 wl[j] = *reinterpret_cast<const f16x8*>(Wl + j * 32 * LD + ks * 16);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+            mfma3<WM, WN>(ah, al, wh, wl, accm);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi);
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
 template <int WM, int WN, int EPI, int OUT>
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
                 (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
     };
 
-    f32x16 accm[WM][WN], accc[WM][WN];
+    f32x16 accm[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -387,7 +388,6 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 accm[i][j][r] = 0.f;
-                accc[i][j][r] = 0.f;
             }
 
     issue(0);
@@ -430,10 +430,10 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
                 wh[j] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offW[j][ks]);
                 wl[j] = *reinterpret_cast<const f16x8*>(st + 3 * DMA_PLANE + offW[j][ks]);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+            mfma3<WM, WN>(ah, al, wh, wl, accm);
         }
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi);
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
 template <int EPI, int OUT>
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
                                              (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
     };
 
-    f32x16 accm[WM][WN], accc[WM][WN];
+    f32x16 accm[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -501,7 +501,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 accm[i][j][r] = 0.f;
-                accc[i][j][r] = 0.f;
             }
     // fragment read offsets (halfs).  A rows 0-127 live in image 0, rows 128-255 in image 1; lo planes 2 images later.
     int offA[WM][2], offW[WN][2];
@@ -550,12 +549,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 #pragma unroll
                 for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(wh[i]), "v"(wl[i]));
             } else {
-                mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+                mfma3<WM, WN>(ah, al, wh, wl, accm);
             }
         }
         stage = stage == 2 ? 0 : stage + 1;
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi, BM, BN);
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
 template <int EPI, int OUT>
@@ -607,11 +606,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
                                              (__attribute__((address_space(3))) void*)(st + i * DMA64_PLANE), 16, 0, 0);
     };
-    f32x16 accm[1][1], accc[1][1];
+    f32x16 accm[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         accm[0][0][r] = 0.f;
-        accc[0][0][r] = 0.f;
     }
     const int rowA = wr * 32 + l31, rowW = wc * 32 + l31;
     int offA[2], offW[2];
@@ -638,10 +636,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
             al[0] = *reinterpret_cast<const f16x8*>(st + DMA64_PLANE + offA[ks]);
             wh[0] = *reinterpret_cast<const f16x8*>(st + 2 * DMA64_PLANE + offW[ks]);
             wl[0] = *reinterpret_cast<const f16x8*>(st + 3 * DMA64_PLANE + offW[ks]);
-            mfma3<1, 1>(ah, al, wh, wl, accm, accc);
+            mfma3<1, 1>(ah, al, wh, wl, accm);
         }
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, accc, m0, n0, wr, wc, l31, hi, BM, BN);
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
 template <int EPI, int OUT>
@@ -691,12 +689,13 @@ __global__ void split_planes_kernel(const float* in, half_t* hi, half_t* lo, siz
 }
 
 // fp32 row-major [rows, K] -> hi/lo planes in the blocked panel layout (weights at load time, diagnostics)
-__global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K, int* range_flag) {
+__global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K, int* range_flag,
+                                            float scale) {   // scale = kWScale for weights, 1 for activations
     bool overflow = false;
     const size_t n = (size_t)rows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / K), k = (int)(i % K);
-        const float v = in[i];
+        const float v = in[i] * scale;
         half_t h, l;
         split_f32(v, h, l);
         overflow |= !(fabsf(v) <= kHalfMax);
@@ -749,7 +748,7 @@ __global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* o
     const size_t n = (size_t)rows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t o = blk_index((int)(i / K), (int)(i % K), K);
-        out[i] = (float)hi[o] + (float)lo[o] * kLoInv;
+        out[i] = (float)hi[o] + (float)lo[o];
     }
 }
 

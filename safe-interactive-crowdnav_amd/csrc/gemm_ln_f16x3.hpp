@@ -47,7 +47,7 @@ __global__ void split_planes_k16_kernel(const float* in, half_t* hi, half_t* lo,
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / K), k = (int)(i % K);
         half_t h, l;
-        split_f32(in[i], h, l);
+        split_f32(in[i] * kWScale, h, l);
         const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + (k & 15);
         hi[o] = h;
         lo[o] = l;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
         }
     };
 
-    f32x16 accm[WM][WN], accc[WM][WN];
+    f32x16 accm[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -98,7 +98,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 accm[i][j][r] = 0.f;
-                accc[i][j][r] = 0.f;
             }
     int offA[WM][2], offW[WN];
 #pragma unroll
@@ -139,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
             wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
             wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
         }
-        mfma3<WM, WN>(ah, al, wh, wl, accm, accc);
+        mfma3<WM, WN>(ah, al, wh, wl, accm);
         wst = wst == 2 ? 0 : wst + 1;
     };
     for (int s = 0; s < nsteps; s += 2) {
@@ -181,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     tile[(i * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
-                        fmaf(accc[i][j][r], kLoInv, accm[i][j][r]) + bv[j];
+                        fmaf(accm[i][j][r], kWInv, bv[j]);
     }
     __syncthreads();
     // residual + LayerNorm, one wave per row, 8 rows per wave (the arithmetic of add_ln_kernel<2, true>)
@@ -196,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
             const int c = (i * 64 + lane) * 4;
             f32x4 a;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = fmaf((float)rpl[rr][i][e], kLoInv, (float)rph[rr][i][e]);
+            for (int e = 0; e < 4; ++e) a[e] = (float)rph[rr][i][e] + (float)rpl[rr][i][e];
             const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
             v[i] = a + y;
             sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];

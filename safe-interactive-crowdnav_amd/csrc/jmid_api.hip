@@ -904,7 +904,7 @@ int jmid_finalize_weights(jmid_handle_t h) {
             HIPCHK(h, hipMemsetAsync(hp.hi, 0, pe * sizeof(half_t), h->stream));
             HIPCHK(h, hipMemsetAsync(hp.lo, 0, pe * sizeof(half_t), h->stream));
             hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(256), dim3(256), 0, h->stream, b.p, hp.hi, hp.lo,
-                               (int)shp[0], (int)shp[1], h->range_flag);
+                               (int)shp[0], (int)shp[1], h->range_flag, kWScale);
             HIPCHK(h, hipGetLastError());
             h->wsplit[nm] = hp;
         }
@@ -1207,9 +1207,9 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
         for (auto pr : {std::make_pair(ah, pa), std::make_pair(al, pa), std::make_pair(wh, pw), std::make_pair(wl, pw)})
             HIPCHK(h, hipMemsetAsync(pr.first, 0, pr.second, h->stream));
         hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(512), dim3(256), 0, h->stream, dA, ah, al, M, K,
-                           h->range_flag);
+                           h->range_flag, 1.0f);
         hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(512), dim3(256), 0, h->stream, dW, wh, wl, N, K,
-                           h->range_flag);
+                           h->range_flag, kWScale);
         GemmHArgs g{};
         g.Ahi = ah; g.Alo = al; g.Whi = wh; g.Wlo = wl; g.bias = dB; g.C = dC; g.ldc = N;
         g.M = M; g.N = N; g.K = K;
