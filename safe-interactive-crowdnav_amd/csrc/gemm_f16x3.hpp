@@ -572,6 +572,128 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 256x256 LDS-DMA variant (N a multiple of 256: in_proj 1536, linear1 1024): 8 waves (4 along M x 2 along N), wave tile
+// 64 x 128 - possible since the product needs ONE accumulator set (128 VGPRs).  A third fewer operand bytes per FLOP
+// through L2 -> LDS and a quarter fewer fragment reads per MFMA than the 256x128 tile.  64 KB stages, 2-stage ring:
+// one K-tile of look-ahead is 48 MFMAs per wave, the same cover time as two tiles of the 256x128 kernel.
+constexpr int DMA3_STAGE = 8 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi(2), Wlo(2)
+constexpr size_t DMA3_LDS_BYTES = size_t(2) * DMA3_STAGE * sizeof(half_t);
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn) {
+    constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;                 // wr 0..3 (64 rows each), wc 0..1 (128 columns each)
+    // XCD-contiguous tile ranges, N fastest: the N-tiles of an M-tile run together and share its A panels in L2
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int tm = swz / ntn, tn = swz - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = g.K / GEMMH_BK;
+    const int nrb = (g.M + 127) / 128;
+    const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
+    const half_t* src[8];
+    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[2] = g.Alo + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[3] = g.Alo + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[4] = g.Whi + (size_t)(2 * tn) * nk * 4096 + tid * 8;
+    src[5] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
+    src[6] = g.Wlo + (size_t)(2 * tn) * nk * 4096 + tid * 8;
+    src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
+    auto issue_one = [&](int kt, int i) {
+        half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
+                                         (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
+    };
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int offA[WM][2], offW[WN][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = wr * 64 + i * 32 + l31, r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offA[i][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int row = wc * 128 + j * 32 + l31, r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offW[j][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_one(0, i);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kt + 1 < nk;
+        const half_t* st = lds + (kt & 1) * DMA3_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
+                al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
+                wl[j] = *reinterpret_cast<const f16x8*>(st + 6 * DMA_PLANE + offW[j][ks]);
+            }
+            // the 8 DMA instructions of the next K-tile go out behind the MFMA groups, four per 16-deep step
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+            if (more) {
+                issue_one(kt + 1, 4 * ks + 0);
+                issue_one(kt + 1, 4 * ks + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+            if (more) {
+                issue_one(kt + 1, 4 * ks + 2);
+                issue_one(kt + 1, 4 * ks + 3);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    gemm_h_epilogue<WM, WN, EPI, OUT>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
+}
+
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
+    const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 64x64 LDS-DMA variant for small M (one scene: M = 1200 tokens): the K loop of a small tile is pure latency, so the
 // 4-stage ring (three 16 KB K-tiles in flight, 64 KB of LDS, two workgroups per CU) matters more here than anywhere.
 // A 64-row half of a 128-row panel image is a contiguous 4 KB piece: one DMA round per plane.
@@ -659,17 +781,24 @@ template <int EPI, int OUT>
 inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA,
-    // 5 = 64x64 LDS-DMA
+    // 5 = 64x64 LDS-DMA, 6 = 256x256 LDS-DMA (N % 256 == 0)
     const int v = g_gemm_h_variant;
     if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
     if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT>(g, st);
     if (v == 3) return launch_gemm_h_dma<EPI, OUT>(g, st);
     if (v == 4) return launch_gemm_h_dma256<EPI, OUT>(g, st);
     if (v == 5) return launch_gemm_h_dma64<EPI, OUT>(g, st);
+    if (v == 6 && g.N % 256 == 0) return launch_gemm_h_dma256x256<EPI, OUT>(g, st);
     if (big < 256) return launch_gemm_h_dma64<EPI, OUT>(g, st);
     // auto: 256x128 unless the coarser grid quantises badly onto the 256 CUs (one workgroup per CU)
     const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };
+    // 256x256 when N allows it (in_proj, linear1) and the grid still fills the chip; the ConcatSquash epilogue needs
+    // too many registers next to the 128 accumulators
+    if (EPI != EPI_CSL && g.N % 256 == 0) {
+        const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
+        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_h_dma256x256<EPI, OUT>(g, st);
+    }
     if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT>(g, st);
     return launch_gemm_h_dma<EPI, OUT>(g, st);
 }

@@ -1070,7 +1070,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     if (!h || !key) return JMID_EINVAL;
     const std::string k(key);
     if (k == "gemm_h_variant") {
-        if (value < 0 || value > 5) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..5");
+        if (value < 0 || value > 6) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..6");
         g_gemm_h_variant = value;
         return JMID_OK;
     }

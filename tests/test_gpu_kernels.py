@@ -85,3 +85,24 @@ def test_add_layernorm_matches_torch(engine, M):
     ref = torch.nn.functional.layer_norm(torch.from_numpy(X + Y).double(), (d,), torch.from_numpy(g).double(),
                                          torch.from_numpy(b).double(), 1e-5).numpy()
     assert np.abs(out - ref).max() <= 1e-5
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("M,N,K", [(700, 512, 512), (513, 256, 64), (1025, 1536, 512)])
+def test_f16x3_gemm_variants_agree_bitwise(engine, variant, M, N, K):
+    """Every tile configuration of the split-fp16 GEMM accumulates k in the same order with the same three MFMAs per
+    step: the kernels are interchangeable bit for bit (tile selection by size must not change a result)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    try:
+        engine.set_tuning("gemm_h_variant", 0)
+        ref = engine.dbg_gemm(A, W, b, precision="f16x3")
+        engine.set_tuning("gemm_h_variant", variant)
+        out = engine.dbg_gemm(A, W, b, precision="f16x3")
+    finally:
+        engine.set_tuning("gemm_h_variant", 0)
+    np.testing.assert_array_equal(out, ref)
+    exact = A.astype(np.float64) @ W.astype(np.float64).T + b
+    assert np.abs(out - exact).max() <= TOL["f16x3"] * max(1.0, np.abs(exact).max())
