@@ -233,12 +233,207 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
     if (overflow) atomicOr(g.range_flag, 1);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 128-row variant (M >= 32768): wave tile 128 x 64 (one accumulator set = 128 VGPRs), so W streams through
+// L2 -> LDS once per 128 rows instead of once per 64.  A ring: 3 stages of a whole k32 panel image per plane (2 DMA
+// instructions per wave); W ring as above.  Six DMA wave-instructions are younger than W(s) at every wait.  The fp32
+// epilogue tile holds 64 rows, so the epilogue runs in two passes.
+constexpr int GLN2_BM = 128;
+constexpr int GLN2_A_STAGE = 2 * GLN2_BM * 32;   // halfs: hi image (4096) + lo image
+constexpr int GLN2_A_OFF = 3 * GLN_W_STAGE;
+constexpr size_t GLN2_LDS_BYTES = size_t(GLN2_A_OFF + 3 * GLN2_A_STAGE) * sizeof(half_t);   // 96 + 48 = 144 KB
+static_assert(size_t(64) * GLN_TILE_LD * sizeof(float) <= GLN2_LDS_BYTES, "epilogue tile must fit the ring");
+
+__global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, int ntm) {
+    constexpr int WM = 4, WN = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wid;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int m0 = tm * GLN2_BM;
+    const int nk = g.K / 32, nsteps = 2 * nk;
+
+    const half_t* a_hi = g.Ahi + (size_t)tm * nk * 4096 + tid * 8;
+    const half_t* a_lo = g.Alo + (size_t)tm * nk * 4096 + tid * 8;
+    auto issueA = [&](int ka) {     // two wave-instructions; past the end: the last tile again into its own stage
+        const int kk = ka < nk ? ka : nk - 1;       // (identical bytes: harmless while that stage is being read)
+        half_t* dst = lds + GLN2_A_OFF + (kk % 3) * GLN2_A_STAGE + wid * 512;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_hi + (size_t)kk * 4096),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_lo + (size_t)kk * 4096),
+                                         (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+    };
+    auto issueW = [&](int s, int stage) {
+        half_t* st = lds + GLN_W_OFF + stage * GLN_W_STAGE + wc * 64 * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const half_t* src = ((q >> 1) ? g.W16lo : g.W16hi) + ((size_t)s * GLN_BN + wc * 64 + (q & 1) * 32) * 16 + lane * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + (q >> 1) * GLN_BN * 16 + (q & 1) * 512),
+                                             16, 0, 0);
+        }
+    };
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int offA[WM][2], offW[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = i * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) offA[i][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) offW[j] = (wc * 64 + j * 32 + l31) * 16 + hi * 8;
+
+    // issue order A0 W0 A1 W1, then per step W(s+2) [+ A(s/2+2) on even steps]
+    issueA(0);
+    issueW(0, 0);
+    issueA(1);
+    issueW(1, 1);
+    int wst = 0, ast = 0;
+    auto step = [&](const int s, const int ks) {
+        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ks == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nsteps) issueW(s + 2, wst == 0 ? 2 : wst - 1);
+        if (ks == 0) issueA((s >> 1) + 2);
+        const half_t* stA = lds + GLN2_A_OFF + ast * GLN2_A_STAGE;
+        const half_t* stW = lds + GLN_W_OFF + wst * GLN_W_STAGE;
+        f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            ah[i] = *reinterpret_cast<const f16x8*>(stA + offA[i][ks]);
+            al[i] = *reinterpret_cast<const f16x8*>(stA + 4096 + offA[i][ks]);
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
+            wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
+        }
+        mfma3<WM, WN>(ah, al, wh, wl, acc);
+        wst = wst == 2 ? 0 : wst + 1;
+        if (ks == 1) ast = ast == 2 ? 0 : ast + 1;
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(s, 0);
+        step(s + 1, 1);
+    }
+
+    // ---- epilogue in two passes of 64 rows (same arithmetic as above / add_ln_kernel<2, true>)
+    constexpr int d = GLN_BN;
+    float* tile = reinterpret_cast<float*>(lds_raw);
+    f32x4 gm[2], bt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gm[i] = *reinterpret_cast<const f32x4*>(g.gamma + (i * 64 + lane) * 4);
+        bt[i] = *reinterpret_cast<const f32x4*>(g.beta + (i * 64 + lane) * 4);
+    }
+    float bv[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bv[j] = g.bias[wc * 64 + j * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]));
+    bool overflow = false;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        f16x4 rph[8][2], rpl[8][2];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const size_t ob = blk_index(m0 + pass * 64 + wid * 8 + rr, (i * 64 + lane) * 4, d);
+                rph[rr][i] = *reinterpret_cast<const f16x4*>(g.Xh + ob);
+                rpl[rr][i] = *reinterpret_cast<const f16x4*>(g.Xl + ob);
+            }
+        __syncthreads();   // pass 0: everybody is done with the rings; pass 1: everybody has read the tile of pass 0
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(i2 * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
+                        fmaf(acc[pass * 2 + i2][j][r], kWInv, bv[j]);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int trow = wid * 8 + rr, row = m0 + pass * 64 + trow;
+            f32x4 v[2];
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (float)rph[rr][i][e] + (float)rpl[rr][i][e];
+                const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
+                v[i] = a + y;
+                sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+            const float mean = wave_sum(sacc) / (float)d;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[i][e] - mean;
+                    q += t * t;
+                }
+            const float rstd = rsqrtf(wave_sum(q) / (float)d + g.eps);
+            if (row < g.M) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                        half_t hh, ll;
+                        split_f32(o, hh, ll);
+                        overflow |= !(fabsf(o) <= kHalfMax);
+                        vh[e] = hh;
+                        vl[e] = ll;
+                    }
+                    const size_t ob = blk_index(row, c, d);
+                    *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
+                    *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
+                }
+            }
+        }
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
+}
+
+static int g_ln_rows = 0;   // tuning knob "ln_rows": 0 auto (128-row tiles from 32768 tokens), 64, 128
+
 inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_f16x3_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN_LDS_BYTES);
         attr_set = true;
+    }
+    const bool rows128 = g_ln_rows == 128 || (g_ln_rows == 0 && g.M >= 32768);
+    if (rows128) {
+        static bool attr2_set = false;
+        if (!attr2_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_f16x3_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN2_LDS_BYTES);
+            attr2_set = true;
+        }
+        const int ntm = (g.M + GLN2_BM - 1) / GLN2_BM;
+        hipLaunchKernelGGL(gemm_ln128_f16x3_kernel, dim3(ntm), dim3(512), GLN2_LDS_BYTES, st, g, ntm);
+        return hipGetLastError();
     }
     const int ntm = (g.M + GLN_BM - 1) / GLN_BM;
     hipLaunchKernelGGL(gemm_ln_f16x3_kernel, dim3(ntm), dim3(512), GLN_LDS_BYTES, st, g, ntm);

@@ -1091,6 +1091,11 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         g_attn_pack = value;
         return JMID_OK;
     }
+    if (k == "ln_rows") {   // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
+        if (value != 0 && value != 64 && value != 128) return fail(h, JMID_EINVAL, "ln_rows must be 0, 64 or 128");
+        g_ln_rows = value;
+        return JMID_OK;
+    }
     if (k == "ln_fuse") {   // 0 auto (M >= 16384 tokens), 1 always, 2 never: fused GEMM + residual + LayerNorm
         if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "ln_fuse must be 0..2");
         g_ln_fuse = value;

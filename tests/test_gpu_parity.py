@@ -244,13 +244,16 @@ def test_fused_gemm_layernorm_equals_gemm_then_add_ln(case):
     eng.set_step(int(z["step"]))
     out = {}
     try:
-        for mode in (1, 2):      # 1 = always fused, 2 = never
+        for mode, rows in ((1, 64), (1, 128), (2, 0)):      # fused with 64- / 128-row tiles, never fused
             eng.set_tuning("ln_fuse", mode)
-            out[mode] = eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16x3", want_pos=False)[0][0]
+            eng.set_tuning("ln_rows", rows)
+            out[(mode, rows)] = eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16x3", want_pos=False)[0][0]
     finally:
         eng.set_tuning("ln_fuse", 0)
-    np.testing.assert_array_equal(out[1], out[2])
-    assert ade(out[1], z["vel"]) <= ADE_GATE
+        eng.set_tuning("ln_rows", 0)
+    np.testing.assert_array_equal(out[(1, 64)], out[(2, 0)])
+    np.testing.assert_array_equal(out[(1, 128)], out[(2, 0)])
+    assert ade(out[(1, 64)], z["vel"]) <= ADE_GATE
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
