@@ -64,6 +64,10 @@ struct HalfPair {
 struct jmid_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    static constexpr int kMaxLanes = 4;
+    hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};   // extra lanes of the chunk loop
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
+    int lanes = 2;                          // chunks in flight at once, 1..4 (jmid_set_tuning "lanes")
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
     HyperLayout hl;
@@ -588,7 +592,13 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         io_off = c.off;
     }
     const SeqGeom sg_full = seq_geom(h, Ec, A, K, T);
-    const size_t need = io_off + step_ws_floats(h, Mc, precision, sg_full, nullptr, nullptr);
+    // Independent chunks run `lanes` at a time on separate streams: the partially filled last round of one chunk's
+    // kernels and its bandwidth-bound kernels overlap with another chunk's MFMA kernels.  Each lane has its own step
+    // workspace; results do not depend on the number of lanes.
+    const int nchunks = (E + Ec - 1) / Ec;
+    const int lanes = single_step < 0 ? std::max(1, std::min(h->lanes, nchunks)) : 1;
+    const size_t lane_floats = step_ws_floats(h, Mc, precision, sg_full, nullptr, nullptr);
+    const size_t need = io_off + lanes * lane_floats;
     if (int rc = ensure_arena(h, need)) return rc;
     Carver c(h->arena);
     float* x_cur = c.take(M * 2);
@@ -602,14 +612,16 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         HIPCHK(h, hipMemcpyAsync(zd, z_in, M * 2 * h->beta.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         z_use = zd;
     }
-    StepBuffers sb;
-    step_ws_floats(h, Mc, precision, sg_full, &sb, h->arena + io_off);
+    StepBuffers sbs[jmid_ctx::kMaxLanes];
+    for (int l = 0; l < lanes; ++l) step_ws_floats(h, Mc, precision, sg_full, &sbs[l], h->arena + io_off + l * lane_floats);
+    const StepBuffers& sb = sbs[0];
     if (precision == JMID_PREC_F16X3) {
         HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
-        if (sb.Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
-            HIPCHK(h, hipMemsetAsync(sb.Vth, 0, sb.vt_elems * sizeof(half_t), h->stream));
-            HIPCHK(h, hipMemsetAsync(sb.Vtl, 0, sb.vt_elems * sizeof(half_t), h->stream));
-        }
+        for (int l = 0; l < lanes; ++l)
+            if (sbs[l].Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
+                HIPCHK(h, hipMemsetAsync(sbs[l].Vth, 0, sbs[l].vt_elems * sizeof(half_t), h->stream));
+                HIPCHK(h, hipMemsetAsync(sbs[l].Vtl, 0, sbs[l].vt_elems * sizeof(half_t), h->stream));
+            }
     }
 
     const hipMemcpyKind kin = mem == JMID_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
@@ -633,19 +645,38 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         if (int rc = run_gemm<EPI_BIAS>(h, KC_HYPER, g)) return rc;
     }
     const int n_steps = (int)h->beta.size();
-    for (int e0 = 0; e0 < E; e0 += Ec) {
-        const int ec = std::min(Ec, E - e0);
-        float* xc = x_cur + (size_t)e0 * K * A * T * 2;
-        const float* hc = hyp + (size_t)e0 * A * h->hl.total;
+    if (lanes > 1) {   // everything enqueued so far (inputs, hyper nets, memsets) precedes the extra lanes as well
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        for (int l = 1; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l - 1], h->ev_fork, 0));
+    }
+    for (int e0 = 0; e0 < E; e0 += lanes * Ec) {
         if (single_step >= 0) {
+            const int ec = std::min(Ec, E - e0);
             float* eo = stage + (size_t)e0 * K * A * T * 2;
-            if (int rc = net_step(h, sb, ec, A, K, T, single_step, xc, hc, eo, precision)) return rc;
-        } else {
-            for (int i = 0; i < n_steps; ++i) {
-                const float* zc = z_use ? z_use + ((size_t)i * M + (size_t)e0 * K * A * T) * 2 : nullptr;
-                if (int rc = net_step(h, sb, ec, A, K, T, i, xc, hc, nullptr, precision, zc)) return rc;
+            if (int rc = net_step(h, sb, ec, A, K, T, single_step, x_cur + (size_t)e0 * K * A * T * 2,
+                                  hyp + (size_t)e0 * A * h->hl.total, eo, precision))
+                return rc;
+            continue;
+        }
+        // the steps of the chunks of this round are enqueued alternately so that all queues stay fed
+        for (int i = 0; i < n_steps; ++i) {
+            for (int l = 0; l < lanes; ++l) {
+                const int el = e0 + l * Ec;
+                if (el >= E) break;
+                const int ec = std::min(Ec, E - el);
+                float* xc = x_cur + (size_t)el * K * A * T * 2;
+                const float* hc = hyp + (size_t)el * A * h->hl.total;
+                const float* zc = z_use ? z_use + ((size_t)i * M + (size_t)el * K * A * T) * 2 : nullptr;
+                if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);   // net_step launches on h->stream
+                const int rc = net_step(h, sbs[l], ec, A, K, T, i, xc, hc, nullptr, precision, zc);
+                if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);
+                if (rc) return rc;
             }
         }
+    }
+    for (int l = 1; l < lanes; ++l) {
+        HIPCHK(h, hipEventRecord(h->ev_join[l - 1], h->lane_stream[l - 1]));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join[l - 1], 0));
     }
     if (single_step >= 0) {
         HIPCHK(h, hipMemcpyAsync(e_out, stage, M * 2 * sizeof(float), kout, h->stream));
@@ -720,7 +751,12 @@ int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, in
     h->H = ctx_dim / 2;
     h->hl = make_hyper_layout(h->d, h->dmid, h->dlow);
     register_shapes(h);
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&h->stream) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int l = 0; ok && l < jmid_ctx::kMaxLanes - 1; ++l)
+        ok = hipStreamCreate(&h->lane_stream[l]) == hipSuccess &&
+             hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         delete h;
         return fail(nullptr, JMID_EHIP, "cannot create a HIP stream");
     }
@@ -754,6 +790,11 @@ int jmid_destroy(jmid_handle_t h) {
         hipEventDestroy(ev.b);
     }
     hipStreamDestroy(h->stream);
+    for (int l = 0; l < jmid_ctx::kMaxLanes - 1; ++l) {
+        hipStreamDestroy(h->lane_stream[l]);
+        hipEventDestroy(h->ev_join[l]);
+    }
+    hipEventDestroy(h->ev_fork);
     delete h;
     return JMID_OK;
 }
@@ -1089,6 +1130,11 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     }
     if (k == "attn_pack") {   // 0: one short sequence per wave (old path), 1: packed short-sequence attention
         g_attn_pack = value;
+        return JMID_OK;
+    }
+    if (k == "lanes") {     // chunks of the denoise loop in flight at once: 1..4
+        if (value < 1 || value > jmid_ctx::kMaxLanes) return fail(h, JMID_EINVAL, "lanes must be 1..4");
+        h->lanes = value;
         return JMID_OK;
     }
     if (k == "ln_rows") {   // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128

@@ -294,3 +294,24 @@ def test_edge_shapes_match_oracle(shape, joint, precision):
     a = ade(vel, ref.numpy())
     print(f"shape {shape} joint={joint} [{precision}] mean ADE vs oracle = {a:.3e}")
     assert np.isfinite(vel).all() and a <= ADE_GATE
+
+
+def test_chunk_lanes_do_not_change_results():
+    """Chunks of the denoise loop run concurrently on 1..4 streams (jmid_set_tuning "lanes"): same bits."""
+    eng, w = get_engine(32, 77, True)
+    eng.set_step(10)
+    E, A, K, T = 7, 3, 4, 6
+    g = torch.Generator().manual_seed(9)
+    ctx = torch.randn([E, A, 32], generator=g).numpy()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).numpy()
+    outs = []
+    try:
+        eng.set_chunk_episodes(2)            # 4 chunks, the last one ragged
+        for lanes in (1, 2, 3, 4):
+            eng.set_tuning("lanes", lanes)
+            outs.append(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0])
+    finally:
+        eng.set_tuning("lanes", 2)
+        eng.set_chunk_episodes(0)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
