@@ -26,7 +26,7 @@ for a, b in [("bench_cfg3_f16x3.log", "bench_cfg3_f16x3.log"), ("bench_cfg3_f32.
              ("bench_cfg2.log", "bench_cfg2.log"), ("bench_cfg4.log", "bench_cfg4.log"), ("bench_cfg5_1gpu.log", "bench_cfg5_1gpu.log"),
              ("bench_cfg3_imid.log", "bench_cfg3_imid.log"), ("pmc_raw.json", "pmc_raw.json")]:
     shutil.copy("gpurun_out/final/" + a, f"profiles/{pref}_{b}")
-hdr = ("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 1 --warmup 0 --cpu-episodes 0 "
+hdr = ("# rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 "
        "--episodes-per-gpu 51   (final kernels of the round, F16X3 path; durations in ns; the run holds one untimed "
        "profiling step, one timed step and the single-scene calls bench.py makes afterwards)\n")
 open(f"profiles/{pref}_f16x3_kernel_stats.csv", "w").write(hdr + open("gpurun_out/final/f16x3_kernel_stats.csv").read())
