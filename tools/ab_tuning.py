@@ -13,6 +13,10 @@ dev = torch.device("cuda", 0)
 eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 0), joint=os.environ.get("AB_NET", "jmid") == "jmid", step=50)
 ctx = torch.randn([E, N, 256], generator=torch.Generator().manual_seed(1)).to(dev)
 x_T = torch.randn([E, K * N, H, 2], generator=torch.Generator().manual_seed(0)).to(dev)
+if os.environ.get("AB_CHUNK"):
+    eng.set_chunk_episodes(int(os.environ["AB_CHUNK"]))
+if os.environ.get("AB_LANES"):
+    eng.set_tuning("lanes", int(os.environ["AB_LANES"]))
 res = {v: [] for v in vals}
 for rep in range(4):
     for v in vals:
