@@ -181,12 +181,13 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
             const int vrow = n * 32 + l31;
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
-                // keys of this lane-half for MFMA mf: {16mf + 4hi + 0..3, 16mf + 8 + 4hi + 0..3}
-                const int c0 = vrow * VLD + 16 * mf + 4 * (hi ^ ((vrow >> 4) & 1));
+                // keys of this lane-half for MFMA mf: {16mf + 4hi + 0..3, 16mf + 8 + 4hi + 0..3} = stored positions
+                // 16mf + 8hi .. +7 (common.hpp::vt_key_pos)
+                const int c0 = vrow * VLD + 16 * mf + 8 * hi;
                 const f16x4 vh0 = *reinterpret_cast<const f16x4*>(&Vsh[c0]);
-                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(&Vsh[c0 + 8]);
+                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(&Vsh[c0 + 4]);
                 const f16x4 vl0 = *reinterpret_cast<const f16x4*>(&Vsl[c0]);
-                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(&Vsl[c0 + 8]);
+                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(&Vsl[c0 + 4]);
                 const f16x8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
                 const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
@@ -232,8 +233,8 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
 // 2-stage ring, the copy of tile t+1 overlapping the MFMAs of tile t (one raw s_barrier per tile, counted vmcnt).
 // LDS rows are unpadded; bank-conflict swizzles live on the DMA source address:
 //   K  tile [32 keys][16 chunks of 16 B]: chunk c of row r stored at c ^ (r & 15)      (conflict-free b128 reads)
-//   V^T tile [128 d][4 chunks of 16 B]  : chunk c of row r stored at c ^ ((r>>2) & 3); rows with bit 4 set hold the
-//                                         two 4-key halves of a chunk swapped (v_transpose_kernel) -> conflict-free b64
+//   V^T tile [128 d][4 chunks of 16 B]  : chunk c of row r stored at c ^ ((r>>2) & 3); a chunk is exactly the 8 keys
+//                                         one lane-half feeds to a PV MFMA (common.hpp::vt_key_pos) -> one b128 read
 constexpr int ATT_KPLANE = 32 * 128;                        // halfs per K plane per stage (8 KB)
 constexpr int ATT_VPLANE = 128 * 32;                        // halfs per V^T plane per stage (8 KB)
 constexpr int ATT_STAGE = 2 * ATT_KPLANE + 2 * ATT_VPLANE;  // Kh, Kl, Vh, Vl = 32 KB
@@ -327,14 +328,11 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     };
     // fragment read offsets (halfs), kept to a handful of registers:
     //   K : row l31, chunk (2ks+hi) ^ (l31&15)                        -> kbase + (((2ks+hi) ^ kx) << 3)
-    //   V : row n*32+l31, chunk (2mf+pc) ^ ((row>>2)&3) (same for every n) -> vbase[mf][pc] + n*1024
+    //   V : row n*32+l31, chunk (2mf+hi) ^ ((row>>2)&3) (same for every n)  -> vbase[mf] + n*1024
     const int kbase = l31 * 128, kx = l31 & 15;
-    int vbase[2][2];
+    int vbase[2];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
-            vbase[mf][pc] = l31 * 32 + (((2 * mf + pc) ^ ((l31 >> 2) & 3)) * 8) + 4 * (hi ^ ((l31 >> 4) & 1));
+    for (int mf = 0; mf < 2; ++mf) vbase[mf] = l31 * 32 + (((2 * mf + hi) ^ ((l31 >> 2) & 3)) * 8);
 
     const int ntiles_all = (S + KT - 1) / KT;
     const int kt_begin = (int)((long)split * ntiles_all / a.nsplit);
@@ -426,12 +424,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             // same pipelining for the V^T fragments: step = (n, mf), 8 steps of three MFMAs
             auto vload = [&](int step, f16x8& vh, f16x8& vl) {
                 const int n = step >> 1, mf = step & 1;
-                const f16x4 vh0 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][0]);
-                const f16x4 vh1 = *reinterpret_cast<const f16x4*>(Vh + n * 1024 + vbase[mf][1]);
-                const f16x4 vl0 = *reinterpret_cast<const f16x4*>(Vl + n * 1024 + vbase[mf][0]);
-                const f16x4 vl1 = *reinterpret_cast<const f16x4*>(Vl + n * 1024 + vbase[mf][1]);
-                vh = f16x8{vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-                vl = f16x8{vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+                vh = *reinterpret_cast<const f16x8*>(Vh + n * 1024 + vbase[mf]);
+                vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
             };
             f16x8 vh_c, vl_c;
             vload(0, vh_c, vl_c);

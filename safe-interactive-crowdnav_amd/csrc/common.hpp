@@ -57,6 +57,16 @@ __host__ __device__ __forceinline__ size_t blk_plane_elems(size_t rows, int K) {
     return ((rows + 127) / 128) * 128 * (size_t)K;
 }
 
+// V^T planes [sequence][head][head-dim row][Spad] are key-contiguous, Spad = S rounded up to 16 keys.  Inside every
+// aligned group of 16 keys the four 4-key granules are stored in the order 0, 2, 1, 3: each half of the group then is
+// exactly the 8 keys a lane-half feeds to one PV MFMA ({4hi..4hi+3, 8+4hi..8+4hi+3}: the S^T accumulator layout), i.e.
+// ONE 16-byte LDS read per fragment.  The map is its own inverse.
+__host__ __device__ __forceinline__ int vt_key_pos(int key) {
+    const int g = (key >> 2) & 3;
+    return (key & ~15) | ((((g & 1) << 1) | (g >> 1)) << 2) | (key & 3);
+}
+__host__ __device__ __forceinline__ int vt_spad(int S) { return (S + 15) / 16 * 16; }
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -129,8 +129,8 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
         if (OUT == OUT_QKV && part == 2 && g.vt_direct) {
             // V^T straight from the accumulators: registers 4q..4q+3 of a lane are 4 consecutive tokens (= keys) of
             // column nn, i.e. one 8-byte granule of V^T row (head, nn % hd).  Granules never straddle a sequence
-            // (S % 4 == 0).  Same layout as v_transpose_kernel, including the swapped halves of rows with bit 4 set.
-            const int head = nn / g.hd, vc = nn - head * g.hd, sw = ((vc >> 4) & 1) * 4, nh = g.d / g.hd;
+            // (S % 4 == 0).  Granule order inside a 16-key group: common.hpp::vt_key_pos (same as v_transpose_kernel).
+            const int head = nn / g.hd, vc = nn - head * g.hd, nh = g.d / g.hd;
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -148,7 +148,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                         vl[e] = ll;
                     }
                     const int seq = m / g.S, key = m - seq * g.S;
-                    const size_t o = (((size_t)seq * nh + head) * g.hd + vc) * g.Spad + (key & ~7) + ((key & 7) ^ sw);
+                    const size_t o = (((size_t)seq * nh + head) * g.hd + vc) * g.Spad + vt_key_pos(key);
                     *reinterpret_cast<f16x4*>(g.Vthi + o) = vh;
                     *reinterpret_cast<f16x4*>(g.Vtlo + o) = vl;
                 }
@@ -837,8 +837,7 @@ __global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t*
 
 // V planes [nseq*S, d] (token-major, as the QKV GEMM emits them) -> V^T planes [nseq][nhead][hd][Spad]
 // (key-contiguous: the k-operand layout of the PV product).  64x64 tiles through LDS; both planes per block.
-// Within each aligned group of 8 keys, rows whose head-dim index has bit 4 set hold keys [4..7, 0..3].
-// grid = (ceil(S/64), d/64, nseq)
+// Key order inside every 16-key group: common.hpp::vt_key_pos.   grid = (ceil(S/64), d/64, nseq)
 __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, const half_t* vl, half_t* vth, half_t* vtl,
                                                           int S, int Spad, int d, int hd) {
     __shared__ half_t tile[2][64][64 + 8];
@@ -861,12 +860,9 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, cons
         const int key = k0 + kc * 8;
         if (key >= Spad) continue;
         const int cg = c0 + col, head = cg / hd, vc = cg - head * hd;
-        // rows 16 apart would hit the same LDS bank in the PV fragment reads: rows with bit 4 set store the two
-        // 4-key halves of every 8-key chunk swapped (the readers apply the same XOR)
-        const int sw = ((vc >> 4) & 1) * 4;
-        f16x8 v;
+        f16x8 v;   // stored position kc*8 + e holds key vt_key_pos(kc*8 + e) of this 64-key tile
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = tile[p][kc * 8 + (e ^ sw)][col];
+        for (int e = 0; e < 8; ++e) v[e] = tile[p][vt_key_pos(kc * 8 + e)][col];
         const size_t o = (((size_t)seq * (d / hd) + head) * hd + vc) * Spad + key;
         *reinterpret_cast<f16x8*>((p ? vtl : vth) + o) = v;
     }
@@ -897,7 +893,7 @@ __global__ void qkv_to_planes_kernel(const float* qkv, half_t* qh, half_t* ql, h
         split_f32_unscaled(qkv[m * 3 * d + 2 * d + c], h, l);
         const size_t seq = m / S, key = m % S;
         const int head = c / hd, vc = c % hd;
-        const size_t o = ((seq * (d / hd) + head) * hd + vc) * Spad + (key ^ (size_t)(((vc >> 4) & 1) * 4));
+        const size_t o = ((seq * (d / hd) + head) * hd + vc) * Spad + (size_t)vt_key_pos((int)key);
         vth[o] = h; vtl[o] = l;
     }
 }

@@ -318,7 +318,7 @@ SeqGeom seq_geom(const jmid_ctx* h, int Ec, int A, int K, int T) {
     SeqGeom g;
     g.nseq = h->net_kind == JMID_NET_JMID ? Ec : Ec * K * A;
     g.S = h->net_kind == JMID_NET_JMID ? K * A * T : T;
-    g.Spad = (g.S + 7) / 8 * 8;
+    g.Spad = vt_spad(g.S);
     return g;
 }
 
@@ -1300,7 +1300,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
         hipError_t e = launch_attn_f32(aa, nseq, hd, h->stream);
         if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
     } else {
-        const int Spad = (S + 7) / 8 * 8;
+        const int Spad = vt_spad(S);
         const size_t vt = (size_t)nseq * d * Spad;
         half_t* b[8];
         const size_t sz[8] = {Mt * d, Mt * d, Mt * d, Mt * d, vt, vt, blk_plane_elems(Mt, d), blk_plane_elems(Mt, d)};
