@@ -19,7 +19,7 @@ All arithmetic is float64 until the final cast to float32, as in the reference
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
