@@ -232,9 +232,9 @@ def main():
                                                     "flight and every kernel shares the GPU with the other lane's kernels, "
                                                     "so its launch takes about twice as long; path_achieved = algorithmic "
                                                     "FLOPs of all MFMA kernel classes / wall time of the region"},
-                           "peak_sustained_random_operands": 1520.0,
+                           "peak_sustained_random_operands": 1660.0,
                            "note": "peak = dense fp16 MFMA of MI355X_MICROARCH.md; a pure MFMA loop with fresh random "
-                                   "operands sustains 1.52 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip), and "
+                                   "operands sustains 1.66 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip, warm clocks), and "
                                    "this mode spends 3 MFMA FLOPs per algorithmic FLOP"}
         out["kernels"] = {c: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
                               "total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 2)}

@@ -2,23 +2,34 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I safe-interactive-crowdnav_amd/csrc tools/attn_trace.hip -o build/attn_trace
 #include "attn_f16x3.hpp"
 #include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 #include <map>
 using namespace jmid;
 int main(int argc, char** argv) {
     const int nseq = argc > 1 ? atoi(argv[1]) : 51, S = argc > 2 ? atoi(argv[2]) : 1200, abl = argc > 3 ? atoi(argv[3]) : 0;
-    const int d = 512, nhead = 4, HD = 128, Spad = (S + 31) / 32 * 32;
+    const int d = 512, nhead = 4, HD = 128, Spad = vt_spad(S);
     const size_t M = (size_t)nseq * S;
-    auto alloc_h = [&](size_t n) {
-        std::vector<_Float16> h(n);
-        for (size_t i = 0; i < n; ++i) h[i] = (_Float16)(((rand() & 1023) - 512) / 512.0f);
-        half_t* p; hipMalloc(&p, n * 2); hipMemcpy(p, h.data(), n * 2, hipMemcpyHostToDevice); return p;
+    // operands as the pipeline produces them: x ~ N(0, sigma) split into hi = fp16(x), lo = fp16(x - hi)
+    auto alloc_pair = [&](size_t n, float sigma, half_t** ph, half_t** pl) {
+        std::vector<_Float16> h(n), l(n);
+        for (size_t i = 0; i < n; ++i) {
+            float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / (float)RAND_MAX;
+            float x = sigma * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+            h[i] = (_Float16)x;
+            l[i] = (_Float16)(x - (float)h[i]);
+        }
+        hipMalloc(ph, n * 2); hipMemcpy(*ph, h.data(), n * 2, hipMemcpyHostToDevice);
+        hipMalloc(pl, n * 2); hipMemcpy(*pl, l.data(), n * 2, hipMemcpyHostToDevice);
     };
     AttnHArgs a{};
-    a.Qhi = alloc_h(M * d); a.Qlo = alloc_h(M * d); a.Khi = alloc_h(M * d); a.Klo = alloc_h(M * d);
-    a.Vthi = alloc_h((size_t)nseq * nhead * HD * Spad); a.Vtlo = alloc_h((size_t)nseq * nhead * HD * Spad);
-    a.Ohi = alloc_h(blk_plane_elems(M, d)); a.Olo = alloc_h(blk_plane_elems(M, d));
+    half_t *qh, *ql, *kh, *kl, *vh, *vl, *oh, *ol;
+    alloc_pair(M * d, 1.4426950f / sqrtf(128.f) * 1.5f, &qh, &ql);   // Q arrives pre-scaled by log2(e)/sqrt(hd)
+    alloc_pair(M * d, 1.0f, &kh, &kl);
+    alloc_pair((size_t)nseq * nhead * HD * Spad, 1.0f, &vh, &vl);
+    alloc_pair(blk_plane_elems(M, d), 1.0f, &oh, &ol);
+    a.Qhi = qh; a.Qlo = ql; a.Khi = kh; a.Klo = kl; a.Vthi = vh; a.Vtlo = vl; a.Ohi = oh; a.Olo = ol;
     a.S = S; a.Spad = Spad; a.d = d; a.nhead = nhead; a.scale = 1.f; a.nsplit = 1;
     hipMalloc(&a.range_flag, 4); hipMemset(a.range_flag, 0, 4);
     const int nqt = (S + 127) / 128, nblk = nqt * nhead * nseq;
@@ -27,7 +38,8 @@ int main(int argc, char** argv) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     float ms_plain = 0, ms_trace = 0;
-    for (int rep = 0; rep < 3; ++rep) {
+    const int nrep = argc > 4 ? atoi(argv[4]) : 3;     // more repetitions = warm clocks / steady-state power management
+    for (int rep = 0; rep < nrep; ++rep) {
         hipEventRecord(e0);
         hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, 0, a, nqt, abl, (unsigned long long*)nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms_plain, e0, e1);

@@ -50,6 +50,9 @@ void run_rand(const char* name, int blocks, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k_f16_rand<NACC>, dim3(blocks), dim3(256), 0, 0, d, 16, fr, clk);
     hipDeviceSynchronize(); hipMemset(clk, 0, 16);
+    // warm clocks first: a GPU coming out of idle runs the first milliseconds far below its sustained clock
+    for (int w = 0; w < 200; ++w) hipLaunchKernelGGL(k_f16_rand<NACC>, dim3(blocks), dim3(256), 0, 0, d, iters, fr, clk);
+    hipDeviceSynchronize(); hipMemset(clk, 0, 16);
     hipEventRecord(e0);
     hipLaunchKernelGGL(k_f16_rand<NACC>, dim3(blocks), dim3(256), 0, 0, d, iters, fr, clk);
     hipEventRecord(e1); hipEventSynchronize(e1);
@@ -77,7 +80,7 @@ template <typename K>
 void run(const char* name, K kern, int blocks, int threads, int iters, int nacc, double flop_per_mfma) {
     float* d; hipMalloc(&d, (size_t)blocks * threads * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, 10);
+    for (int w = 0; w < 200; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, iters);   // warm clocks
     hipDeviceSynchronize();
     hipEventRecord(e0);
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d, iters);
