@@ -574,13 +574,14 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 // 256x256 LDS-DMA variant (N a multiple of 256: in_proj 1536, linear1 1024): 8 waves (4 along M x 2 along N), wave tile
 // 64 x 128 - possible since the product needs ONE accumulator set (128 VGPRs).  A third fewer operand bytes per FLOP
-// through L2 -> LDS and a quarter fewer fragment reads per MFMA than the 256x128 tile.  64 KB stages, 2-stage ring:
+// through L2 -> LDS and a quarter fewer fragment reads per MFMA than the 256x128 tile.  64 KB stages, 2-stage ring
+// (the next tile's 8 DMA instructions are issued right after the barrier):
 // one K-tile of look-ahead is 48 MFMAs per wave, the same cover time as two tiles of the 256x128 kernel.
 constexpr int DMA3_STAGE = 8 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi(2), Wlo(2)
 constexpr size_t DMA3_LDS_BYTES = size_t(2) * DMA3_STAGE * sizeof(half_t);
 
 template <int EPI, int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn) {
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int burst) {
     constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
@@ -638,7 +639,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const bool more = kt + 1 < nk;
+        const bool more = kt + 1 < nk && !burst;
+        if (burst && kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_one(kt + 1, i);
+        }
         const half_t* st = lds + (kt & 1) * DMA3_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -653,7 +658,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
                 wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
                 wl[j] = *reinterpret_cast<const f16x8*>(st + 6 * DMA_PLANE + offW[j][ks]);
             }
-            // the 8 DMA instructions of the next K-tile go out behind the MFMA groups, four per 16-deep step
+            // burst == 0 (diagnostics, gemm_abl bit 3): the 8 DMA instructions of the next K-tile go out behind the MFMA
+            // groups instead of right after the barrier - measured 1 % slower here, unlike in the attention kernel
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -689,7 +695,7 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn);
+    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (g_gemm_abl & 8) ? 0 : 1);
     return hipGetLastError();
 }
 
