@@ -544,12 +544,28 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t M
     if (overflow) atomicOr(a.range_flag, 1);
 }
 
-// number of key-range splits for a launch with `base_blocks` workgroups: fill ~2 workgroups per CU, >= 4 tiles each
+// number of key-range splits for a launch with `base_blocks` workgroups.
+//  * few workgroups (a scene or two): fill ~2 workgroups per CU, >= 4 tiles each;
+//  * more than one "round" of the 512 resident workgroups: the smallest split count (<= 8, >= 4 tiles each) that
+//    fills the last round to >= 90 % - one dense scene (N=25, K=64: 600 workgroups = 1.17 rounds, 59 % efficient)
+//    becomes 2400 workgroups = 4.7 rounds (94 %).
 inline int attn_pick_nsplit(int base_blocks, int S) {
     const int ntiles = (S + 31) / 32;
-    int ns = 1;
-    while (ns < 8 && base_blocks * ns * 2 <= 512 && ntiles / (ns * 2) >= 4) ns *= 2;
-    return ns;
+    if (base_blocks * 2 <= 512) {
+        int ns = 1;
+        while (ns < 8 && base_blocks * ns * 2 <= 512 && ntiles / (ns * 2) >= 4) ns *= 2;
+        return ns;
+    }
+    auto eff = [&](int ns) {
+        const long w = (long)base_blocks * ns;
+        return (double)w / (double)(((w + 511) / 512) * 512);
+    };
+    int best = 1;
+    for (int ns = 1; ns <= 8 && ntiles / ns >= 4; ++ns) {
+        if (eff(ns) >= 0.9) return ns;
+        if (eff(ns) > eff(best) + 1e-9) best = ns;
+    }
+    return eff(best) > eff(1) + 0.1 ? best : 1;
 }
 
 static int g_attn_abl = 0;        // timing ablation bits (diagnostics)
