@@ -236,6 +236,16 @@ def main():
                            "note": "peak = dense fp16 MFMA of MI355X_MICROARCH.md; a pure MFMA loop with fresh random "
                                    "operands sustains 1.66 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip, warm clocks), and "
                                    "this mode spends 3 MFMA FLOPs per algorithmic FLOP"}
+        try:   # PMC: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), tools/mfma_busy.sh
+            busy = json.load(open(os.path.join(REPO, "profiles", "r01_mfma_busy.json")))
+            if args.precision == "f16x3" and joint:
+                out["roofline"]["mfma_busy"] = {
+                    "whole_call": round(busy["whole_call_mfma_busy"], 4),
+                    "dominant_kernel": round(next(v["mfma_busy"] for k, v in busy["kernels"].items() if "attn_f16x3" in k), 4),
+                    "source": "rocprofv3 PMC over one 51-episode predictor call (profiles/r01_mfma_busy.json): fraction "
+                              "of the shader cycles of a dispatch in which a SIMD's MFMA pipe is busy"}
+        except Exception:
+            pass
         out["kernels"] = {c: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
                               "total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 2)}
                           for c, v in per.items()}
