@@ -1,13 +1,13 @@
 // Flash attention with fp32-class accuracy on the fp16 matrix cores (hi/lo split operands, see gemm_f16x3.hpp).
 //
 // Same transposed formulation as attn_f32.hpp (a lane owns one query row, softmax state is lane-local):
-//   S^T = K . Q^T      3 MFMAs per 16-deep step:  Khi.Qhi  (+ 2^-11 (Khi.Qlo + Klo.Qhi))
+//   S^T = K . Q^T      3 MFMAs per 16-deep step:  Khi.Qhi + Khi.Qlo + Klo.Qhi
 //   O^T = V^T . P^T    P is split to hi/lo in registers straight from the S^T accumulators; V^T comes
-//                      key-contiguous from the QKV GEMM epilogue, so no transpose is needed on the way in.
-// Inside attention the lo planes are UNSCALED (lo = fp16(x - hi)): v_mfma_f32_32x32x16_f16 takes fp16 subnormal
-// inputs exactly (probed on gfx950, tools/mfma_denorm.hip), so hi.hi + hi.lo + lo.hi all accumulate into ONE fp32
-// accumulator with no correction accumulator and no fold (the pair carries x to max(2^-22 |x|, 2^-25) absolute,
-// which is what the O(1) Q/K/V/P values need).  Q arrives pre-multiplied by log2(e)/sqrt(head_dim) from the QKV GEMM
+//                      key-contiguous from the QKV GEMM epilogue (key order inside 16-key groups:
+//                      common.hpp::vt_key_pos), so no transpose is needed on the way in.
+// The lo planes are lo = fp16(x - hi): v_mfma_f32_32x32x16_f16 takes fp16 subnormal inputs exactly (probed on gfx950,
+// tools/mfma_denorm.hip), so hi.hi + hi.lo + lo.hi all accumulate into ONE fp32 accumulator (the pair carries x to
+// max(2^-22 |x|, 2^-25) absolute, which is what the O(1) Q/K/V/P values need).  Q arrives pre-multiplied by log2(e)/sqrt(head_dim) from the QKV GEMM
 // epilogue, so the scores are already in log2 units: softmax is one v_exp_f32 per element.
 //
 // Inputs : Qhi/Qlo, Khi/Klo [nseq*S, d] planes;  Vthi/Vtlo [nseq][nhead][hd][Spad] planes (all lo unscaled).
