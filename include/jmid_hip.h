@@ -152,7 +152,7 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     3 = 128x128 LDS-DMA ring, 4 = 256x128 LDS-DMA ring, 5 = 64x64 LDS-DMA ring,
  *                     6 = 256x256 LDS-DMA ring (N % 256 == 0)
  *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
- *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 16384 tokens), 1 always, 2 never
+ *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 8192 tokens), 1 always, 2 never
  *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
  *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 2)
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128

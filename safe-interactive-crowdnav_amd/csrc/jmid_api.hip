@@ -465,9 +465,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 AttnArgs aa{sb.QKV, nullptr, S, d, h->nhead, att_scale, sb.Ah, sb.Al};
                 HIPCHK(h, launch_attn_f32(aa, nseq, hd, h->stream));
             }
-            // row-complete GEMM with residual + LayerNorm fused in (gemm_ln_f16x3.hpp) once there are enough 64-row
-            // tiles to fill the chip; otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
-            const bool ln_fused = d == GLN_BN && g_ln_fuse != 2 && (g_ln_fuse == 1 || M >= 16384);
+            // row-complete GEMM with residual + LayerNorm fused in (gemm_ln_f16x3.hpp) from 8192 tokens
+            // (enough row tiles to occupy the chip); otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
+            const bool ln_fused = d == GLN_BN && g_ln_fuse != 2 && (g_ln_fuse == 1 || M >= 8192);
             if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".self_attn.out_proj.weight"];
                 GemmLnArgs gl{sb.Ah, sb.Al, w16.hi, w16.lo, W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"),
