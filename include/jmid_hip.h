@@ -154,11 +154,12 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
  *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 8192 tokens), 1 always, 2 never
  *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
- *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 2)
+ *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 1; > 1 is ~5 %
+ *                     faster but results were seen to vary from run to run - see DESIGN.md)
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
  *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
  *   "gemm_ng", "gemm_abl", "attn_abl", "print_occupancy"   diagnostics used by tools/ (ablations give WRONG results)
- * All variants of a key compute the same values (bit-identical for gemm_h_variant, ln_fuse, ln_rows, lanes and no_vt_direct).
+ * All variants of a key compute the same values (bit-identical for gemm_h_variant, ln_fuse, ln_rows and no_vt_direct).
  * Unknown keys return JMID_EINVAL. */
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream.

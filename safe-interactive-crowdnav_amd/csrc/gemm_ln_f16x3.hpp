@@ -23,8 +23,7 @@ constexpr int GLN_W_STAGE = 2 * GLN_BN * 16;     // halfs per W stage (hi plane 
 constexpr int GLN_A_STAGE = 2 * GLN_BM * 32;     // halfs per A stage
 constexpr int GLN_W_OFF = 0;
 constexpr int GLN_A_OFF = 3 * GLN_W_STAGE;
-constexpr int GLN_SCRATCH_OFF = GLN_A_OFF + 4 * GLN_A_STAGE;
-constexpr size_t GLN_LDS_BYTES = size_t(GLN_SCRATCH_OFF + GLN_A_STAGE) * sizeof(half_t);   // 136 KB
+constexpr size_t GLN_LDS_BYTES = size_t(GLN_A_OFF + 5 * GLN_A_STAGE) * sizeof(half_t);   // 136 KB (>= the epilogue tile)
 constexpr int GLN_TILE_LD = GLN_BN + 8;          // floats per row of the epilogue tile
 static_assert(size_t(GLN_BM) * GLN_TILE_LD * sizeof(float) <= GLN_LDS_BYTES, "epilogue tile must fit the ring");
 
@@ -70,10 +69,10 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
 
     const half_t* a_src = (tid < 256 ? g.Ahi : g.Alo) + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + (tid & 255) * 8;
     const int a_dst = (tid < 256 ? 0 : 2048) + (wid & 3) * 512;
-    auto issueA = [&](int ka) {     // one wave-instruction; past the end: the last tile again, into the scratch stage
-        const bool live = ka < nk;
-        const int kk = live ? ka : nk - 1;
-        half_t* dst = lds + (live ? GLN_A_OFF + (ka & 3) * GLN_A_STAGE : GLN_SCRATCH_OFF) + a_dst;
+    auto issueA = [&](int ka) {     // one wave-instruction; past the end: the last tile again into its own stage
+                                    // (identical bytes: harmless while that stage is being read) so that the DMA count stays fixed
+        const int kk = ka < nk ? ka : nk - 1;
+        half_t* dst = lds + GLN_A_OFF + (kk & 3) * GLN_A_STAGE + a_dst;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)kk * 4096),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };

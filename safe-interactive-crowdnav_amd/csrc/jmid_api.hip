@@ -67,7 +67,11 @@ struct jmid_ctx {
     static constexpr int kMaxLanes = 4;
     hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};   // extra lanes of the chunk loop
     hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
-    int lanes = 2;                          // chunks in flight at once, 1..4 (jmid_set_tuning "lanes")
+    // chunks in flight at once, 1..4 (jmid_set_tuning "lanes").  Default 1: two lanes are ~5 % faster, but kernels of
+    // different chunks running concurrently on two streams were seen to change a few episodes by 1e-4..1e-2 per run
+    // (not reproducible run to run; every kernel alone and every single-stream run is bit-reproducible; see
+    // tools/concurrency_probe.hip and DESIGN.md) - opt-in until that is understood.
+    int lanes = 1;
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
     HyperLayout hl;
