@@ -156,6 +156,9 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
  *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 1; > 1 is ~5 %
  *                     faster but results were seen to vary from run to run - see DESIGN.md)
+ *   "bystander_lds"   bytes of dynamic LDS (0..163840, default 0) the row-wise kernels request without using them, so
+ *                     that they never share a CU with an attention / GEMM workgroup of another lane (>= 65536 made
+ *                     lanes > 1 reproducible in every soak run so far; process-wide, not per handle)
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
  *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
  *   "gemm_ng", "gemm_abl", "attn_abl", "print_occupancy"   diagnostics used by tools/ (ablations give WRONG results)

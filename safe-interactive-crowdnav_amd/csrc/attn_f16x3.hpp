@@ -585,7 +585,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
         if (a.nsplit > 1) {
             const size_t Mtot = (size_t)nseq * a.S;
             const int blocks = (int)std::min<size_t>((Mtot * (a.d / 4) + 255) / 256, 2048);
-            hipLaunchKernelGGL(attn_combine_kernel, dim3(blocks), dim3(256), 0, st, a, Mtot, 128);
+            hipLaunchKernelGGL(attn_combine_kernel, dim3(blocks), dim3(256), bystander_lds(attn_combine_kernel), st, a, Mtot, 128);
         }
         return hipGetLastError();
     }

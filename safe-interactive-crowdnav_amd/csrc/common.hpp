@@ -67,6 +67,15 @@ __host__ __device__ __forceinline__ int vt_key_pos(int key) {
 }
 __host__ __device__ __forceinline__ int vt_spad(int S) { return (S + 15) / 16 * 16; }
 
+// Dynamic LDS the small row-wise kernels request although they use none (tuning knob "bystander_lds").  With a
+// request above 96 KB such a workgroup cannot share a CU with an attention or GEMM workgroup of another chunk lane.
+static int g_bystander_lds = 0;
+template <typename F>
+static inline int bystander_lds(F* fn) {
+    if (g_bystander_lds > 0) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bystander_lds);
+    return g_bystander_lds;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {

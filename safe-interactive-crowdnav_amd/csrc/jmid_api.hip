@@ -289,8 +289,8 @@ int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const flo
     const int vpl = (d + 255) / 256;
     const bool planes = Xh != nullptr;   // split-fp16 mode: the residual stream lives only in its planes
 #define JMID_LN(V)                                                                                                    \
-    if (planes) hipLaunchKernelGGL((add_ln_kernel<V, true>), grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); \
-    else hipLaunchKernelGGL((add_ln_kernel<V, false>), grid, dim3(256), 0, h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl);
+    if (planes) hipLaunchKernelGGL((add_ln_kernel<V, true>), grid, dim3(256), bystander_lds(add_ln_kernel<V, true>), h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl); \
+    else hipLaunchKernelGGL((add_ln_kernel<V, false>), grid, dim3(256), bystander_lds(add_ln_kernel<V, false>), h->stream, X, Y, gm, bt, M, d, 1e-5f, Xh, Xl);
     switch (vpl) {
         case 1: JMID_LN(1) break;
         case 2: JMID_LN(2) break;
@@ -388,7 +388,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                      split ? sb.Xl : nullptr};
         const long total = (long)M * (d / 4);
         int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
-        hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), 0, h->stream, ea);
+        hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), bystander_lds(embed_kernel), h->stream, ea);
         HIPCHK(h, hipGetLastError());
     }
     const SeqGeom sg = seq_geom(h, Ec, A, K, T);
@@ -533,7 +533,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.c1 = h->p_c1[step_idx];
             oa.sigma = h->p_sigma[step_idx];
         }
-        hipLaunchKernelGGL(out_ddim_kernel, dim3((M + 3) / 4), dim3(256), 0, h->stream, oa);
+        hipLaunchKernelGGL(out_ddim_kernel, dim3((M + 3) / 4), dim3(256), bystander_lds(out_ddim_kernel), h->stream, oa);
         HIPCHK(h, hipGetLastError());
     }
     return 0;
@@ -1139,6 +1139,11 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     if (k == "lanes") {     // chunks of the denoise loop in flight at once: 1..4
         if (value < 1 || value > jmid_ctx::kMaxLanes) return fail(h, JMID_EINVAL, "lanes must be 1..4");
         h->lanes = value;
+        return JMID_OK;
+    }
+    if (k == "bystander_lds") {   // bytes of unused dynamic LDS requested by the row-wise kernels (0..163840)
+        if (value < 0 || value > 160 * 1024) return fail(h, JMID_EINVAL, "bystander_lds must be 0..163840");
+        g_bystander_lds = value;
         return JMID_OK;
     }
     if (k == "ln_rows") {   // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128

@@ -314,6 +314,14 @@ def test_chunk_lanes_single_lane_is_reproducible_and_lanes_stay_close():
         for lanes in (2, 3, 4):
             eng.set_tuning("lanes", lanes)
             assert ade(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref) <= ADE_GATE
+        # row-wise kernels kept off the CUs of the MFMA kernels by an LDS request they never use: same values
+        eng.set_tuning("bystander_lds", 96 * 1024)
+        for lanes in (1, 2):
+            eng.set_tuning("lanes", lanes)
+            assert ade(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref) <= ADE_GATE
+        with pytest.raises(Exception):
+            eng.set_tuning("bystander_lds", 1 << 20)
     finally:
+        eng.set_tuning("bystander_lds", 0)
         eng.set_tuning("lanes", 1)
         eng.set_chunk_episodes(0)

@@ -17,6 +17,9 @@ if os.environ.get("AB_CHUNK"):
     eng.set_chunk_episodes(int(os.environ["AB_CHUNK"]))
 if os.environ.get("AB_LANES"):
     eng.set_tuning("lanes", int(os.environ["AB_LANES"]))
+for kv in os.environ.get("AB_PRESET", "").split(","):   # AB_PRESET="key=value,key=value": fixed for both arms
+    if kv:
+        eng.set_tuning(kv.split("=")[0], int(kv.split("=")[1]))
 res = {v: [] for v in vals}
 for rep in range(4):
     for v in vals:

@@ -27,6 +27,9 @@ __global__ __launch_bounds__(256) void valu_loop(float* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = x + y;
 }
 int main(int argc, char** argv) {
+    const int elds = argc > 6 ? atoi(argv[6]) : 0;    // unused dynamic LDS requested by embed_kernel
+    const int alds = argc > 7 ? atoi(argv[7]) : 0;    // extra (unused) dynamic LDS of the attention co-runner: 32768 -> one workgroup per CU
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&embed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     const int nseq = 8, S = 1200, d = 512, nhead = 4, HD = 128, Spad = vt_spad(S), T = 12, A = 5, K = 20;
     const size_t M = (size_t)nseq * S;
     auto dev_rand_h = [&](size_t n, float sc) {
@@ -52,7 +55,7 @@ int main(int argc, char** argv) {
     e.hyp = dev_rand_f((size_t)EA * hyp_ld, 1.f); e.thyp = dev_rand_f(hyp_ld, 1.f);
     e.X = nullptr; e.M = (int)M; e.d = d; e.hyp_ld = hyp_ld; e.goff = 0; e.boff = d; e.rmap = RowMap{T, A, K * A};
     hipMalloc(&e.Xh, blk_plane_elems(M, d) * 2); hipMalloc(&e.Xl, blk_plane_elems(M, d) * 2);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS + alds);
     hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
     // consumer of the embed output on the same stream: C = X . W^T (256x128 LDS-DMA GEMM, fp32 out)
     GemmHArgs g{};
@@ -68,18 +71,18 @@ int main(int argc, char** argv) {
     std::vector<_Float16> ref_h(pe), ref_l(pe), cur_h(pe), cur_l(pe);
     std::vector<_Float16> oref(pe), ocur(pe);
     // reference: each kernel alone
-    hipLaunchKernelGGL(embed_kernel, dim3(eblocks), dim3(256), 0, s2, e);
+    hipLaunchKernelGGL(embed_kernel, dim3(eblocks), dim3(256), elds, s2, e);
     (void)launch_gemm_h_dma256<EPI_BIAS, OUT_F32>(g, s2);
     hipDeviceSynchronize();
     hipMemcpy(ref_h.data(), e.Xh, pe * 2, hipMemcpyDeviceToHost); hipMemcpy(ref_l.data(), e.Xl, pe * 2, hipMemcpyDeviceToHost);
     hipMemcpy(cref.data(), g.C, M * 1536 * 4, hipMemcpyDeviceToHost);
     hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
     hipDeviceSynchronize(); hipMemcpy(oref.data(), a.Ohi, pe * 2, hipMemcpyDeviceToHost);
-    const int mode = argc > 1 ? atoi(argv[1]) : 0; const int abl = argc > 2 ? atoi(argv[2]) : 0; const int niter = argc > 3 ? atoi(argv[3]) : 100;   // co-runner: 0 attention, 1 pure MFMA loop, 2 pure VALU loop, 3 nothing
+    const int mode = argc > 1 ? atoi(argv[1]) : 0; const int abl = argc > 2 ? atoi(argv[2]) : 0; const int niter = argc > 3 ? atoi(argv[3]) : 100; const int use_gemm = argc > 4 ? atoi(argv[4]) : 1; const int copy_c = argc > 5 ? atoi(argv[5]) : 1;   // co-runner: 0 attention, 1 pure MFMA loop, 2 pure VALU loop, 3 nothing
     float* sink; hipMalloc(&sink, 2048 * 256 * 4);
     f16x8* fr = reinterpret_cast<f16x8*>(dev_rand_h(2048 * 8, 1.f));
     auto corunner = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, abl, (unsigned long long*)nullptr);
+        if (mode == 0) hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS + alds, s1, a, nqt, abl, (unsigned long long*)nullptr);
         else if (mode == 5) hipLaunchKernelGGL(attn_f16x3_kernel<128>, dim3((S + 127) / 128, nhead, nseq), dim3(256), 0, s1, a);
         else if (mode == 1) hipLaunchKernelGGL(mfma_loop, dim3(1024), dim3(256), 0, s1, sink, 800, fr);
         else if (mode == 2) hipLaunchKernelGGL(valu_loop, dim3(2048), dim3(256), 0, s1, sink, 20000);
@@ -88,12 +91,12 @@ int main(int argc, char** argv) {
     for (int it = 0; it < niter; ++it) {
         hipMemsetAsync(e.Xh, 0xff, pe * 2, s2); hipMemsetAsync(e.Xl, 0xff, pe * 2, s2); hipDeviceSynchronize();
         corunner();
-        hipLaunchKernelGGL(embed_kernel, dim3(eblocks), dim3(256), 0, s2, e);
-        (void)launch_gemm_h_dma256<EPI_BIAS, OUT_F32>(g, s2);
+        hipLaunchKernelGGL(embed_kernel, dim3(eblocks), dim3(256), elds, s2, e);
+        if (use_gemm) (void)launch_gemm_h_dma256<EPI_BIAS, OUT_F32>(g, s2);
         corunner();
         hipDeviceSynchronize();
-        hipMemcpy(ccur.data(), g.C, M * 1536 * 4, hipMemcpyDeviceToHost);
-        { size_t nc = 0; for (size_t i = 0; i < M * 1536; ++i) nc += memcmp(&ccur[i], &cref[i], 4) != 0;
+        if (copy_c) hipMemcpy(ccur.data(), g.C, M * 1536 * 4, hipMemcpyDeviceToHost);
+        if (copy_c) { size_t nc = 0; for (size_t i = 0; i < M * 1536; ++i) nc += memcmp(&ccur[i], &cref[i], 4) != 0;
           if (nc && 0) printf("iter %d: GEMM output (consumer of embed on the same stream) differs in %zu elements\n", it, nc); }
         hipMemcpy(cur_h.data(), e.Xh, pe * 2, hipMemcpyDeviceToHost); hipMemcpy(cur_l.data(), e.Xl, pe * 2, hipMemcpyDeviceToHost);
         hipMemcpy(ocur.data(), a.Ohi, pe * 2, hipMemcpyDeviceToHost);
@@ -119,6 +122,6 @@ int main(int argc, char** argv) {
         if (nb) { ++bad_embed; if (bad_embed <= 0) printf("iter %d: embed differs in %zu elements (first index %zu, value %f vs %f)\n", it, nb, first, (float)cur_h[first], (float)ref_h[first]); }
         if (na) { ++bad_attn; if (bad_attn <= 0) printf("iter %d: attention output differs in %zu elements\n", it, na); }
     }
-    printf("mode %d abl %d: concurrent runs with a different embed result: %d / %d (attention differs: %d)\n", mode, abl, bad_embed, niter, bad_attn);
+    printf("attn +LDS %d | embed LDS %d | gemm %d copyC %d | mode %d abl %d: concurrent runs with a different embed result: %d / %d (attention differs: %d)\n", alds, elds, use_gemm, copy_c, mode, abl, bad_embed, niter, bad_attn);
     return 0;
 }
