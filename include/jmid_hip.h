@@ -43,8 +43,13 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *   JMID_PREC_F32     exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
  *   JMID_PREC_F16X3   fp32 emulated by three fp16 MFMAs per product on hi/lo-split operands
  *                     (~22 significand bits, fp32 accumulate)
- *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only) */
-enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2 };
+ *   JMID_PREC_F16X2   same operand planes, but the linear contractions take the activation as its fp16 hi plane only:
+ *                     A_hi x (W_hi + W_lo) in the GEMMs and (P_hi + P_lo) x V_hi in attention, two MFMAs per product;
+ *                     the softmax logits Q.K keep all three terms (their error is exponentiated) and the residual
+ *                     stream, LayerNorm and DDIM state keep hi + lo.  Mean ADE vs the reference 7e-6 m on the cfg3
+ *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~15 % more trajectories per second
+ *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
+enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3 };
 
 enum {
     JMID_OK = 0,
@@ -52,7 +57,7 @@ enum {
     JMID_ENOWEIGHT = -2,  /* a required weight has not been loaded */
     JMID_EHIP = -3,       /* HIP runtime error */
     JMID_ENOMEM = -4,
-    JMID_ERANGE = -5      /* F16X3/F16: an operand left the fp16 range; rerun with JMID_PREC_F32 */
+    JMID_ERANGE = -5      /* F16X3/F16X2: an operand left the fp16 range; rerun with JMID_PREC_F32 */
 };
 
 /* Library / build identification (also the cheap "does it load" probe). */

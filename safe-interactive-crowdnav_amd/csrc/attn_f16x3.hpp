@@ -50,6 +50,7 @@ struct AttnHArgs {
     int nsplit;
     float* Opart;      // [nsplit][nseq*S][d] fp32
     float* MLpart;     // [nsplit][nseq*S][nhead][2]
+    int x2;            // JMID_PREC_F16X2: V enters P.V as its hi plane only (P and the logits keep all terms)
 };
 
 template <int HD>
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
                 const f16x8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[mf], ot[n], 0, 0, 0);
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[mf], ot[n], 0, 0, 0);
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], ot[n], 0, 0, 0);
+                if (!a.x2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[mf], ot[n], 0, 0, 0);
             }
         }
     }
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
                     }
                     const size_t ob = blk_index(orow, h * HD + c0, d);
                     *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
-                    *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;
+                    if (!a.x2) *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;   // F16X2: out_proj reads O_hi only
                 }
             }
         }
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     // one of the 8 DMA wave-instructions of key tile kt (i < 4: K planes, else V^T planes)
     auto issue_one = [&](int kt, int i) {
         half_t* st = lds + (kt & 1) * ATT_STAGE + wid * 512;
+        if (i >= 6 && a.x2) return;   // F16X2: the V^T lo plane is neither written by the QKV epilogue nor read here
         if (i < 4) {
             int key = kt * KT + 16 * (i & 1) + k_row;
             key = key < S ? key : S - 1;
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             auto vload = [&](int step, f16x8& vh, f16x8& vl) {
                 const int n = step >> 1, mf = step & 1;
                 vh = *reinterpret_cast<const f16x8*>(Vh + n * 1024 + vbase[mf]);
-                vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
+                if (!a.x2) vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
             };
             f16x8 vh_c, vl_c;
             vload(0, vh_c, vl_c);
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 const int n = step >> 1, mf = step & 1;
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, ph[mf], ot[n], 0, 0, 0);
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
+                if (!a.x2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 vh_c = vh_n;
                 vl_c = vl_n;
@@ -499,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 }
                 const size_t ob = blk_index(orow, h * HD + c0, d);
                 *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
-                *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;
+                if (!a.x2) *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;   // F16X2: out_proj reads O_hi only
             }
         }
         if (overflow) atomicOr(a.range_flag, 1);
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t M
         }
         const size_t ob = blk_index((int)tok, c, d);
         *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
-        *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;
+        if (!a.x2) *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;   // F16X2: out_proj reads O_hi only
     }
     if (overflow) atomicOr(a.range_flag, 1);
 }

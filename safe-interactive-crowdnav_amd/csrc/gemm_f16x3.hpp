@@ -64,6 +64,7 @@ struct GemmHArgs {
     int hyp_ld, goff, boff;
     RowMap rmap;
     int* range_flag;          // set to 1 when an emitted fp16 operand would leave the fp16 range
+    int x2;                   // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
 };
 
 constexpr int GEMMH_BK = 32;
@@ -78,7 +79,7 @@ constexpr size_t gemm_h_lds_bytes() {
 // apart (a back-to-back dependent pair stalls for the MFMA latency)
 template <int WM, int WN>
 __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[WM], const f16x8 (&wh)[WN],
-                                      const f16x8 (&wl)[WN], f32x16 (&acc)[WM][WN]) {
+                                      const f16x8 (&wl)[WN], f32x16 (&acc)[WM][WN], bool x2) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -87,6 +88,7 @@ __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[W
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+    if (x2) return;   // JMID_PREC_F16X2: the activation's lo plane stays out of the product (wave-uniform)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -150,7 +152,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     const int seq = m / g.S, key = m - seq * g.S;
                     const size_t o = (((size_t)seq * nh + head) * g.hd + vc) * g.Spad + vt_key_pos(key);
                     *reinterpret_cast<f16x4*>(g.Vthi + o) = vh;
-                    *reinterpret_cast<f16x4*>(g.Vtlo + o) = vl;
+                    if (!g.x2) *reinterpret_cast<f16x4*>(g.Vtlo + o) = vl;   // F16X2: P.V takes V_hi only
                 }
             }
             continue;
@@ -181,7 +183,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     if (OUT == OUT_SPLIT) {
                         const size_t o = blk_index(m, n, g.N);
                         g.Chi[o] = h;
-                        g.Clo[o] = l;
+                        if (!g.x2) g.Clo[o] = l;   // F16X2: the consumer GEMM takes A_hi only
                     } else {
                         if (part == 0) {
                             g.Chi[(size_t)m * g.d + nn] = h;
@@ -191,7 +193,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                             g.Klo[(size_t)m * g.d + nn] = l;
                         } else {   // V row-major planes; v_transpose_kernel makes them key-contiguous
                             g.Vthi[(size_t)m * g.d + nn] = h;
-                            g.Vtlo[(size_t)m * g.d + nn] = l;
+                            if (!g.x2) g.Vtlo[(size_t)m * g.d + nn] = l;
                         }
                     }
                 }
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
                 wh[j] = *reinterpret_cast<const f16x8*>(Wh + j * 32 * LD + ks * 16);
                 wl[j] = *reinterpret_cast<const f16x8*>(Wl + j * 32 * LD + ks * 16);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm);
+            mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
                 wh[j] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offW[j][ks]);
                 wl[j] = *reinterpret_cast<const f16x8*>(st + 3 * DMA_PLANE + offW[j][ks]);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm);
+            mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
         }
     }
     gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi);
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 #pragma unroll
                 for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(wh[i]), "v"(wl[i]));
             } else {
-                mfma3<WM, WN>(ah, al, wh, wl, accm);
+                mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
             }
         }
         stage = stage == 2 ? 0 : stage + 1;
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
     src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
     auto issue_one = [&](int kt, int i) {
         half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
+        if ((i == 2 || i == 3) && g.x2) return;   // F16X2: the A lo images stay out of LDS
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
                                          (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
     };
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
-                al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+                if (!g.x2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
                 issue_one(kt + 1, 4 * ks + 2);
                 issue_one(kt + 1, 4 * ks + 3);
             }
+            if (!g.x2)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
             al[0] = *reinterpret_cast<const f16x8*>(st + DMA64_PLANE + offA[ks]);
             wh[0] = *reinterpret_cast<const f16x8*>(st + 2 * DMA64_PLANE + offW[ks]);
             wl[0] = *reinterpret_cast<const f16x8*>(st + 3 * DMA64_PLANE + offW[ks]);
-            mfma3<1, 1>(ah, al, wh, wl, accm);
+            mfma3<1, 1>(ah, al, wh, wl, accm, g.x2);
         }
     }
     gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);

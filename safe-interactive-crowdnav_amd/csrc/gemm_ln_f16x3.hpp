@@ -38,6 +38,7 @@ struct GemmLnArgs {
     int M, K;
     float eps;
     int* range_flag;
+    int x2;                       // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
 };
 
 // fp32 row-major [512, K] -> k16-panel hi/lo planes
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
             wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
             wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
         }
-        mfma3<WM, WN>(ah, al, wh, wl, accm);
+        mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
         wst = wst == 2 ? 0 : wst + 1;
     };
     for (int s = 0; s < nsteps; s += 2) {
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
             wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
             wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
         }
-        mfma3<WM, WN>(ah, al, wh, wl, acc);
+        mfma3<WM, WN>(ah, al, wh, wl, acc, g.x2);
         wst = wst == 2 ? 0 : wst + 1;
         if (ks == 1) ast = ast == 2 ? 0 : ast + 1;
     };

@@ -72,6 +72,7 @@ struct jmid_ctx {
     // (not reproducible run to run; every kernel alone and every single-stream run is bit-reproducible; see
     // tools/concurrency_probe.hip and DESIGN.md) - opt-in until that is understood.
     int lanes = 1;
+    int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
     HyperLayout hl;
@@ -276,6 +277,7 @@ template <int EPI, int OUT>
 int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
     if (g.K % GEMMH_BK != 0) return fail(h, JMID_EINVAL, "GEMM K must be a multiple of 32");
     g.range_flag = h->range_flag;
+    g.x2 = h->x2;
     ProfScope ps(h, cls);
     HIPCHK(h, (launch_gemm_h<EPI, OUT>(g, h->stream)));
     return 0;
@@ -460,7 +462,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 if (hd == 128) ns = attn_pick_nsplit(((S + 127) / 128) * h->nhead * nseq, S);
                 if (ns > sb.attn_nsplit) ns = sb.attn_nsplit;   // workspace was sized for the full chunk
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
-                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart};
+                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2};
                 HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
             } else {
                 g.C = sb.QKV; g.ldc = 3 * d;
@@ -475,7 +477,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".self_attn.out_proj.weight"];
                 GemmLnArgs gl{sb.Ah, sb.Al, w16.hi, w16.lo, W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"),
-                              W(h, p + ".norm1.bias"), sb.Xh, sb.Xl, M, d, 1e-5f, h->range_flag};
+                              W(h, p + ".norm1.bias"), sb.Xh, sb.Xl, M, d, 1e-5f, h->range_flag, h->x2};
                 ProfScope ps(h, KC_GEMM_OUT);
                 HIPCHK(h, launch_gemm_ln(gl, h->stream));
             } else {
@@ -494,7 +496,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".linear2.weight"];
                 GemmLnArgs gl{sb.H1h, sb.H1l, w16.hi, w16.lo, W(h, p + ".linear2.bias"), W(h, p + ".norm2.weight"),
-                              W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag};
+                              W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag, h->x2};
                 ProfScope ps(h, KC_GEMM_FF2);
                 HIPCHK(h, launch_gemm_ln(gl, h->stream));
             } else {
@@ -571,9 +573,10 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     if (int rc = check_ready(h)) return rc;
     if (E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "E, A, K, T must be positive");
     if (T > 24) return fail(h, JMID_EINVAL, "T exceeds the positional-encoding table (max_len=24, diffusion.py:116-118)");
-    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3)
-        return fail(h, JMID_EINVAL, "precision must be JMID_PREC_F32 or JMID_PREC_F16X3 (JMID_PREC_F16 is not built)");
-    if (precision == JMID_PREC_F16X3 && !h->weights_in_half_range)
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2)
+        return fail(h, JMID_EINVAL, "precision must be JMID_PREC_F32, JMID_PREC_F16X3 or JMID_PREC_F16X2 (JMID_PREC_F16 is not built)");
+    h->x2 = precision == JMID_PREC_F16X2;
+    if (precision != JMID_PREC_F32 && !h->weights_in_half_range)
         return fail(h, JMID_ERANGE, "a weight exceeds the fp16 range: use JMID_PREC_F32");
     if (!x_in || !ctx) return fail(h, JMID_EINVAL, "null input");
     if (pos_out && !p0) return fail(h, JMID_EINVAL, "pos_out requested without p0");
@@ -619,7 +622,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     StepBuffers sbs[jmid_ctx::kMaxLanes];
     for (int l = 0; l < lanes; ++l) step_ws_floats(h, Mc, precision, sg_full, &sbs[l], h->arena + io_off + l * lane_floats);
     const StepBuffers& sb = sbs[0];
-    if (precision == JMID_PREC_F16X3) {
+    if (precision != JMID_PREC_F32) {
         HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
         for (int l = 0; l < lanes; ++l)
             if (sbs[l].Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
@@ -697,12 +700,12 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
             HIPCHK(h, hipMemcpyAsync(pos_out, stage, M * 2 * sizeof(float), kout, h->stream));
         }
     }
-    if (precision == JMID_PREC_F16X3) {
+    if (precision != JMID_PREC_F32) {
         // an activation outside the fp16 range poisons the split operands: report it instead of returning garbage
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3: rerun with JMID_PREC_F32");
+        if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2: rerun with JMID_PREC_F32");
     } else if (mem == JMID_MEM_HOST) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
@@ -1236,7 +1239,9 @@ int jmid_synchronize(jmid_handle_t h) {
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
                   int precision, float* C) {
     if (!h || !A || !Wt || !C) return JMID_EINVAL;
-    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3) return fail(h, JMID_EINVAL, "bad precision");
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2)
+        return fail(h, JMID_EINVAL, "bad precision");
+    h->x2 = precision == JMID_PREC_F16X2;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
@@ -1289,7 +1294,9 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
 
 int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT) {
     if (!h || !QKV || !OUT) return JMID_EINVAL;
-    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3) return fail(h, JMID_EINVAL, "bad precision");
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2)
+        return fail(h, JMID_EINVAL, "bad precision");
+    h->x2 = precision == JMID_PREC_F16X2;
     HIPCHK(h, hipSetDevice(h->device));
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
@@ -1330,7 +1337,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
             tmp.push_back(reinterpret_cast<half_t*>(mlpart));
         }
         AttnHArgs aa{b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], S, Spad, d, h->nhead, 1.0f / sqrtf((float)hd),
-                     h->range_flag, ns, opart, mlpart};
+                     h->range_flag, ns, opart, mlpart, h->x2};
         {
             ProfScope ps(h, KC_ATTN);
             hipError_t e = launch_attn_f16x3(aa, nseq, hd, h->stream);
