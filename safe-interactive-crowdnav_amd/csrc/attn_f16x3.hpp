@@ -250,7 +250,7 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
         tprev = now_;                                                 \
         __builtin_amdgcn_sched_barrier(0);                            \
     }
-template <bool TRACE>
+template <bool TRACE, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     // one of the 8 DMA wave-instructions of key tile kt (i < 4: K planes, else V^T planes)
     auto issue_one = [&](int kt, int i) {
         half_t* st = lds + (kt & 1) * ATT_STAGE + wid * 512;
-        if (i >= 6 && a.x2) return;   // F16X2: the V^T lo plane is neither written by the QKV epilogue nor read here
+        if (i >= 6 && X2) return;   // F16X2: the V^T lo plane is neither written by the QKV epilogue nor read here
         if (i < 4) {
             int key = kt * KT + 16 * (i & 1) + k_row;
             key = key < S ? key : S - 1;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             auto vload = [&](int step, f16x8& vh, f16x8& vl) {
                 const int n = step >> 1, mf = step & 1;
                 vh = *reinterpret_cast<const f16x8*>(Vh + n * 1024 + vbase[mf]);
-                if (!a.x2) vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
+                if (!X2) vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
             };
             f16x8 vh_c, vl_c;
             vload(0, vh_c, vl_c);
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 const int n = step >> 1, mf = step & 1;
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, ph[mf], ot[n], 0, 0, 0);
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
-                if (!a.x2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
+                if (!X2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 vh_c = vh_n;
                 vl_c = vl_n;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 }
                 const size_t ob = blk_index(orow, h * HD + c0, d);
                 *reinterpret_cast<f16x4*>(a.Ohi + ob) = vh;
-                if (!a.x2) *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;   // F16X2: out_proj reads O_hi only
+                if (!X2) *reinterpret_cast<f16x4*>(a.Olo + ob) = vl;   // F16X2: out_proj reads O_hi only
             }
         }
         if (overflow) atomicOr(a.range_flag, 1);
@@ -577,13 +577,20 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
     if (head_dim == 128 && g_attn_h_variant != 1) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
             attr_set = true;
         }
         const int nqt = (a.S + 127) / 128;
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nqt * a.nhead * nseq * a.nsplit), dim3(256), ATT_DMA_LDS, st,
-                           a, nqt, g_attn_abl, (unsigned long long*)nullptr);
+        const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
+        if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, g_attn_abl,
+                               (unsigned long long*)nullptr);
+        else
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, g_attn_abl,
+                               (unsigned long long*)nullptr);
         if (a.nsplit > 1) {
             const size_t Mtot = (size_t)nseq * a.S;
             const int blocks = (int)std::min<size_t>((Mtot * (a.d / 4) + 255) / 256, 2048);

@@ -77,9 +77,9 @@ constexpr size_t gemm_h_lds_bytes() {
 
 // three passes over the wave's tiles so that consecutive MFMAs into the same accumulator are WM*WN instructions
 // apart (a back-to-back dependent pair stalls for the MFMA latency)
-template <int WM, int WN>
+template <int WM, int WN, bool X2>
 __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[WM], const f16x8 (&wh)[WN],
-                                      const f16x8 (&wl)[WN], f32x16 (&acc)[WM][WN], bool x2) {
+                                      const f16x8 (&wl)[WN], f32x16 (&acc)[WM][WN]) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -88,7 +88,7 @@ __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[W
     for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
-    if (x2) return;   // JMID_PREC_F16X2: the activation's lo plane stays out of the product (wave-uniform)
+    if (X2) return;   // JMID_PREC_F16X2: the activation's lo plane stays out of the product
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -99,7 +99,7 @@ __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[W
 // stores issue back to back.  The per-column scalars (bias, time part of the hyper nets) are loaded once and pinned
 // with an empty asm: otherwise hipcc re-waits `vmcnt(0)` before every use inside the store loop, and since stores
 // count on vmcnt too (CDNA4) every store would wait for the previous one to complete.
-template <int WM, int WN, int EPI, int OUT, bool FULL>
+template <int WM, int WN, int EPI, int OUT, bool X2, bool FULL>
 __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 (&accm)[WM][WN],
                                                      int m0, int n0, int wr, int wc, int l31, int hi) {
     bool overflow = false;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     const int seq = m / g.S, key = m - seq * g.S;
                     const size_t o = (((size_t)seq * nh + head) * g.hd + vc) * g.Spad + vt_key_pos(key);
                     *reinterpret_cast<f16x4*>(g.Vthi + o) = vh;
-                    if (!g.x2) *reinterpret_cast<f16x4*>(g.Vtlo + o) = vl;   // F16X2: P.V takes V_hi only
+                    if (!X2) *reinterpret_cast<f16x4*>(g.Vtlo + o) = vl;   // F16X2: P.V takes V_hi only
                 }
             }
             continue;
@@ -183,7 +183,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     if (OUT == OUT_SPLIT) {
                         const size_t o = blk_index(m, n, g.N);
                         g.Chi[o] = h;
-                        if (!g.x2) g.Clo[o] = l;   // F16X2: the consumer GEMM takes A_hi only
+                        if (!X2) g.Clo[o] = l;   // F16X2: the consumer GEMM takes A_hi only
                     } else {
                         if (part == 0) {
                             g.Chi[(size_t)m * g.d + nn] = h;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                             g.Klo[(size_t)m * g.d + nn] = l;
                         } else {   // V row-major planes; v_transpose_kernel makes them key-contiguous
                             g.Vthi[(size_t)m * g.d + nn] = h;
-                            if (!g.x2) g.Vtlo[(size_t)m * g.d + nn] = l;
+                            if (!X2) g.Vtlo[(size_t)m * g.d + nn] = l;
                         }
                     }
                 }
@@ -203,17 +203,17 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
     if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
 }
 
-template <int WM, int WN, int EPI, int OUT>
+template <int WM, int WN, int EPI, int OUT, bool X2 = false>
 __device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&accm)[WM][WN],
                                                 int m0, int n0, int wr, int wc, int l31, int hi, int bm = 64 * WM,
                                                 int bn = 64 * WN) {
     if (m0 + bm <= g.M && n0 + bn <= g.N)
-        gemm_h_epilogue_impl<WM, WN, EPI, OUT, true>(g, accm, m0, n0, wr, wc, l31, hi);
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, true>(g, accm, m0, n0, wr, wc, l31, hi);
     else
-        gemm_h_epilogue_impl<WM, WN, EPI, OUT, false>(g, accm, m0, n0, wr, wc, l31, hi);
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, false>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
-template <int WM, int WN, int EPI, int OUT>
+template <int WM, int WN, int EPI, int OUT, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int LD = GEMMH_LD;
@@ -306,27 +306,27 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
                 wh[j] = *reinterpret_cast<const f16x8*>(Wh + j * 32 * LD + ks * 16);
                 wl[j] = *reinterpret_cast<const f16x8*>(Wl + j * 32 * LD + ks * 16);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
+            mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi);
+    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
-template <int WM, int WN, int EPI, int OUT>
+template <int WM, int WN, int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_cfg(const GemmHArgs& g, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
     size_t lds = gemm_h_lds_bytes<WM, WN>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<WM, WN, EPI, OUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<WM, WN, EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_kernel<WM, WN, EPI, OUT>), grid, dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_f16x3_kernel<WM, WN, EPI, OUT, X2>), grid, dim3(256), lds, st, g);
     return hipGetLastError();
 }
 
@@ -343,7 +343,7 @@ constexpr int DMA_PLANE = 128 * 32;                       // halfs per plane per
 constexpr int DMA_STAGE = 4 * DMA_PLANE;                  // Ahi, Alo, Whi, Wlo
 constexpr size_t DMA_LDS_BYTES = size_t(DMA_STAGES) * DMA_STAGE * sizeof(half_t);
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int ntm, int ntn) {
     constexpr int WM = 2, WN = 2, BM = 128, BN = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -432,22 +432,22 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
                 wh[j] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offW[j][ks]);
                 wl[j] = *reinterpret_cast<const f16x8*>(st + 3 * DMA_PLANE + offW[j][ks]);
             }
-            mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
+            mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
         }
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi);
+    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 127) / 128, ntn = (g.N + 127) / 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<EPI, OUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(256), DMA_LDS_BYTES, st, g, ntm, ntn);
+    hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(256), DMA_LDS_BYTES, st, g, ntm, ntn);
     return hipGetLastError();
 }
 
@@ -459,7 +459,7 @@ constexpr int DMA2_STAGES = 3;
 constexpr int DMA2_STAGE = 6 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi, Wlo
 constexpr size_t DMA2_LDS_BYTES = size_t(DMA2_STAGES) * DMA2_STAGE * sizeof(half_t);
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, int ntm, int ntn, int ng_req, int abl) {
     constexpr int WM = 2, WN = 2, BM = 256, BN = 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -490,9 +490,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
     auto issue = [&](int kt, int stage) {
         half_t* st = lds + stage * DMA2_STAGE + wid * 512;
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i) {
+            if (X2 && (i == 2 || i == 3)) continue;   // F16X2: no A_lo images (4 instructions per tile: vmcnt 4 below)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
                                              (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
+        }
     };
 
     f32x16 accm[WM][WN];
@@ -527,8 +529,9 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
     if (nk > 1) issue(1, 1);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk && !(abl & 4)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(kt + 1 < nk && !(abl & 4))) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (X2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < nk && !(abl & 4)) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (stage + 2) % 3
@@ -540,7 +543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
-                al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+                if (!X2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
@@ -549,26 +552,26 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
             }
             if (abl & 2) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(wh[i]), "v"(wl[i]));
+                for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(wh[i]), "v"(wl[i]));
             } else {
-                mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
+                mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
             }
         }
         stage = stage == 2 ? 0 : stage + 1;
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
+    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 255) / 256, ntn = (g.N + 127) / 128;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<EPI, OUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA2_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn,
                        g_gemm_ng, g_gemm_abl);
     return hipGetLastError();
 }
@@ -582,7 +585,7 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
 constexpr int DMA3_STAGE = 8 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi(2), Wlo(2)
 constexpr size_t DMA3_LDS_BYTES = size_t(2) * DMA3_STAGE * sizeof(half_t);
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int burst) {
     constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
     src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
     auto issue_one = [&](int kt, int i) {
         half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
-        if ((i == 2 || i == 3) && g.x2) return;   // F16X2: the A lo images stay out of LDS
+        if ((i == 2 || i == 3) && X2) return;   // F16X2: the A lo images stay out of LDS
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
                                          (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
     };
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
-                if (!g.x2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+                if (!X2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
             }
 #pragma unroll
             for (int j = 0; j < WN; ++j) {
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
                 issue_one(kt + 1, 4 * ks + 2);
                 issue_one(kt + 1, 4 * ks + 3);
             }
-            if (!g.x2)
+            if (!X2)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -687,19 +690,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
+    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (g_gemm_abl & 8) ? 0 : 1);
+    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (g_gemm_abl & 8) ? 0 : 1);
     return hipGetLastError();
 }
 
@@ -711,7 +714,7 @@ constexpr int DMA64_PLANE = 64 * 32;
 constexpr int DMA64_STAGE = 4 * DMA64_PLANE;
 constexpr size_t DMA64_LDS_BYTES = size_t(4) * DMA64_STAGE * sizeof(half_t);
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, int ntm, int ntn) {
     constexpr int WM = 1, WN = 1, BM = 64, BN = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -768,38 +771,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
             al[0] = *reinterpret_cast<const f16x8*>(st + DMA64_PLANE + offA[ks]);
             wh[0] = *reinterpret_cast<const f16x8*>(st + 2 * DMA64_PLANE + offW[ks]);
             wl[0] = *reinterpret_cast<const f16x8*>(st + 3 * DMA64_PLANE + offW[ks]);
-            mfma3<1, 1>(ah, al, wh, wl, accm, g.x2);
+            mfma3<1, 1, X2>(ah, al, wh, wl, accm);
         }
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
+    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma64(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 63) / 64, ntn = (g.N + 63) / 64;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma64_kernel<EPI, OUT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma64_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA64_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma64_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(256), DMA64_LDS_BYTES, st, g, ntm, ntn);
+    hipLaunchKernelGGL((gemm_f16x3_dma64_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(256), DMA64_LDS_BYTES, st, g, ntm, ntn);
     return hipGetLastError();
 }
 
-template <int EPI, int OUT>
-inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
+template <int EPI, int OUT, bool X2>
+inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA,
     // 5 = 64x64 LDS-DMA, 6 = 256x256 LDS-DMA (N % 256 == 0)
     const int v = g_gemm_h_variant;
-    if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT>(g, st);
-    if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT>(g, st);
-    if (v == 3) return launch_gemm_h_dma<EPI, OUT>(g, st);
-    if (v == 4) return launch_gemm_h_dma256<EPI, OUT>(g, st);
-    if (v == 5) return launch_gemm_h_dma64<EPI, OUT>(g, st);
-    if (v == 6 && g.N % 256 == 0) return launch_gemm_h_dma256x256<EPI, OUT>(g, st);
-    if (big < 256) return launch_gemm_h_dma64<EPI, OUT>(g, st);
+    if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT, X2>(g, st);
+    if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT, X2>(g, st);
+    if (v == 3) return launch_gemm_h_dma<EPI, OUT, X2>(g, st);
+    if (v == 4) return launch_gemm_h_dma256<EPI, OUT, X2>(g, st);
+    if (v == 5) return launch_gemm_h_dma64<EPI, OUT, X2>(g, st);
+    if (v == 6 && g.N % 256 == 0) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
+    if (big < 256) return launch_gemm_h_dma64<EPI, OUT, X2>(g, st);
     // auto: 256x128 unless the coarser grid quantises badly onto the 256 CUs (one workgroup per CU)
     const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };
@@ -807,10 +810,16 @@ inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
     // too many registers next to the 128 accumulators
     if (EPI != EPI_CSL && g.N % 256 == 0) {
         const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
-        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_h_dma256x256<EPI, OUT>(g, st);
+        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
     }
-    if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT>(g, st);
-    return launch_gemm_h_dma<EPI, OUT>(g, st);
+    if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT, X2>(g, st);
+    return launch_gemm_h_dma<EPI, OUT, X2>(g, st);
+}
+
+// the arithmetic mode is a template parameter of every kernel (a run-time flag in the K loops cost F16X3 4 %)
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
+    return g.x2 ? launch_gemm_h_mode<EPI, OUT, true>(g, st) : launch_gemm_h_mode<EPI, OUT, false>(g, st);
 }
 
 // fp32 -> hi/lo planes (weights at load time, activations produced by fp32-only kernels)

@@ -54,6 +54,7 @@ __global__ void split_planes_k16_kernel(const float* in, half_t* hi, half_t* lo,
     }
 }
 
+template <bool X2>
 __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int ntm) {
     constexpr int WM = 2, WN = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
     const int a_dst = (tid < 256 ? 0 : 2048) + (wid & 3) * 512;
     auto issueA = [&](int ka) {     // one wave-instruction; past the end: the last tile again into its own stage
                                     // (identical bytes: harmless while that stage is being read) so that the DMA count stays fixed
+        if (X2 && wid >= 4) return;   // F16X2: waves 4-7 would copy A_lo, which is not read (their vmcnt is 4 below)
         const int kk = ka < nk ? ka : nk - 1;
         half_t* dst = lds + GLN_A_OFF + (kk & 3) * GLN_A_STAGE + a_dst;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src + (size_t)kk * 4096),
@@ -119,8 +121,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
     int wst = 0;
     // one k16 step; ks (which half of the A tile) is a literal at both call sites so every LDS offset stays in a register
     auto step = [&](const int s, const int ks) {
-        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (X2 && wid >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         if (ks == 0) __builtin_amdgcn_s_barrier();   // A tile s/2 landed for everybody; A stage (s/2 - 1) is free again
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < nsteps) issueW(s + 2, wst == 0 ? 2 : wst - 1);   // (wst + 2) % 3
@@ -131,14 +134,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             ah[i] = *reinterpret_cast<const f16x8*>(stA + offA[i][ks]);
-            al[i] = *reinterpret_cast<const f16x8*>(stA + 2048 + offA[i][ks]);
+            if (!X2) al[i] = *reinterpret_cast<const f16x8*>(stA + 2048 + offA[i][ks]);
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
             wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
         }
-        mfma3<WM, WN>(ah, al, wh, wl, accm, g.x2);
+        mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
         wst = wst == 2 ? 0 : wst + 1;
     };
     for (int s = 0; s < nsteps; s += 2) {
@@ -244,6 +247,7 @@ constexpr int GLN2_A_OFF = 3 * GLN_W_STAGE;
 constexpr size_t GLN2_LDS_BYTES = size_t(GLN2_A_OFF + 3 * GLN2_A_STAGE) * sizeof(half_t);   // 96 + 48 = 144 KB
 static_assert(size_t(64) * GLN_TILE_LD * sizeof(float) <= GLN2_LDS_BYTES, "epilogue tile must fit the ring");
 
+template <bool X2>
 __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, int ntm) {
     constexpr int WM = 4, WN = 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
         half_t* dst = lds + GLN2_A_OFF + (kk % 3) * GLN2_A_STAGE + wid * 512;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_hi + (size_t)kk * 4096),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        if (X2) return;             // F16X2: A_lo is neither copied nor read (one instruction per tile: vmcnt 5 below)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_lo + (size_t)kk * 4096),
                                          (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
     };
@@ -301,8 +306,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
     issueW(1, 1);
     int wst = 0, ast = 0;
     auto step = [&](const int s, const int ks) {
-        if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (X2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         if (ks == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < nsteps) issueW(s + 2, wst == 0 ? 2 : wst - 1);
@@ -313,14 +319,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
             ah[i] = *reinterpret_cast<const f16x8*>(stA + offA[i][ks]);
-            al[i] = *reinterpret_cast<const f16x8*>(stA + 4096 + offA[i][ks]);
+            if (!X2) al[i] = *reinterpret_cast<const f16x8*>(stA + 4096 + offA[i][ks]);
         }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
             wl[j] = *reinterpret_cast<const f16x8*>(stW + GLN_BN * 16 + offW[j]);
         }
-        mfma3<WM, WN>(ah, al, wh, wl, acc, g.x2);
+        mfma3<WM, WN, X2>(ah, al, wh, wl, acc);
         wst = wst == 2 ? 0 : wst + 1;
         if (ks == 1) ast = ast == 2 ? 0 : ast + 1;
     };
@@ -416,11 +422,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
 
 static int g_ln_rows = 0;   // tuning knob "ln_rows": 0 auto (128-row tiles from 32768 tokens), 64, 128
 
-inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
+template <bool X2>
+inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_f16x3_kernel),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_f16x3_kernel<X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_f16x3_kernel<X2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN2_LDS_BYTES);
         attr_set = true;
     }
     // row tile by how well the grid fills whole rounds of the 256 CUs (one workgroup per CU); at equal fill the
@@ -429,19 +438,17 @@ inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
     const long n128 = (g.M + GLN2_BM - 1) / GLN2_BM, n64 = (g.M + GLN_BM - 1) / GLN_BM;
     const bool rows128 = g_ln_rows == 128 || (g_ln_rows == 0 && 1.04 * fill(n128) >= fill(n64));
     if (rows128) {
-        static bool attr2_set = false;
-        if (!attr2_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_f16x3_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN2_LDS_BYTES);
-            attr2_set = true;
-        }
         const int ntm = (g.M + GLN2_BM - 1) / GLN2_BM;
-        hipLaunchKernelGGL(gemm_ln128_f16x3_kernel, dim3(ntm), dim3(512), GLN2_LDS_BYTES, st, g, ntm);
+        hipLaunchKernelGGL(gemm_ln128_f16x3_kernel<X2>, dim3(ntm), dim3(512), GLN2_LDS_BYTES, st, g, ntm);
         return hipGetLastError();
     }
     const int ntm = (g.M + GLN_BM - 1) / GLN_BM;
-    hipLaunchKernelGGL(gemm_ln_f16x3_kernel, dim3(ntm), dim3(512), GLN_LDS_BYTES, st, g, ntm);
+    hipLaunchKernelGGL(gemm_ln_f16x3_kernel<X2>, dim3(ntm), dim3(512), GLN_LDS_BYTES, st, g, ntm);
     return hipGetLastError();
+}
+
+inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
+    return g.x2 ? launch_gemm_ln_mode<true>(g, st) : launch_gemm_ln_mode<false>(g, st);
 }
 
 }  // namespace jmid
