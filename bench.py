@@ -39,8 +39,14 @@ WORKLOADS = {
     "cfg4": (1, 25, 64, 12, 50),     # configs[3]: dense crowd, one scene
     "cfg5": (512, 5, 20, 12, 50),    # configs[4]: 4096 episodes sharded 512 / GPU
 }
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
-MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16": 1}
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0, "f16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+# MFMA FLOPs spent per algorithmic FLOP; f16x2: 2 in the GEMMs, (3 + 2) / 2 in attention (logits keep all three terms)
+MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2, "f16": 1}
+MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.5, "f16": 1}
+# PMC summaries of the mode (tools/round_profile.sh, tools/mfma_busy.sh): (HBM traffic, MFMA busy); absent file = field omitted
+PMC_FILES = {"f16x3": ("r01_pmc_traffic.json", "r01_mfma_busy.json"),
+             "f16x2": ("r01_pmc_traffic_f16x2.json", "r01_mfma_busy_f16x2.json"),
+             "f32": ("r01_pmc_traffic_f32.json", "r01_mfma_busy_f32.json")}
 
 
 def algorithmic_flops(dims: NetDims, joint: bool, E, A, K, T):
@@ -73,7 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--episodes-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2"])
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="episodes timed on the host for cpu_baseline (0 = skip)")
@@ -183,8 +189,9 @@ def main():
         "value": round(value, 2), "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None,
-        "dtype": {"f32": "f32", "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate"}[
-            args.precision],
+        "dtype": {"f32": "f32", "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate",
+                  "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; softmax "
+                           "logits, residual stream, LayerNorm and DDIM state at f32-class precision"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {E} episodes/GPU x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
@@ -205,10 +212,11 @@ def main():
         dom_t = {"launches": n, "avg_ms": ms / n, "total_ms": ms,
                  "tflops": fl[dom] * steps50 * args.steps / (ms * 1e-3) / 1e12}
         peak = PEAK_TFLOPS[args.precision]
+        passes = (MFMA_PASSES_ATTN if dom == "attention" else MFMA_PASSES)[args.precision]
         traffic = None
         try:   # PMC-measured HBM bytes per launch of this kernel class (separate rocprofv3 --pmc passes, profiles/)
-            pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))
-            if dom in pmc and args.precision == "f16x3":
+            pmc = json.load(open(os.path.join(REPO, "profiles", PMC_FILES[args.precision][0])))
+            if dom in pmc:
                 launches_per_step = dom_t["launches"] / (steps50 * args.steps * dims.tf_layer)   # chunks per step
                 tokens_per_launch = E * A * K * H / launches_per_step
                 traffic = pmc[dom]["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
@@ -220,8 +228,8 @@ def main():
         path_tflops = sum(fl.values()) * steps50 * args.steps / elapsed / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(dom_x["tflops"], 2), "peak": peak,
                            "unit": "TFLOP/s", "frac": round(dom_x["tflops"] / peak, 4), "traffic": traffic,
-                           "frac_of_split_peak": round(dom_x["tflops"] * MFMA_PASSES[args.precision] / peak, 4),
-                           "mfma_passes_per_product": MFMA_PASSES[args.precision],
+                           "frac_of_split_peak": round(dom_x["tflops"] * passes / peak, 4),
+                           "mfma_passes_per_product": passes,
                            "flops_per_launch": fl[dom] * steps50 * (args.steps if args.lanes == 1 else 1) / dom_x["launches"],
                            "avg_launch_ms": round(dom_x["avg_ms"], 4), "launches": dom_x["launches"],
                            "measured": ("HIP events on the library's stream around every launch of this kernel class in the "
@@ -240,14 +248,14 @@ def main():
                            "peak_sustained_random_operands": 1660.0,
                            "note": "peak = dense fp16 MFMA of MI355X_MICROARCH.md; a pure MFMA loop with fresh random "
                                    "operands sustains 1.66 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip, warm clocks), and "
-                                   "this mode spends 3 MFMA FLOPs per algorithmic FLOP"}
+                                   f"this mode spends {passes} MFMA FLOPs per algorithmic FLOP of this kernel"}
         try:   # PMC: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), tools/mfma_busy.sh
-            busy = json.load(open(os.path.join(REPO, "profiles", "r01_mfma_busy.json")))
-            if args.precision == "f16x3" and joint:
+            busy = json.load(open(os.path.join(REPO, "profiles", PMC_FILES[args.precision][1])))
+            if joint:
                 out["roofline"]["mfma_busy"] = {
                     "whole_call": round(busy["whole_call_mfma_busy"], 4),
                     "dominant_kernel": round(next(v["mfma_busy"] for k, v in busy["kernels"].items() if "attn_f16x3" in k), 4),
-                    "source": "rocprofv3 PMC over one 51-episode predictor call (profiles/r01_mfma_busy.json): fraction "
+                    "source": f"rocprofv3 PMC over one 51-episode predictor call (profiles/{PMC_FILES[args.precision][1]}): fraction "
                               "of the shader cycles of a dispatch in which a SIMD's MFMA pipe is busy"}
         except Exception:
             pass
@@ -257,12 +265,12 @@ def main():
         out["kernels_note"] = "per-class HIP-event times of ONE untimed pass over the same batch with one chunk in flight"
     # ---- HBM side of the roofline (north_star asks for it): PMC bytes of one whole predictor call, per trajectory
     try:
-        call = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["call"]
-        if args.precision == "f16x3" and joint and (N, K, H, steps50) == (5, 20, 12, 50):
+        call = json.load(open(os.path.join(REPO, "profiles", PMC_FILES[args.precision][0])))["call"]
+        if joint and (N, K, H, steps50) == (5, 20, 12, 50):
             bpt = call["hbm_bytes_per_trajectory"]
             out["hbm"] = {"bytes_per_trajectory": bpt, "GBps": round(bpt * value / 1e9, 1), "peak_GBps": 8000.0,
                           "frac": round(bpt * value / 8e12, 4), "source": "rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE over one "
-                          "51-episode call (profiles/r01_pmc_traffic.json), scaled by this run's traj/s",
+                          f"51-episode call (profiles/{PMC_FILES[args.precision][0]}), scaled by this run's traj/s",
                           "model_bytes_per_trajectory": {"layer_streamed_bf16": call[
                               "model_bytes_per_trajectory_layer_streamed_bf16"], "minimal": call[
                               "model_bytes_per_trajectory_minimal"]}}
@@ -288,6 +296,24 @@ def main():
         dt1 = (time.perf_counter() - t1) / reps
         out["single_scene"] = {"workload": f"cfg2: 1 scene x N={N} x K={K} x H={H}, {steps50} steps",
                                "ms_per_call": round(1e3 * dt1, 3), "traj_per_s": round(A * K / dt1, 1)}
+
+        # the other split-fp16 mode on the same batch, one warm pass + one timed pass (not part of `value`)
+        other = {"f16x2": "f16x3", "f16x3": "f16x2"}.get(args.precision)
+        if other:
+            ctx_o = eng.encode(x_st, nbr, emask).view(E, A, -1)
+            eng.denoise(x_T, ctx_o, p0, dt=0.25, precision=other, want_vel=False)
+            eng.synchronize()
+            t2 = time.perf_counter()
+            ctx_o = eng.encode(x_st, nbr, emask).view(E, A, -1)
+            _, pos_other = eng.denoise(x_T, ctx_o, p0, dt=0.25, precision=other, want_vel=False)
+            met_o = eng.episode_metrics(pos_other, gt)
+            eng.synchronize()
+            dt2 = time.perf_counter() - t2
+            out["other_modes"] = {other: {"value": round(E * A * K / dt2, 2), "unit": "traj/s", "ms_per_step": round(1e3 * dt2, 3),
+                                          "mean_ADE_between_modes_m": float(np.linalg.norm(
+                                              (pos_other - pos).cpu().numpy(), axis=-1).mean()),
+                                          "note": "same batch, one pass, same run; f16x3 = three-term split products "
+                                                  "(fp32-class everywhere), f16x2 = activation-lo terms left out"}}
 
     log("single-scene done")
     # ---- CPU baseline (the oracle, a port of the reference; bounded sample) + parity on the same episodes
@@ -334,7 +360,11 @@ def main():
                                "kind": "port",
                                "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, "
                                          f"{cpu_s:.1f} s; oracle/jmid_oracle.py, torch-CPU fp32)"}
-        out["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4}
+        out["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4,
+                         "precision": args.precision}
+        if "other_modes" in out:
+            for m, o in out["other_modes"].items():
+                o["mean_ADE_vs_oracle_m"] = float(np.linalg.norm(pos_other[:ne].cpu().numpy() - pos_ref, axis=-1).mean())
     print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -8,4 +8,4 @@ rng = np.random.default_rng(0)
 nseq, S, d = 51, 1200, 512
 qkv = rng.standard_normal((nseq * S, 3 * d)).astype(np.float32)
 for _ in range(3):
-    eng.dbg_attention(qkv, nseq, S, precision=sys.argv[1] if len(sys.argv) > 1 else "f16x3")
+    eng.dbg_attention(qkv, nseq, S, precision=sys.argv[1] if len(sys.argv) > 1 else os.environ.get("JMID_PREC", "f16x2"))

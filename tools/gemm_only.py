@@ -11,4 +11,4 @@ b = rng.standard_normal(N).astype(np.float32)
 v = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 eng.set_tuning("gemm_h_variant", v)
 for _ in range(3):
-    eng.dbg_gemm(A, W, b, precision="f16x3")
+    eng.dbg_gemm(A, W, b, precision=os.environ.get("JMID_PREC", "f16x2"))

@@ -18,6 +18,6 @@ emask = torch.from_numpy(syn["edge_mask"].reshape(E * N, 2)).to(dev)
 p0 = torch.from_numpy(syn["p0"]).to(dev)
 x_T = torch.randn([E, K * N, H, 2], generator=torch.Generator().manual_seed(0)).to(dev)
 ctx = eng.encode(x_st, nbr, emask)
-vel, pos = eng.denoise(x_T, ctx.view(E, N, -1), p0, dt=0.25, precision="f16x3", want_vel=False)
+vel, pos = eng.denoise(x_T, ctx.view(E, N, -1), p0, dt=0.25, precision=os.environ.get("JMID_PREC", "f16x2"), want_vel=False)
 eng.synchronize()
 print("trajectories", E * N * K)
