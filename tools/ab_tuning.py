@@ -26,7 +26,7 @@ for rep in range(4):
         eng.set_tuning(key, v)
         eng.synchronize(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        eng.denoise(x_T, ctx, None, precision="f16x3", want_pos=False)
+        eng.denoise(x_T, ctx, None, precision=os.environ.get("AB_PREC", "f16x2"), want_pos=False)
         eng.synchronize()
         if rep:
             res[v].append(time.perf_counter() - t0)
