@@ -16,7 +16,7 @@ timeout 300 python bench.py --workload cfg4 --cpu-episodes 0 --steps 3 > $O/benc
 timeout 400 python bench.py --workload cfg5 --cpu-episodes 0 --steps 2 > $O/bench_cfg5_1gpu.log 2>&1
 timeout 300 python bench.py --net imid --cpu-episodes 0 --steps 2 > $O/bench_cfg3_imid.log 2>&1
 fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --precision $P --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --precision $P --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$P.log 2>&1
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${P}_kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_attn_$c -- python tools/attn_only.py > /dev/null 2>&1
