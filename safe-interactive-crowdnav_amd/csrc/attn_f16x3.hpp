@@ -274,6 +274,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const size_t tok0 = (size_t)seq * S;
     const int q = (qt * 4 + wid) * 32 + l31;
     const int qc = q < S ? q : S - 1;
+    // all 32 queries of this wave lie past the end of the sequence (last q-tile): it keeps copying its share of every
+    // K / V^T tile and meets the barriers, but computes nothing
+    const bool wave_idle = (qt * 4 + wid) * 32 >= S;
 
     f16x8 qh[NKS], ql[NKS];
     {
@@ -352,6 +355,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         const bool more = kt + 1 < ntiles && !(abl & 1);    // abl: timing ablations (diagnostics only)
         if (more && (abl & 16)) issue(kt + 1);
         ATT_STAMP(3)
+        if (wave_idle) {       // S = 1200: 2 of the 40 waves of a (sequence, head) - 5 % of the kernel's MFMA work
+            if (more && !(abl & 16)) issue(kt + 1);
+            continue;
+        }
         const half_t* Kh = lds + ((abl & 1) ? 0 : (kt & 1)) * ATT_STAGE;
         const half_t* Kl = Kh + ATT_KPLANE;
         const half_t* Vh = Kh + 2 * ATT_KPLANE;

@@ -7,6 +7,9 @@
 // ONE fp32 accumulator:      acc += Ahi.Whi ; acc += Ahi.Wlo ; acc += Alo.Whi
 // (the lo.lo term is 2^-22 relative and dropped).  Operand representation error 8e-8 relative on a K = 512 product
 // (fp32 inputs: 6e-8).  Peak is 1/3 of the dense fp16 MFMA rate = 833 TFLOP/s, 5.3x the exact-fp32 MFMA path.
+// JMID_PREC_F16X2 (template parameter X2 of every kernel here): the Alo.Whi term is left out - the activation enters
+// as fp16, the weights stay exact - and the A_lo images are neither copied into LDS nor written by the epilogues
+// whose consumer is such a GEMM.  Two MFMAs per product, 1250 TFLOP/s peak; parity in DESIGN.md section 3.
 //
 // Operand fragments are 8 consecutive k per lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15 of each 16-wide step);
 // A and W use the same per-lane k assignment, which is all the instruction requires.
