@@ -164,6 +164,7 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "bystander_lds"   bytes of dynamic LDS (0..163840, default 0) the row-wise kernels request without using them, so
  *                     that they never share a CU with an attention / GEMM workgroup of another lane (>= 65536 made
  *                     lanes > 1 reproducible in every soak run so far; process-wide, not per handle)
+ *   "fuse_embed"      0 = separate embedding kernel at the start of every step instead of the fused output kernel
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
  *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
  *   "gemm_ng", "gemm_abl", "attn_abl", "print_occupancy"   diagnostics used by tools/ (ablations give WRONG results)

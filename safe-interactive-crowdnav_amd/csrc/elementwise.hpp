@@ -24,38 +24,41 @@ struct EmbedArgs {
     half_t* Xl;
 };
 
+// channels j..j+3 of token m (row t of the positional table): ConcatSquash(2 -> d) + PE, stored as fp32 and / or planes
+__device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, int t, float x0, float x1, const float* hrow) {
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = j + e;
+        const float lin = a.W1[2 * c] * x0 + a.W1[2 * c + 1] * x1 + a.b1[c];
+        const float gate = sigmoidf_(hrow[a.goff + c] + a.thyp[a.goff + c]);
+        const float bias = hrow[a.boff + c] + a.thyp[a.boff + c];
+        o[e] = lin * gate + bias + a.pe[(size_t)t * a.d + c];
+    }
+    if (a.X) *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
+    if (a.Xh) {
+        f16x4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            half_t hh, ll;
+            split_f32(o[e], hh, ll);
+            vh[e] = hh;
+            vl[e] = ll;
+        }
+        const size_t ob = blk_index(m, j, a.d);
+        *reinterpret_cast<f16x4*>(a.Xh + ob) = vh;
+        *reinterpret_cast<f16x4*>(a.Xl + ob) = vl;
+    }
+}
+
 // one thread per (token, 4 channels)
 __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     const int d4 = a.d >> 2;
     const long total = (long)a.M * d4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / d4), j = (int)(idx % d4) * 4;
-        const float x0 = a.x[2 * (size_t)m], x1 = a.x[2 * (size_t)m + 1];
-        const int t = m % a.rmap.T;
-        const float* hrow = a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld;
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = j + e;
-            const float lin = a.W1[2 * c] * x0 + a.W1[2 * c + 1] * x1 + a.b1[c];
-            const float gate = sigmoidf_(hrow[a.goff + c] + a.thyp[a.goff + c]);
-            const float bias = hrow[a.boff + c] + a.thyp[a.boff + c];
-            o[e] = lin * gate + bias + a.pe[(size_t)t * a.d + c];
-        }
-        if (a.X) *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
-        if (a.Xh) {
-            f16x4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                half_t hh, ll;
-                split_f32(o[e], hh, ll);
-                vh[e] = hh;
-                vl[e] = ll;
-            }
-            const size_t ob = blk_index(m, j, a.d);
-            *reinterpret_cast<f16x4*>(a.Xh + ob) = vh;
-            *reinterpret_cast<f16x4*>(a.Xl + ob) = vl;
-        }
+        embed_store(a, m, j, m % a.rmap.T, a.x[2 * (size_t)m], a.x[2 * (size_t)m + 1],
+                    a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld);
     }
 }
 
@@ -154,8 +157,10 @@ struct OutArgs {
     float c0, c1, sigma;
 };
 
-// one wave per token
-__global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a) {
+// one wave per token.  EMBED_NEXT: the wave goes on with the next step's embedding of its token (same arithmetic as
+// embed_kernel, with the next step's time parts `nxt.thyp`): one launch and one pass over x less per denoise step.
+template <bool EMBED_NEXT>
+__global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= a.M) return;
@@ -168,6 +173,7 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a) {
     }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
+    float xn0 = 0.f, xn1 = 0.f;      // the updated x of this token (lane 0)
     if (lane == 0) {
         const float* hrow = a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld;
         const float e0 = (s0 + a.bo[0]) * sigmoidf_(hrow[a.goff] + a.thyp[a.goff]) + hrow[a.boff] + a.thyp[a.boff];
@@ -188,7 +194,15 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a) {
                 a.x[2 * (size_t)m] = a.n_x * p0 + a.n_e * e0;
                 a.x[2 * (size_t)m + 1] = a.n_x * p1 + a.n_e * e1;
             }
+            xn0 = a.x[2 * (size_t)m];
+            xn1 = a.x[2 * (size_t)m + 1];
         }
+    }
+    if (EMBED_NEXT) {
+        const float x0 = __shfl(xn0, 0, 64), x1 = __shfl(xn1, 0, 64);
+        const int t = m % nxt.rmap.T;
+        const float* hrow = nxt.hyp + (size_t)nxt.rmap.ea(m) * nxt.hyp_ld;
+        for (int j = lane * 4; j < nxt.d; j += 256) embed_store(nxt, m, j, t, x0, x1, hrow);
     }
 }
 

@@ -264,6 +264,8 @@ int upload_time_table(jmid_ctx* h) {
     return dev_alloc_copy(h, &h->thyp, t);
 }
 
+static int g_fuse_embed = 1;   // tuning knob "fuse_embed": the output kernel of step i embeds x for step i + 1
+
 // ---------------------------------------------------------------------------------------------- launch helpers
 template <int EPI>
 int run_gemm(jmid_ctx* h, int cls, GemmArgs& g) {
@@ -377,13 +379,21 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
 
 // one evaluation of the net on a chunk of whole episodes + (optionally) the DDIM update
 int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, int step_idx, float* x_chunk,
-             const float* hyp_chunk, float* e_out, int precision, const float* z_chunk = nullptr) {
+             const float* hyp_chunk, float* e_out, int precision, const float* z_chunk = nullptr,
+             bool embed_done = false, int next_step = -1) {
+    // embed_done: the previous step's output kernel already embedded x for this step; next_step >= 0: this step's
+    // output kernel does the same for step `next_step` (same chunk, same buffers)
     const bool split = precision != JMID_PREC_F32;
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
     RowMap rm{T, A, K * A};
-    {
+    const auto embed_args = [&](const float* th) {
+        return EmbedArgs{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, th,
+                         split ? nullptr : sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
+                         split ? sb.Xl : nullptr};
+    };
+    if (!embed_done) {
         ProfScope ps(h, KC_EMBED);
         EmbedArgs ea{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, thyp,
                      split ? nullptr : sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
@@ -535,7 +545,12 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.c1 = h->p_c1[step_idx];
             oa.sigma = h->p_sigma[step_idx];
         }
-        hipLaunchKernelGGL(out_ddim_kernel, dim3((M + 3) / 4), dim3(256), bystander_lds(out_ddim_kernel), h->stream, oa);
+        if (next_step >= 0 && !e_out)
+            hipLaunchKernelGGL(out_ddim_kernel<true>, dim3((M + 3) / 4), dim3(256), bystander_lds(out_ddim_kernel<true>),
+                               h->stream, oa, embed_args(h->thyp + (size_t)next_step * h->hl.total));
+        else
+            hipLaunchKernelGGL(out_ddim_kernel<false>, dim3((M + 3) / 4), dim3(256), bystander_lds(out_ddim_kernel<false>),
+                               h->stream, oa, EmbedArgs{});
         HIPCHK(h, hipGetLastError());
     }
     return 0;
@@ -675,7 +690,8 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
                 const float* hc = hyp + (size_t)el * A * h->hl.total;
                 const float* zc = z_use ? z_use + ((size_t)i * M + (size_t)el * K * A * T) * 2 : nullptr;
                 if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);   // net_step launches on h->stream
-                const int rc = net_step(h, sbs[l], ec, A, K, T, i, xc, hc, nullptr, precision, zc);
+                const int rc = net_step(h, sbs[l], ec, A, K, T, i, xc, hc, nullptr, precision, zc, g_fuse_embed && i > 0,
+                                        g_fuse_embed && i + 1 < n_steps ? i + 1 : -1);
                 if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);
                 if (rc) return rc;
             }
@@ -1142,6 +1158,10 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     if (k == "lanes") {     // chunks of the denoise loop in flight at once: 1..4
         if (value < 1 || value > jmid_ctx::kMaxLanes) return fail(h, JMID_EINVAL, "lanes must be 1..4");
         h->lanes = value;
+        return JMID_OK;
+    }
+    if (k == "fuse_embed") {    // 0: separate embed_kernel at the start of every step (A/B of the fused output kernel)
+        g_fuse_embed = value != 0;
         return JMID_OK;
     }
     if (k == "bystander_lds") {   // bytes of unused dynamic LDS requested by the row-wise kernels (0..163840)

@@ -352,3 +352,24 @@ def test_split_modes_hold_parity_when_attention_is_peaked():
     print("peaked attention: mean ADE vs exact fp32", err)
     assert err["f16x3"] <= 1e-5, err
     assert err["f16x2"] <= ADE_GATE, err
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w32_a5k20t12_s50.npz", "ddpm_jmid_w32_a2k3t4_s10.npz"])
+def test_output_kernel_with_fused_next_embedding_is_bit_identical(case, precision):
+    """The output kernel of step i also embeds x for step i + 1 (one launch less per step): same bits as the separate
+    embed_kernel, DDIM and DDPM."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    ddpm = case.startswith("ddpm")
+    eng.set_step(int(z["step"]), "ddpm" if ddpm else "ddim")
+    out = []
+    try:
+        for fuse in (1, 0):
+            eng.set_tuning("fuse_embed", fuse)
+            kw = {"z": z["z"][:, None]} if ddpm else {}
+            out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False, **kw)[0][0])
+    finally:
+        eng.set_tuning("fuse_embed", 1)
+        eng.set_step(int(z["step"]), "ddim")
+    np.testing.assert_array_equal(out[0], out[1])
