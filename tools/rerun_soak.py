@@ -1,0 +1,27 @@
+"""Bit-reproducibility soak of the default path (one chunk in flight): N full 50-step calls on the same inputs, every
+output compared bit for bit with the first.   python tools/rerun_soak.py [precision] [calls] [episodes]"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from safe_interactive_crowdnav_amd.engine import JmidEngine
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x2"
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+E = int(sys.argv[3]) if len(sys.argv) > 3 else 103
+A, K, T = 5, 20, 12
+eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 23), joint=True, step=50)
+g = torch.Generator().manual_seed(3)
+ctx = torch.randn([E, A, 256], generator=g).cuda()
+x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+ref, bad = None, 0
+for i in range(calls):
+    v = eng.denoise(x_T, ctx, None, precision=prec, want_pos=False)[0]
+    eng.synchronize()
+    if ref is None:
+        ref = v.clone()
+    elif not torch.equal(v, ref):
+        bad += 1
+        print(f"call {i}: {int((v != ref).any(dim=-1).sum())} points differ", flush=True)
+print(f"{prec}: {calls} calls of {E} episodes ({E * A * K} trajectories each), {bad} differ from the first")
