@@ -47,7 +47,7 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     A_hi x (W_hi + W_lo) in the GEMMs and (P_hi + P_lo) x V_hi in attention, two MFMAs per product;
  *                     the softmax logits Q.K keep all three terms (their error is exponentiated) and the residual
  *                     stream, LayerNorm and DDIM state keep hi + lo.  Mean ADE vs the reference 7e-6 m on the cfg3
- *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~15 % more trajectories per second
+ *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~25 % more trajectories per second on batches; the lo planes this mode never reads are not written
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3 };
 
