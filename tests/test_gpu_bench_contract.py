@@ -30,3 +30,7 @@ def test_bench_json_contract():
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
+    # the default run is the two-term mode; the three-term mode is timed and checked against the oracle in the same run
+    assert j["config"]["precision"] == "f16x2" and j["parity"]["precision"] == "f16x2"
+    o = j["other_modes"]["f16x3"]
+    assert o["value"] > 0 and o["mean_ADE_vs_oracle_m"] <= 1e-5 and o["mean_ADE_between_modes_m"] <= 1e-4
