@@ -17,6 +17,12 @@
  *     e.g. torch.Tensor.data_ptr(); no copies are made).
  *   - one HIP stream per handle; a handle is not re-entrant (the reference is a
  *     single-threaded caller; mid_sim_wrapper.py:174 only locks its history buffer).
+ *   - JMID_MEM_DEVICE calls are stream-ordered against the CALLER's stream (jmid_set_caller_stream, default the
+ *     legacy null stream): on entry the handle's stream waits for everything the caller enqueued on that stream,
+ *     on exit that stream waits for the call's last kernel.  The call may return before the outputs are complete
+ *     (exact-fp32 mode; the split modes read a range flag back and therefore block): consume them on the caller's
+ *     stream, or call jmid_synchronize first.  Buffers produced or consumed on any OTHER stream need the caller's
+ *     own events.  JMID_MEM_HOST calls return with the outputs complete.
  *   - all floating point buffers are fp32, row-major, densely packed.
  *
  * Row / token order used throughout (matches the reference's `context.repeat(sample, 1)`,
@@ -148,9 +154,15 @@ int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, con
 int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const float* pos, const float* gt,
                          float* out, int mem);
 
+/* The stream (a hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream; NULL = the legacy default
+ * stream) that produces the inputs and consumes the outputs of this handle's JMID_MEM_DEVICE calls - see Conventions. */
+int jmid_set_caller_stream(jmid_handle_t h, void* stream);
+
 /* ---- tuning / measurement ------------------------------------------------------------------ */
-/* Episodes processed together per pass of the 50-step loop (0 = automatic).  Smaller chunks keep the
- * activations of one pass resident in the 256 MiB Infinity Cache. */
+/* Episodes processed together per pass of the 50-step loop (0 = automatic: a whole number of rounds of the attention
+ * launch, a short ragged tail spread over the full chunks).  Results are bit-identical for every chunking of the same
+ * call; the split-KV factor of the attention launches is a function of (E, A, K, T) only, so calls with different
+ * episode counts agree to rounding (ADE ~1e-7 m), not bit for bit, when head_dim is 128. */
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
 /* Implementation knobs for experiments (never needed for correctness).  Keys:
  *   "gemm_h_variant"  F16X3 GEMM kernel: 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged,
@@ -163,13 +175,16 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     faster but results were seen to vary from run to run - see DESIGN.md)
  *   "bystander_lds"   bytes of dynamic LDS (0..163840, default 0) the row-wise kernels request without using them, so
  *                     that they never share a CU with an attention / GEMM workgroup of another lane (>= 65536 made
- *                     lanes > 1 reproducible in every soak run so far; process-wide, not per handle)
+ *                     lanes > 1 reproducible in every soak run so far)
  *   "fuse_embed"      0 = separate embedding kernel at the start of every step instead of the fused output kernel
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
  *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
- *   "gemm_ng", "gemm_abl", "attn_abl", "print_occupancy"   diagnostics used by tools/ (ablations give WRONG results)
- * All variants of a key compute the same values (bit-identical for gemm_h_variant, ln_fuse, ln_rows and no_vt_direct).
- * Unknown keys return JMID_EINVAL. */
+ *   "persist"         one persistent kernel per denoise step for small token counts: 0 auto, 1 always, 2 never
+ *   "ff_fuse"         linear1 -> ReLU -> linear2 + residual + LayerNorm in one kernel: 0 auto, 1 always, 2 never
+ *   "gemm_ng", "print_occupancy"   diagnostics used by tools/
+ *   "gemm_abl", "attn_abl"         timing ablations (WRONG results): exist only in builds with -DJMID_ABLATIONS
+ * Every knob belongs to the handle it is set on.  All variants of a key compute the same values (bit-identical for
+ * gemm_h_variant, ln_fuse, ln_rows and no_vt_direct).  Unknown keys return JMID_EINVAL. */
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream.
  * mask: bit i enables class i (see jmid_kernel_class_name); 0 disables.  Timers accumulate until reset. */

@@ -577,26 +577,23 @@ inline int attn_pick_nsplit(int base_blocks, int S) {
     return eff(best) > eff(1) + 0.1 ? best : 1;
 }
 
-static int g_attn_abl = 0;        // timing ablation bits (diagnostics)
-static int g_attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
 
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, hipStream_t st) {
-    if (head_dim == 128 && g_attn_h_variant != 1) {
-        static bool attr_set = false;
-        if (!attr_set) {
+    if (head_dim == 128 && tune().attn_h_variant != 1) {
+        static bool attr_seen[64] = {};
+        if (first_use_on_device(attr_seen)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-            attr_set = true;
         }
         const int nqt = (a.S + 127) / 128;
         const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
         if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
-            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, g_attn_abl,
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
                                (unsigned long long*)nullptr);
         else
-            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, g_attn_abl,
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
                                (unsigned long long*)nullptr);
         if (a.nsplit > 1) {
             const size_t Mtot = (size_t)nseq * a.S;

@@ -319,19 +319,17 @@ __global__ __launch_bounds__(256, 2) void attn_f32_packed_kernel(AttnArgs a, int
     }
 }
 
-static int g_attn_pack = 1;   // tuning knob: 0 = one sequence per wave even when S <= 16 (A/B, jmid_set_tuning "attn_pack")
 
 template <int HD>
 inline hipError_t launch_attn_f32_hd(const AttnArgs& a, int nseq, hipStream_t st) {
-    if (a.S <= 16 && g_attn_pack) {
+    if (a.S <= 16 && tune().attn_pack) {
         const int J = (a.S + 1) / 2;
         const int G = std::min(32 / a.S, 16 / J);
         const size_t lds = size_t(4) * 32 * (HD + 4) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_seen[64] = {};
+        if (first_use_on_device(attr_seen)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_packed_kernel<HD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
         }
         dim3 grid((nseq + G - 1) / G, (a.nhead + 3) / 4);
         hipLaunchKernelGGL((attn_f32_packed_kernel<HD>), grid, dim3(256), lds, st, a, nseq, G, J);

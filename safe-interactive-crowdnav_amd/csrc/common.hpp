@@ -67,13 +67,62 @@ __host__ __device__ __forceinline__ int vt_key_pos(int key) {
 }
 __host__ __device__ __forceinline__ int vt_spad(int S) { return (S + 15) / 16 * 16; }
 
+// Tuning knobs (jmid_set_tuning).  They belong to a handle: every entry point of the C ABI installs its handle's
+// set for the duration of the call (TuneScope, thread-local), the launch helpers read it through tune().
+struct Tuning {
+    int fuse_embed = 1;      // the output kernel of step i embeds x for step i + 1
+    int ln_fuse = 0;         // 0 auto, 1 always, 2 never: fused GEMM + residual + LayerNorm
+    int ln_rows = 0;         // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
+    int bystander_lds = 0;   // dynamic LDS the small row-wise kernels request although they use none
+    int gemm_h_variant = 0;  // 0 auto, 1..6 force a tile variant of the split-fp16 GEMM
+    int gemm_ng = 0;         // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
+    int no_vt_direct = 0;    // 1: V row-major + v_transpose_kernel even when the fused V^T epilogue applies
+    int attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
+    int attn_pack = 1;       // 0 = one short sequence per wave even when S <= 16
+    int persist = 0;         // small-M persistent step kernel: 0 auto, 1 always (when applicable), 2 never
+    int ff_fuse = 0;         // fused linear1 -> ReLU -> linear2 + residual + LayerNorm: 0 auto, 1 always, 2 never
+    int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS
+    int gemm_abl = 0;
+};
+inline const Tuning*& tuning_slot() {
+    static thread_local const Tuning* p = nullptr;
+    return p;
+}
+inline const Tuning& tune() {
+    static const Tuning dflt;
+    const Tuning* p = tuning_slot();
+    return p ? *p : dflt;
+}
+struct TuneScope {
+    const Tuning* prev;
+    explicit TuneScope(const Tuning* t) : prev(tuning_slot()) { tuning_slot() = t; }
+    ~TuneScope() { tuning_slot() = prev; }
+};
+#ifdef JMID_ABLATIONS
+inline int attn_abl_bits() { return tune().attn_abl; }
+inline int gemm_abl_bits() { return tune().gemm_abl; }
+#else
+inline int attn_abl_bits() { return 0; }
+inline int gemm_abl_bits() { return 0; }
+#endif
+
+// One-time per-device setup (function attributes are per device): true the first time `seen` meets the current device.
+inline bool first_use_on_device(bool (&seen)[64]) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (seen[dev]) return false;
+    seen[dev] = true;
+    return true;
+}
+
 // Dynamic LDS the small row-wise kernels request although they use none (tuning knob "bystander_lds").  With a
 // request above 96 KB such a workgroup cannot share a CU with an attention or GEMM workgroup of another chunk lane.
-static int g_bystander_lds = 0;
 template <typename F>
 static inline int bystander_lds(F* fn) {
-    if (g_bystander_lds > 0) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, g_bystander_lds);
-    return g_bystander_lds;
+    const int n = tune().bystander_lds;
+    if (n > 0) (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, n);
+    return n;
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -43,10 +43,6 @@ __device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& 
 
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
-static int g_gemm_h_variant = 0;  // tuning knob (jmid_set_tuning)
-static int g_gemm_ng = 0;         // N-tiles per L2 group (0 = auto)
-static int g_gemm_abl = 0;        // timing ablation bits of the 256x128 kernel (diagnostics)
-static int g_no_vt_direct = 0;    // 1: V row-major + v_transpose_kernel even when the fused V^T epilogue applies
 
 struct GemmHArgs {
     const half_t *Ahi, *Alo;  // [M, K] in the blocked panel layout (common.hpp::blk_index), rows padded to 128
@@ -323,11 +319,10 @@ inline hipError_t launch_gemm_h_cfg(const GemmHArgs& g, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
     size_t lds = gemm_h_lds_bytes<WM, WN>();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<WM, WN, EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f16x3_kernel<WM, WN, EPI, OUT, X2>), grid, dim3(256), lds, st, g);
     return hipGetLastError();
@@ -444,11 +439,10 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 127) / 128, ntn = (g.N + 127) / 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f16x3_dma_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(256), DMA_LDS_BYTES, st, g, ntm, ntn);
     return hipGetLastError();
@@ -568,14 +562,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 255) / 256, ntn = (g.N + 127) / 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA2_LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f16x3_dma256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA2_LDS_BYTES, st, g, ntm, ntn,
-                       g_gemm_ng, g_gemm_abl);
+                       tune().gemm_ng, gemm_abl_bits());
     return hipGetLastError();
 }
 
@@ -699,13 +692,12 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
-        attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (g_gemm_abl & 8) ? 0 : 1);
+    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (gemm_abl_bits() & 8) ? 0 : 1);
     return hipGetLastError();
 }
 
@@ -783,11 +775,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma64(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 63) / 64, ntn = (g.N + 63) / 64;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma64_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA64_LDS_BYTES);
-        attr_set = true;
     }
     hipLaunchKernelGGL((gemm_f16x3_dma64_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(256), DMA64_LDS_BYTES, st, g, ntm, ntn);
     return hipGetLastError();
@@ -798,7 +789,7 @@ inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA,
     // 5 = 64x64 LDS-DMA, 6 = 256x256 LDS-DMA (N % 256 == 0)
-    const int v = g_gemm_h_variant;
+    const int v = tune().gemm_h_variant;
     if (v == 1) return launch_gemm_h_cfg<1, 1, EPI, OUT, X2>(g, st);
     if (v == 2) return launch_gemm_h_cfg<2, 2, EPI, OUT, X2>(g, st);
     if (v == 3) return launch_gemm_h_dma<EPI, OUT, X2>(g, st);

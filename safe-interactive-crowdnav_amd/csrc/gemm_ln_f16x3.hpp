@@ -27,7 +27,6 @@ constexpr size_t GLN_LDS_BYTES = size_t(GLN_A_OFF + 5 * GLN_A_STAGE) * sizeof(ha
 constexpr int GLN_TILE_LD = GLN_BN + 8;          // floats per row of the epilogue tile
 static_assert(size_t(GLN_BM) * GLN_TILE_LD * sizeof(float) <= GLN_LDS_BYTES, "epilogue tile must fit the ring");
 
-static int g_ln_fuse = 0;   // tuning knob: 0 auto, 1 always, 2 never (jmid_set_tuning "ln_fuse")
 
 struct GemmLnArgs {
     const half_t *Ahi, *Alo;      // [M, K] blocked panel layout (common.hpp::blk_index)
@@ -420,23 +419,21 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
     if (overflow) atomicOr(g.range_flag, 1);
 }
 
-static int g_ln_rows = 0;   // tuning knob "ln_rows": 0 auto (128-row tiles from 32768 tokens), 64, 128
 
 template <bool X2>
 inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_f16x3_kernel<X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_f16x3_kernel<X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN2_LDS_BYTES);
-        attr_set = true;
     }
     // row tile by how well the grid fills whole rounds of the 256 CUs (one workgroup per CU); at equal fill the
     // 128-row kernel is ~4 % faster (W streams through L2 -> LDS half as often)
     auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };
     const long n128 = (g.M + GLN2_BM - 1) / GLN2_BM, n64 = (g.M + GLN_BM - 1) / GLN_BM;
-    const bool rows128 = g_ln_rows == 128 || (g_ln_rows == 0 && 1.04 * fill(n128) >= fill(n64));
+    const bool rows128 = tune().ln_rows == 128 || (tune().ln_rows == 0 && 1.04 * fill(n128) >= fill(n64));
     if (rows128) {
         const int ntm = (g.M + GLN2_BM - 1) / GLN2_BM;
         hipLaunchKernelGGL(gemm_ln128_f16x3_kernel<X2>, dim3(ntm), dim3(512), GLN2_LDS_BYTES, st, g, ntm);

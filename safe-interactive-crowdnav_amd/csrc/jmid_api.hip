@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -72,6 +73,9 @@ struct jmid_ctx {
     // (not reproducible run to run; every kernel alone and every single-stream run is bit-reproducible; see
     // tools/concurrency_probe.hip and DESIGN.md) - opt-in until that is understood.
     int lanes = 1;
+    Tuning tune;         // jmid_set_tuning knobs of THIS handle (installed per call by TuneScope)
+    hipStream_t caller_stream = nullptr;   // stream device-mode buffers are ordered on (jmid_set_caller_stream)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
@@ -264,7 +268,6 @@ int upload_time_table(jmid_ctx* h) {
     return dev_alloc_copy(h, &h->thyp, t);
 }
 
-static int g_fuse_embed = 1;   // tuning knob "fuse_embed": the output kernel of step i embeds x for step i + 1
 
 // ---------------------------------------------------------------------------------------------- launch helpers
 template <int EPI>
@@ -330,7 +333,8 @@ SeqGeom seq_geom(const jmid_ctx* h, int Ec, int A, int K, int T) {
     return g;
 }
 
-size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom& sg, StepBuffers* sb, char* base) {
+size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom& sg, int nsplit, StepBuffers* sb,
+                      char* base) {
     Carver c(base);
     StepBuffers s{};
     s.X = c.take(Mc * h->d);
@@ -354,11 +358,7 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
             s.vt_elems = (size_t)sg.nseq * h->d * sg.Spad;
             s.Vth = take_half(c, s.vt_elems);
             s.Vtl = take_half(c, s.vt_elems);
-            s.attn_nsplit = 1;
-            if (h->d / h->nhead == 128) {
-                const int base_blocks = ((sg.S + 127) / 128) * h->nhead * sg.nseq;
-                s.attn_nsplit = attn_pick_nsplit(base_blocks, sg.S);
-            }
+            s.attn_nsplit = nsplit;
             if (s.attn_nsplit > 1) {
                 s.Opart = c.take((size_t)s.attn_nsplit * Mc * h->d);
                 s.MLpart = c.take((size_t)s.attn_nsplit * Mc * h->nhead * 2);
@@ -456,7 +456,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
             if (joint) {
                 // S % 4 == 0: the QKV epilogue writes V^T itself; otherwise V row-major + v_transpose_kernel
-                const bool vt_direct = (S % 4 == 0) && !g_no_vt_direct;
+                const bool vt_direct = (S % 4 == 0) && !tune().no_vt_direct;
                 g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl;
                 g.Vthi = vt_direct ? sb.Vth : sb.Vh; g.Vtlo = vt_direct ? sb.Vtl : sb.Vl; g.vt_direct = vt_direct;
                 g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad; g.qscale = att_scale * 1.4426950408889634f;
@@ -468,9 +468,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                     HIPCHK(h, hipGetLastError());
                 }
                 ProfScope ps(h, KC_ATTN);
-                int ns = 1;
-                if (hd == 128) ns = attn_pick_nsplit(((S + 127) / 128) * h->nhead * nseq, S);
-                if (ns > sb.attn_nsplit) ns = sb.attn_nsplit;   // workspace was sized for the full chunk
+                const int ns = sb.attn_nsplit;   // per call, not per chunk (run_network)
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
                              att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2};
                 HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
@@ -483,7 +481,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             }
             // row-complete GEMM with residual + LayerNorm fused in (gemm_ln_f16x3.hpp) from 8192 tokens
             // (enough row tiles to occupy the chip); otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
-            const bool ln_fused = d == GLN_BN && g_ln_fuse != 2 && (g_ln_fuse == 1 || M >= 8192);
+            const bool ln_fused = d == GLN_BN && tune().ln_fuse != 2 && (tune().ln_fuse == 1 || M >= 8192);
             if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".self_attn.out_proj.weight"];
                 GemmLnArgs gl{sb.Ah, sb.Al, w16.hi, w16.lo, W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"),
@@ -556,12 +554,11 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     return 0;
 }
 
-int pick_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
-    if (h->chunk_eps > 0) return std::min(E, h->chunk_eps);
-    // Episodes per pass of the 50-step loop.  Large enough to fill the chip several times over per launch, and -
-    // for JMID - a whole number of "rounds" of the attention launch: that kernel runs 2 workgroups per CU (512
-    // slots) and one episode contributes nhead * ceil(S/128) workgroups, so a chunk of floor(k*512 / that) episodes
-    // leaves no partially filled last round (20 -> 51 episodes: +15 % attention throughput on BASELINE cfg3).
+// Episodes per pass of the 50-step loop when nothing is forced: large enough to fill the chip several times over per
+// launch, and - for JMID - a whole number of "rounds" of the attention launch: that kernel runs 2 workgroups per CU
+// (512 slots) and one episode contributes nhead * ceil(S/128) workgroups, so a chunk of floor(k*512 / that) episodes
+// leaves no partially filled last round (20 -> 51 episodes: +15 % attention throughput on BASELINE cfg3).
+int auto_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
     const long max_tokens = 65536;
     if (h->net_kind == JMID_NET_JMID) {
         const long bpe = (long)h->nhead * ((tokens_per_episode + 127) / 128);
@@ -573,6 +570,39 @@ int pick_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
     long c = max_tokens / std::max(1, tokens_per_episode);
     if (c < 1) c = 1;
     return (int)std::min<long>(c, E);
+}
+
+// The chunks of a call: `c` episodes each (jmid_set_chunk_episodes, or auto_chunk).  A short ragged tail (less than a
+// quarter of a chunk, e.g. 256 = 5 x 51 + 1) would run all 50 steps at single-scene latency, so it is spread over the
+// full chunks instead (52 + 4 x 51) - only with the automatic size: a forced size is taken literally.
+std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
+    const int c = h->chunk_eps > 0 ? std::min(E, h->chunk_eps) : auto_chunk(h, E, tokens_per_episode);
+    std::vector<int> sizes(E / c, c);
+    const int tail = E % c;
+    if (tail) {
+        if (h->chunk_eps > 0 || sizes.empty() || tail * 4 >= c || (tail + sizes.size() - 1) / sizes.size() > (size_t)c / 8)
+            sizes.push_back(tail);
+        else
+            for (int i = 0; i < tail; ++i) sizes[i % sizes.size()] += 1;
+    }
+    return sizes;
+}
+
+// Device-mode calls read and write the caller's buffers on the handle's private stream.  They are ordered against
+// the stream the caller works on (jmid_set_caller_stream; default: the legacy null stream): the handle's stream waits
+// for everything the caller enqueued before the call, and the caller's stream waits for the call's last kernel, so
+// neither a producer kernel of an input nor a consumer (or the allocator's reuse) of an output can race with it.
+int order_in(jmid_ctx* h, int mem) {
+    if (mem != JMID_MEM_DEVICE) return 0;
+    HIPCHK(h, hipEventRecord(h->ev_in, h->caller_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in, 0));
+    return 0;
+}
+int order_out(jmid_ctx* h, int mem) {
+    if (mem != JMID_MEM_DEVICE) return 0;
+    HIPCHK(h, hipEventRecord(h->ev_out, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->caller_stream, h->ev_out, 0));
+    return 0;
 }
 
 int check_ready(jmid_ctx* h) {
@@ -598,9 +628,22 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     if (single_step < 0 && h->ddpm && !z_in) return fail(h, JMID_EINVAL, "DDPM table installed: use jmid_denoise_ddpm (needs z)");
     if (single_step < 0 && !h->ddpm && z_in) return fail(h, JMID_EINVAL, "jmid_denoise_ddpm needs jmid_set_ddpm_table");
     HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
+    if (int rc = order_in(h, mem)) return rc;
     const size_t R = (size_t)E * K * A, M = R * T, EA = (size_t)E * A;
-    const int Ec = pick_chunk(h, E, K * A * T);
+    const std::vector<int> chunk_sizes = plan_chunks(h, E, K * A * T);
+    std::vector<int> chunk_start(chunk_sizes.size(), 0);
+    for (size_t i = 1; i < chunk_sizes.size(); ++i) chunk_start[i] = chunk_start[i - 1] + chunk_sizes[i - 1];
+    const int Ec = *std::max_element(chunk_sizes.begin(), chunk_sizes.end());
     const size_t Mc = (size_t)Ec * K * A * T;
+    // Split-KV factor of the attention launches: chosen ONCE per call from the automatic chunk size, never from the
+    // chunk at hand - a ragged last chunk or a forced chunk size must not change the order in which a sequence's keys
+    // are summed (results are bit-identical for every chunking of the same call).
+    int ns_call = 1;
+    if (h->net_kind == JMID_NET_JMID && precision != JMID_PREC_F32 && h->d / h->nhead == 128) {
+        const int S = K * A * T;
+        ns_call = attn_pick_nsplit(((S + 127) / 128) * h->nhead * auto_chunk(h, E, S), S);
+    }
     // ---- workspace
     size_t io_off;
     {
@@ -617,9 +660,9 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     // Independent chunks run `lanes` at a time on separate streams: the partially filled last round of one chunk's
     // kernels and its bandwidth-bound kernels overlap with another chunk's MFMA kernels.  Each lane has its own step
     // workspace; results do not depend on the number of lanes.
-    const int nchunks = (E + Ec - 1) / Ec;
+    const int nchunks = (int)chunk_sizes.size();
     const int lanes = single_step < 0 ? std::max(1, std::min(h->lanes, nchunks)) : 1;
-    const size_t lane_floats = step_ws_floats(h, Mc, precision, sg_full, nullptr, nullptr);
+    const size_t lane_floats = step_ws_floats(h, Mc, precision, sg_full, ns_call, nullptr, nullptr);
     const size_t need = io_off + lanes * lane_floats;
     if (int rc = ensure_arena(h, need)) return rc;
     Carver c(h->arena);
@@ -635,7 +678,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         z_use = zd;
     }
     StepBuffers sbs[jmid_ctx::kMaxLanes];
-    for (int l = 0; l < lanes; ++l) step_ws_floats(h, Mc, precision, sg_full, &sbs[l], h->arena + io_off + l * lane_floats);
+    for (int l = 0; l < lanes; ++l) step_ws_floats(h, Mc, precision, sg_full, ns_call, &sbs[l], h->arena + io_off + l * lane_floats);
     const StepBuffers& sb = sbs[0];
     if (precision != JMID_PREC_F32) {
         HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
@@ -671,9 +714,9 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         for (int l = 1; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l - 1], h->ev_fork, 0));
     }
-    for (int e0 = 0; e0 < E; e0 += lanes * Ec) {
+    for (int c0 = 0; c0 < nchunks; c0 += lanes) {
         if (single_step >= 0) {
-            const int ec = std::min(Ec, E - e0);
+            const int e0 = chunk_start[c0], ec = chunk_sizes[c0];
             float* eo = stage + (size_t)e0 * K * A * T * 2;
             if (int rc = net_step(h, sb, ec, A, K, T, single_step, x_cur + (size_t)e0 * K * A * T * 2,
                                   hyp + (size_t)e0 * A * h->hl.total, eo, precision))
@@ -683,15 +726,14 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         // the steps of the chunks of this round are enqueued alternately so that all queues stay fed
         for (int i = 0; i < n_steps; ++i) {
             for (int l = 0; l < lanes; ++l) {
-                const int el = e0 + l * Ec;
-                if (el >= E) break;
-                const int ec = std::min(Ec, E - el);
+                if (c0 + l >= nchunks) break;
+                const int el = chunk_start[c0 + l], ec = chunk_sizes[c0 + l];
                 float* xc = x_cur + (size_t)el * K * A * T * 2;
                 const float* hc = hyp + (size_t)el * A * h->hl.total;
                 const float* zc = z_use ? z_use + ((size_t)i * M + (size_t)el * K * A * T) * 2 : nullptr;
                 if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);   // net_step launches on h->stream
-                const int rc = net_step(h, sbs[l], ec, A, K, T, i, xc, hc, nullptr, precision, zc, g_fuse_embed && i > 0,
-                                        g_fuse_embed && i + 1 < n_steps ? i + 1 : -1);
+                const int rc = net_step(h, sbs[l], ec, A, K, T, i, xc, hc, nullptr, precision, zc, tune().fuse_embed && i > 0,
+                                        tune().fuse_embed && i + 1 < n_steps ? i + 1 : -1);
                 if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);
                 if (rc) return rc;
             }
@@ -716,6 +758,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
             HIPCHK(h, hipMemcpyAsync(pos_out, stage, M * 2 * sizeof(float), kout, h->stream));
         }
     }
+    if (int rc = order_out(h, mem)) return rc;
     if (precision != JMID_PREC_F32) {
         // an activation outside the fp16 range poisons the split operands: report it instead of returning garbage
         int flag = 0;
@@ -775,7 +818,9 @@ int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, in
     h->hl = make_hyper_layout(h->d, h->dmid, h->dlow);
     register_shapes(h);
     bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&h->stream) == hipSuccess &&
-              hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; ok && l < jmid_ctx::kMaxLanes - 1; ++l)
         ok = hipStreamCreate(&h->lane_stream[l]) == hipSuccess &&
              hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) == hipSuccess;
@@ -792,11 +837,14 @@ int jmid_destroy(jmid_handle_t h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (auto& kv : h->w) hipFree(kv.second.p);
-    for (auto& kv : h->wsplit) {
-        hipFree(kv.second.hi);
-        hipFree(kv.second.lo);
-    }
+    for (auto* m : {&h->wsplit, &h->w16})
+        for (auto& kv : *m) {
+            hipFree(kv.second.hi);
+            hipFree(kv.second.lo);
+        }
     if (h->range_flag) hipFree(h->range_flag);
+    if (h->ev_in) hipEventDestroy(h->ev_in);
+    if (h->ev_out) hipEventDestroy(h->ev_out);
     for (float* p : {h->pe, h->Whyp, h->bhyp, h->thyp, h->attW1T, h->attW2T})
         if (p) hipFree(p);
     for (auto& l : h->lstmT)
@@ -1041,6 +1089,8 @@ int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* n
     if (!h->finalized) return fail(h, JMID_ENOWEIGHT, "jmid_finalize_weights has not been called");
     if (n_agents <= 0 || !x_st || !nbr_sum || !edge_mask || !ctx_out) return fail(h, JMID_EINVAL, "bad argument");
     HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
+    if (int rc = order_in(h, mem)) return rc;
     const int Th = h->hist_len, H = h->H;
     const size_t n = n_agents;
     const float *xs = x_st, *ns = nbr_sum, *em = edge_mask;
@@ -1075,7 +1125,7 @@ int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* n
         HIPCHK(h, hipMemcpyAsync(ctx_out, co, n * 2 * H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    return JMID_OK;
+    return order_out(h, mem);
 }
 
 int jmid_denoise(jmid_handle_t h, int E, int A, int K, int T, const float* x_T, const float* ctx, const float* p0,
@@ -1097,6 +1147,8 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
                          float* out, int mem) {
     if (!h || !pos || !gt || !out || E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "bad argument");
     HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
+    if (int rc = order_in(h, mem)) return rc;
     const size_t np_ = (size_t)E * K * A * T * 2, ng = (size_t)E * A * T * 2;
     const float *dp = pos, *dg = gt;
     float* dout = out;
@@ -1121,7 +1173,7 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
         HIPCHK(h, hipMemcpyAsync(out, dout, (size_t)E * 4 * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
-    return JMID_OK;
+    return order_out(h, mem);
 }
 
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
@@ -1133,9 +1185,32 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     if (!h || !key) return JMID_EINVAL;
     const std::string k(key);
-    if (k == "gemm_h_variant") {
-        if (value < 0 || value > 6) return fail(h, JMID_EINVAL, "gemm_h_variant must be 0..6");
-        g_gemm_h_variant = value;
+    struct Knob {
+        const char* name;
+        int Tuning::*field;
+        int lo, hi;
+    };
+    // every knob belongs to the handle (h->tune); none is process-wide
+    static const Knob knobs[] = {
+        {"gemm_h_variant", &Tuning::gemm_h_variant, 0, 6},     // 0 auto, 1..6 force a tile variant of the split GEMM
+        {"attn_pack", &Tuning::attn_pack, 0, 1},               // 0: one short sequence per wave, 1: packed (iMID)
+        {"fuse_embed", &Tuning::fuse_embed, 0, 1},             // 0: separate embed_kernel at the start of every step
+        {"bystander_lds", &Tuning::bystander_lds, 0, 160 * 1024},   // unused dynamic LDS requested by row-wise kernels
+        {"ln_rows", &Tuning::ln_rows, 0, 128},                 // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
+        {"ln_fuse", &Tuning::ln_fuse, 0, 2},                   // 0 auto (M >= 8192 tokens), 1 always, 2 never
+        {"no_vt_direct", &Tuning::no_vt_direct, 0, 1},         // 1: always V row-major + v_transpose_kernel
+        {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
+        {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
+        {"persist", &Tuning::persist, 0, 2},                   // small-M persistent step kernel: 0 auto, 1 always, 2 never
+        {"ff_fuse", &Tuning::ff_fuse, 0, 2},                   // fused linear1 -> linear2 + LayerNorm: 0 auto, 1 always, 2 never
+#ifdef JMID_ABLATIONS
+        {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
+        {"gemm_abl", &Tuning::gemm_abl, 0, 1 << 30},
+#endif
+    };
+    if (k == "lanes") {     // chunks of the denoise loop in flight at once: 1..4
+        if (value < 1 || value > jmid_ctx::kMaxLanes) return fail(h, JMID_EINVAL, "lanes must be 1..4");
+        h->lanes = value;
         return JMID_OK;
     }
     if (k == "print_occupancy") {   // diagnostics: resident workgroups per CU of the main kernels
@@ -1151,56 +1226,20 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         fprintf(stderr, "attn_f32_kernel<128,4>: %d workgroups/CU\n", n);
         return JMID_OK;
     }
-    if (k == "attn_pack") {   // 0: one short sequence per wave (old path), 1: packed short-sequence attention
-        g_attn_pack = value;
-        return JMID_OK;
-    }
-    if (k == "lanes") {     // chunks of the denoise loop in flight at once: 1..4
-        if (value < 1 || value > jmid_ctx::kMaxLanes) return fail(h, JMID_EINVAL, "lanes must be 1..4");
-        h->lanes = value;
-        return JMID_OK;
-    }
-    if (k == "fuse_embed") {    // 0: separate embed_kernel at the start of every step (A/B of the fused output kernel)
-        g_fuse_embed = value != 0;
-        return JMID_OK;
-    }
-    if (k == "bystander_lds") {   // bytes of unused dynamic LDS requested by the row-wise kernels (0..163840)
-        if (value < 0 || value > 160 * 1024) return fail(h, JMID_EINVAL, "bystander_lds must be 0..163840");
-        g_bystander_lds = value;
-        return JMID_OK;
-    }
-    if (k == "ln_rows") {   // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
-        if (value != 0 && value != 64 && value != 128) return fail(h, JMID_EINVAL, "ln_rows must be 0, 64 or 128");
-        g_ln_rows = value;
-        return JMID_OK;
-    }
-    if (k == "ln_fuse") {   // 0 auto (M >= 16384 tokens), 1 always, 2 never: fused GEMM + residual + LayerNorm
-        if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "ln_fuse must be 0..2");
-        g_ln_fuse = value;
-        return JMID_OK;
-    }
-    if (k == "no_vt_direct") {   // 1: always V row-major + v_transpose_kernel (A/B of the fused V^T epilogue)
-        g_no_vt_direct = value;
-        return JMID_OK;
-    }
-    if (k == "attn_abl") {     // timing ablations of the attention kernel (results are WRONG; tools/attn_abl.py)
-        g_attn_abl = value;
-        return JMID_OK;
-    }
-    if (k == "gemm_abl") {
-        g_gemm_abl = value;
-        return JMID_OK;
-    }
-    if (k == "gemm_ng") {      // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
-        g_gemm_ng = value;
-        return JMID_OK;
-    }
-    if (k == "attn_h_variant") {
-        if (value < 0 || value > 2) return fail(h, JMID_EINVAL, "attn_h_variant must be 0..2");
-        g_attn_h_variant = value;
-        return JMID_OK;
-    }
+    for (const Knob& kn : knobs)
+        if (k == kn.name) {
+            if (value < kn.lo || value > kn.hi || (k == "ln_rows" && value != 0 && value != 64 && value != 128))
+                return fail(h, JMID_EINVAL, k + " out of range");
+            h->tune.*(kn.field) = value;
+            return JMID_OK;
+        }
     return fail(h, JMID_EINVAL, "unknown tuning key " + k);
+}
+
+int jmid_set_caller_stream(jmid_handle_t h, void* stream) {
+    if (!h) return JMID_EINVAL;
+    h->caller_stream = reinterpret_cast<hipStream_t>(stream);
+    return JMID_OK;
 }
 
 int jmid_profile_enable(jmid_handle_t h, uint32_t class_mask) {
@@ -1263,6 +1302,7 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
         return fail(h, JMID_EINVAL, "bad precision");
     h->x2 = precision == JMID_PREC_F16X2;
     HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
         HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
@@ -1318,6 +1358,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
         return fail(h, JMID_EINVAL, "bad precision");
     h->x2 = precision == JMID_PREC_F16X2;
     HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
         HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
@@ -1379,6 +1420,7 @@ int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float*
                            const float* beta) {
     if (!h || !X || !Y || !gamma || !beta) return JMID_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
     float *dX, *dY, *dG, *dB;
     HIPCHK(h, hipMalloc((void**)&dX, (size_t)M * d * 4));
     HIPCHK(h, hipMalloc((void**)&dY, (size_t)M * d * 4));

@@ -55,6 +55,7 @@ class JmidEngine:
         self.dims = weights.dims
         self.joint = bool(joint)
         self.device_id = device_id
+        self._caller_stream = 0          # NULL: the legacy default stream
         self.hist_len = hist_len
         rc = self._lib.jmid_create(C.byref(self._h), device_id, _lib.NET_JMID if joint else _lib.NET_IMID,
                                    self.dims.ctx_dim, self.dims.tf_layer, self.dims.nhead, hist_len)
@@ -109,6 +110,16 @@ class JmidEngine:
     def set_tuning(self, key: str, value: int) -> None:
         self._check(self._lib.jmid_set_tuning(self._h, key.encode(), int(value)))
 
+    def _mem(self, dev: bool) -> int:
+        """Memory mode of a call; device-mode calls are ordered against torch's CURRENT stream (include/jmid_hip.h)."""
+        if not dev:
+            return _lib.MEM_HOST
+        st = int(torch.cuda.current_stream(self.device_id).cuda_stream)
+        if st != self._caller_stream:
+            self._check(self._lib.jmid_set_caller_stream(self._h, C.c_void_p(st)))
+            self._caller_stream = st
+        return _lib.MEM_DEVICE
+
     def synchronize(self) -> None:
         self._check(self._lib.jmid_synchronize(self._h))
 
@@ -128,7 +139,7 @@ class JmidEngine:
             out = np.empty((n, self.dims.ctx_dim), dtype=np.float32)
             optr = C.c_void_p(out.ctypes.data)
         self._check(self._lib.jmid_encode(self._h, n, a.ptr, b.ptr, c.ptr, optr,
-                                          _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+                                          self._mem(dev)))
         return out
 
     def _shapes(self, x, ctx) -> Tuple[int, int, int, int]:
@@ -167,11 +178,11 @@ class JmidEngine:
             bz = _Buf(z, dev)
             self._check(self._lib.jmid_denoise_ddpm(self._h, E, A, K, T, bx.ptr, bz.ptr, bc.ptr, bp.ptr if bp else None,
                                                     float(dt), _lib.PRECISIONS[precision], vptr, pptr,
-                                                    _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+                                                    self._mem(dev)))
         else:
             self._check(self._lib.jmid_denoise(self._h, E, A, K, T, bx.ptr, bc.ptr, bp.ptr if bp else None, float(dt),
                                                _lib.PRECISIONS[precision], vptr, pptr,
-                                               _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+                                               self._mem(dev)))
         return vel, pos
 
     def net_eval(self, x: ArrayLike, ctx: ArrayLike, step_idx: int = 0, precision: str = "f32"):
@@ -187,7 +198,7 @@ class JmidEngine:
             optr = C.c_void_p(out.ctypes.data)
         self._check(self._lib.jmid_net_eval(self._h, E, A, K, T, int(step_idx), bx.ptr, bc.ptr,
                                             _lib.PRECISIONS[precision], optr,
-                                            _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+                                            self._mem(dev)))
         return out
 
     def episode_metrics(self, pos: ArrayLike, gt: ArrayLike) -> ArrayLike:
@@ -204,7 +215,7 @@ class JmidEngine:
             out = np.empty((E, 4), dtype=np.float32)
             optr = C.c_void_p(out.ctypes.data)
         self._check(self._lib.jmid_episode_metrics(self._h, E, A, K, T, bp.ptr, bg.ptr, optr,
-                                                   _lib.MEM_DEVICE if dev else _lib.MEM_HOST))
+                                                   self._mem(dev)))
         return out
 
     # ------------------------------------------------------------------ measurement

@@ -16,9 +16,18 @@ Arithmetic: the contractions run in the library's F16X3 mode (fp16 hi/lo split o
 measured ADE vs the reference as exact fp32); if an activation ever leaves the fp16 range the call is repeated
 transparently in the exact-fp32 MFMA mode.
 
+RNG contract (``rng_compat``): ``x_T`` is always the first draw of torch's CPU default generator
+(``MID/models/diffusion.py:499``).  The reference also draws one (unused, DDIM) ``randn_like(x_T)`` per reverse step
+(``:509``) on the device ``x_T`` was moved to: the CPU generator in a CPU-only run (what the golden captures are),
+the CUDA generator on a GPU host (``MID/mid.py:91``).  ``rng_compat="cpu"`` consumes those draws from the CPU
+generator, ``"cuda"`` from the device generator (the CPU generator then advances by ``x_T`` only), and the default
+``"auto"`` does what the reference itself would do on this host (``"cuda"`` iff ``torch.cuda.is_available()``).
+
 Differences from the reference that a caller can observe:
   * the engine (weights on the GPU) is cached across instances: the reference rebuilds the model and reloads the
-    checkpoint at the start of every episode (``sicnav_acados.py:1171``);
+    checkpoint at the start of every episode (``sicnav_acados.py:1171``); the cache key holds the checkpoint file's
+    identity (path, size, mtime) or the weight checksum (computed once per ``JMIDWeights`` object), the engine is
+    one per (weights, net, device, history length, step size) and calls on it are serialised by a lock;
   * ``model_path`` may point to the neutral ``.npz`` written by ``export_checkpoint`` instead of the pickled
     ``nn.ModuleDict`` container (which needs the reference tree on ``sys.path`` to unpickle);
   * a too-short history raises ``HistoryTooShortError`` (a ``TypeError``, like the reference's failure mode).
@@ -27,7 +36,7 @@ from __future__ import annotations
 
 import configparser
 import os
-from threading import Lock
+from threading import Lock, RLock
 from typing import Dict, Optional, Tuple
 
 import numpy as np
@@ -40,6 +49,8 @@ from .kde import most_likely_samples
 from .weights import JMIDWeights, NetDims
 
 _ENGINE_CACHE: Dict[tuple, JmidEngine] = {}
+_ENGINE_LOCKS: Dict[int, RLock] = {}
+_WEIGHTS_CACHE: Dict[tuple, JMIDWeights] = {}     # (path, size, mtime_ns, dims) -> weights (re-created every episode)
 
 
 def load_weights(model_path: str, dims: NetDims) -> JMIDWeights:
@@ -50,13 +61,19 @@ def load_weights(model_path: str, dims: NetDims) -> JMIDWeights:
     for p in cand:
         if not os.path.exists(p):
             continue
+        st = os.stat(p)
+        key = (os.path.abspath(p), st.st_size, st.st_mtime_ns, dims)
+        if key in _WEIGHTS_CACHE:
+            return _WEIGHTS_CACHE[key]
         if p.endswith(".npz"):
             w = JMIDWeights.load(p)
             if w.dims != dims:
                 raise ValueError(f"{p} holds dims {w.dims}, config asks for {dims}")
-            return w
-        ckpt = torch.load(p, map_location="cpu", weights_only=False)
-        return JMIDWeights.from_reference_state(dims, ckpt["ddpm"], ckpt["encoder"])
+        else:
+            ckpt = torch.load(p, map_location="cpu", weights_only=False)
+            w = JMIDWeights.from_reference_state(dims, ckpt["ddpm"], ckpt["encoder"])
+        _WEIGHTS_CACHE[key] = w
+        return w
     raise FileNotFoundError(f"no checkpoint at {model_path} (or its .npz export)")
 
 
@@ -65,10 +82,8 @@ class ForecasterSimSuper:
 
     def init_super(self, env_config):
         self.prev_states_lock = Lock()
-        if env_config is None:
-            env_config_file = "./src/human_traj_forecaster/configs/env_utias_vicon.config"
-            env_config = configparser.RawConfigParser()
-            env_config.read(env_config_file)
+        if env_config is None:     # the reference falls back to a config file that is not in its tree and then fails here
+            raise configparser.NoSectionError("human_trajectory_forecaster")
         self.publish_freq = env_config.getfloat("human_trajectory_forecaster", "publish_freq")
         self.time_step = env_config.getfloat("env", "time_step")
         assert (self.time_step * 100).is_integer(), \
@@ -99,9 +114,12 @@ class _ModelInfo:
 
 class HumanTrajectoryForecasterSim(ForecasterSimSuper):
     def __init__(self, env_config=None, mid_config_file=None, *, weights: Optional[JMIDWeights] = None,
-                 device_id: int = 0, precision: str = "f16x3"):
+                 device_id: int = 0, precision: str = "f16x3", rng_compat: str = "auto"):
         self.init_super(env_config)
         self.precision = precision
+        if rng_compat not in ("auto", "cpu", "cuda"):
+            raise ValueError("rng_compat must be 'auto', 'cpu' or 'cuda'")
+        self.rng_compat = rng_compat if rng_compat != "auto" else ("cuda" if torch.cuda.is_available() else "cpu")
         self._init_MID(mid_config_file, weights, device_id)
 
     def _init_MID(self, mid_config_file, weights, device_id):
@@ -122,13 +140,15 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
             raise ValueError("maximum_history_length must equal past_num_frames - 1")
         if weights is None:
             weights = load_weights(cfg["model_path"], dims)
-        key = (weights.checksum(), self.joint, device_id, self.num_hist_frames)
+        key = (weights.checksum(), self.joint, device_id, self.num_hist_frames, self.step_size)
         eng = _ENGINE_CACHE.get(key)
         if eng is None:
             eng = JmidEngine(weights, joint=self.joint, device_id=device_id, hist_len=self.num_hist_frames,
                              step=self.step_size)
             _ENGINE_CACHE[key] = eng
+            _ENGINE_LOCKS[id(eng)] = RLock()
         self.engine = eng
+        self._engine_lock = _ENGINE_LOCKS[id(eng)]
         self.mid_model = _ModelInfo(cfg, eng, self.num_samples)
         self.model = self.mid_model
 
@@ -143,24 +163,26 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
         hum_xy, rob_xy, pose_now = SC.frame_table(prev, rob, self.time_step, self.num_hist_frames)
         sb = SC.build_scene(hum_xy, rob_xy, self.time_step, self.predict_horizon, self.num_hist_frames)
         A, K, H, k = len(sb.ids_in), self.num_samples, self.predict_horizon, self.num_ret_samples
-        if self.engine.step != self.step_size or self.engine.sampling != "ddim":   # the engine is shared
-            self.engine.set_step(self.step_size, "ddim")       # eval_sicnav hard-codes sampling="ddim" (MID/mid.py:333)
-        ctx = self.engine.encode(sb.x_st, sb.nbr_sum, sb.edge_mask)
-        # RNG contract (MID/models/diffusion.py:499, 509): x_T is the first draw of the CPU default generator,
-        # and one (unused, DDIM) randn_like is drawn per step with t > 1
+        # RNG contract (module docstring): x_T is the first draw of the CPU default generator; the per-step z of the
+        # reference (unused by DDIM) comes from the generator of the device the reference would run on
         x_T = torch.randn([K * A, H, 2])
         stride = int(100 / self.step_size)
+        z_like = x_T if self.rng_compat == "cpu" else torch.empty_like(x_T, device=f"cuda:{self.engine.device_id}")
         for t in range(100, 0, -stride):
             if t > 1:
-                torch.randn_like(x_T)
-        try:
-            _, pos = self.engine.denoise(x_T.numpy()[None], ctx[None], sb.p0[None], dt=self.time_step,
-                                         precision=self.precision, want_vel=False)
-        except JmidError as e:
-            if e.code != -5 or self.precision == "f32":     # JMID_ERANGE: an operand left the fp16 range
-                raise
-            _, pos = self.engine.denoise(x_T.numpy()[None], ctx[None], sb.p0[None], dt=self.time_step,
-                                         precision="f32", want_vel=False)   # exact-fp32 MFMA path, same result
+                torch.randn_like(z_like)
+        with self._engine_lock:               # the engine is shared between forecaster instances and not re-entrant
+            if self.engine.step != self.step_size or self.engine.sampling != "ddim":
+                self.engine.set_step(self.step_size, "ddim")   # eval_sicnav hard-codes sampling="ddim" (MID/mid.py:333)
+            ctx = self.engine.encode(sb.x_st, sb.nbr_sum, sb.edge_mask)
+            try:
+                _, pos = self.engine.denoise(x_T.numpy()[None], ctx[None], sb.p0[None], dt=self.time_step,
+                                             precision=self.precision, want_vel=False)
+            except JmidError as e:
+                if e.code != -5 or self.precision == "f32":     # JMID_ERANGE: an operand left the fp16 range
+                    raise
+                _, pos = self.engine.denoise(x_T.numpy()[None], ctx[None], sb.p0[None], dt=self.time_step,
+                                             precision="f32", want_vel=False)   # exact-fp32 MFMA path, same result
         samples = pos[0]                                                  # [K, A, H, 2], agents by ascending id
         if k < K:
             in_cluster, logw_in = most_likely_samples(samples, k)        # [A, k, H, 2], [A, k]

@@ -195,13 +195,22 @@ class JMIDWeights:
 
     # ------------------------------------------------------------------ misc
     def checksum(self) -> str:
+        """SHA-256 over names and values; computed once per object (tensors are treated as immutable afterwards;
+        ``invalidate_checksum()`` after editing them in place)."""
         import hashlib
 
+        cached = getattr(self, "_checksum", None)
+        if cached is not None:
+            return cached
         hsh = hashlib.sha256()
         for k, v in self.tensors.items():
             hsh.update(k.encode())
             hsh.update(v.numpy().tobytes())
-        return hsh.hexdigest()
+        self._checksum = hsh.hexdigest()
+        return self._checksum
+
+    def invalidate_checksum(self) -> None:
+        self._checksum = None
 
     def net_state_dict(self) -> Dict[str, torch.Tensor]:
         return {k: v for k, v in self.tensors.items() if "/" not in k}

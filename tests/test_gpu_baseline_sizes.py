@@ -1,0 +1,116 @@
+"""Oracle parity AT the BASELINE.json sizes, on the kernels that carry the bench (width 256 -> head_dim 128: the
+LDS-DMA GEMM / attention kernels, fused GEMM + LayerNorm, split-KV attention + combine).
+
+  * cfg3: 256 episodes x N=5 x K=20 x H=12, 50 DDIM steps - at least one episode of EVERY chunk of the call is held
+    against the oracle (first / last episode of each chunk, incl. the one-episode tail a forced chunk of 51 leaves),
+    and the whole 256-episode result is bit-identical for every chunking (automatic 52+4x51, 51 -> 5x51+1, 17, 64).
+  * cfg4: one dense scene N=25, K=64 -> ONE attention sequence of 19 200 tokens (600 q-tile workgroups: the
+    efficiency branch of attn_pick_nsplit + attn_combine_kernel at 19 200 keys), 5 DDIM steps against the oracle.
+
+Reference: DiffusionTraj.sample_sicnav_inference (sicnav_diffusion/JMID/MID/models/diffusion.py:478-541) through
+oracle/jmid_oracle.py (pinned to the reference by tests/test_oracle_golden.py).  Gate: mean ADE <= 1e-4 m.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import jmid_oracle as O
+from safe_interactive_crowdnav_amd.engine import JmidEngine
+from safe_interactive_crowdnav_amd.scene import synthetic_episodes
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+
+ADE_GATE = 1e-4
+SPLIT_MODES = ["f16x3", "f16x2"]
+
+
+def ade(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64), axis=-1).mean())
+
+
+def _cpu_threads():
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+
+
+@pytest.fixture(scope="module")
+def cfg3():
+    """The bench's own cfg3 batch (bench.py: weights seed 0, synthetic_episodes seed 0, per-episode x_T seeds)."""
+    E, A, K, T = 256, 5, 20, 12
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=256), 0)
+    eng = JmidEngine(w, joint=True, step=50)
+    syn = synthetic_episodes(E, A, seed=0, horizon=T)
+    x_st = torch.from_numpy(syn["x_st"].reshape(E * A, 6, 6))
+    nbr = torch.from_numpy(syn["nbr_sum"].reshape(E * A, 2, 6, 6))
+    em = torch.from_numpy(syn["edge_mask"].reshape(E * A, 2))
+    p0 = torch.from_numpy(syn["p0"])
+    x_T = torch.stack([torch.randn([K * A, T, 2], generator=torch.Generator().manual_seed(e)) for e in range(E)])
+    ctx = eng.encode(x_st.cuda(), nbr.cuda(), em.cuda()).view(E, A, -1)
+    # one episode on each side of every chunk boundary of the automatic plan (52 + 4 x 51) and of the forced plan
+    # 5 x 51 + 1: every chunk of either plan holds at least one checked episode, the one-episode tail included
+    picks = [0, 50, 51, 52, 102, 103, 153, 154, 204, 205, 255]
+    _cpu_threads()
+    ref = {}
+    with torch.no_grad():
+        for e in picks:
+            c = O.encode_context(w.tensors, x_st[e * A:(e + 1) * A], nbr[e * A:(e + 1) * A], em[e * A:(e + 1) * A])
+            assert np.abs(c.numpy() - ctx[e].cpu().numpy()).max() < 1e-5
+            v = O.denoise(w.tensors, c, x_T[e], sample=K, step=50, joint=True)
+            ref[e] = O.integrate(v, p0[e], 0.25).numpy()
+    yield dict(eng=eng, ctx=ctx, x_T=x_T.cuda(), p0=p0.cuda(), ref=ref, picks=picks, dims=(E, A, K, T))
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", SPLIT_MODES)
+def test_cfg3_every_chunk_matches_oracle_and_chunking_is_bit_invariant(cfg3, precision):
+    eng, picks = cfg3["eng"], cfg3["picks"]
+    outs = {}
+    try:
+        for chunk in (0, 51, 17, 64):        # 52 + 4 x 51 | 5 x 51 + 1 (one-episode tail) | 15 x 17 + 1 | 4 x 64
+            eng.set_chunk_episodes(chunk)
+            _, pos = eng.denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision=precision, want_vel=False)
+            outs[chunk] = pos.cpu().numpy()
+    finally:
+        eng.set_chunk_episodes(0)
+    for chunk, pos in outs.items():
+        per = {e: ade(pos[e], cfg3["ref"][e]) for e in picks}
+        print(f"cfg3 [{precision}] chunk={chunk}: worst episode ADE vs oracle = {max(per.values()):.3e}")
+        assert max(per.values()) <= ADE_GATE, (chunk, per)
+    for chunk in (51, 17, 64):
+        np.testing.assert_array_equal(outs[chunk], outs[0])     # no chunking moves a single bit
+
+
+def test_cfg3_exact_fp32_mode_matches_oracle_at_full_size(cfg3):
+    _, pos = cfg3["eng"].denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision="f32", want_vel=False)
+    pos = pos.cpu().numpy()
+    per = {e: ade(pos[e], cfg3["ref"][e]) for e in cfg3["picks"]}
+    print(f"cfg3 [f32]: worst episode ADE vs oracle = {max(per.values()):.3e}")
+    assert max(per.values()) <= 1e-5, per
+
+
+@pytest.fixture(scope="module")
+def cfg4():
+    E, A, K, T, step = 1, 25, 64, 12, 5
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=256), 23)
+    g = torch.Generator().manual_seed(11)
+    ctx = torch.randn([E, A, 256], generator=g)
+    x_T = torch.randn([E, K * A, T, 2], generator=g)
+    _cpu_threads()
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx, x_T, sample=K, step=step, joint=True).numpy()
+    eng = JmidEngine(w, joint=True, step=step)
+    yield dict(eng=eng, ctx=ctx, x_T=x_T, ref=ref)
+    eng.close()
+
+
+@pytest.mark.parametrize("precision", ["f32"] + SPLIT_MODES)
+def test_cfg4_full_geometry_matches_oracle(cfg4, precision):
+    """N=25, K=64, H=12: S = 19 200 keys in one sequence (BASELINE configs[3]), split-KV + combine in the split modes."""
+    vel, _ = cfg4["eng"].denoise(cfg4["x_T"].cuda(), cfg4["ctx"].cuda(), precision=precision, want_pos=False)
+    a = ade(vel.cpu().numpy(), cfg4["ref"])
+    print(f"cfg4 full geometry [{precision}] mean ADE vs oracle = {a:.3e}")
+    assert a <= ADE_GATE
+    vel2, _ = cfg4["eng"].denoise(cfg4["x_T"].cuda(), cfg4["ctx"].cuda(), precision=precision, want_pos=False)
+    assert torch.equal(vel, vel2)            # rerun determinism of the split-KV path

@@ -29,7 +29,7 @@ def test_predict_ret_best_matches_reference(case, tmp_path):
                                k_ret=k_ret, H=H, step=int(z["step"]))
     w = JMIDWeights.from_seed(NetDims(ctx_dim=int(z["ctx_dim"])), int(z["wseed"]))
     assert w.checksum() == str(z["wsum"])
-    f = HumanTrajectoryForecasterSim(env, ypath, weights=w)
+    f = HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="cpu")   # the captures are CPU-reference runs
     assert f.num_hist_frames == int(z["past"])
     for r, h, t in zip(z["robot_xy"], z["human_xy"], z["stamps"]):
         f.update_state_hists(State(r), [State(p) for p in h], float(t))
@@ -60,7 +60,7 @@ def test_predict_ret_best_matches_reference(case, tmp_path):
         assert dist.min(axis=1).max() <= 1e-4
         np.testing.assert_allclose(np.sort(logw, axis=1), np.sort(z["logw"], axis=1), rtol=0, atol=1e-3)
         np.testing.assert_allclose(forecasts[:, :, 0, :], z["forecasts"][:, :, 0, :], rtol=0, atol=0)
-    # RNG contract: the global CPU generator is left where the reference leaves it
+    # RNG contract: the global CPU generator is left where the (CPU-only) reference leaves it
     torch.manual_seed(int(z["dseed"]))
     A = len(z["node_ids"])
     x_T = torch.randn([K * A, H, 2])
@@ -70,6 +70,35 @@ def test_predict_ret_best_matches_reference(case, tmp_path):
     torch.manual_seed(int(z["dseed"]))
     f.predict_ret_best()
     assert torch.equal(torch.randn(4), expect_next)
+
+
+def test_rng_compat_cuda_leaves_the_cpu_generator_after_x_T(tmp_path):
+    """On a GPU host the reference draws its per-step z on the device x_T was moved to (MID/models/diffusion.py:499-509,
+    MID/mid.py:91): the CPU generator advances by x_T only.  rng_compat="cuda" (and "auto" here) reproduces that; the
+    forecasts depend on x_T alone, so they equal the rng_compat="cpu" ones."""
+    z = np.load(os.path.join(GOLDEN, "wrapper_jmid_w32_spread50.npz"))
+    N, K, H = int(z["N"]), int(z["K"]), int(z["H"])
+    env, ypath = write_configs(str(tmp_path), joint=True, ctx_dim=32, N=N, K=K, k_ret=int(z["k_ret"]), H=H, step=2)
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=32), int(z["wseed"]))
+    outs = {}
+    for mode in ("cpu", "cuda", "auto"):
+        f = HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat=mode)
+        assert f.rng_compat == ("cuda" if mode == "auto" else mode)
+        for r, h, t in zip(z["robot_xy"], z["human_xy"], z["stamps"]):
+            f.update_state_hists(State(r), [State(p) for p in h], float(t))
+        torch.manual_seed(7)
+        outs[mode] = f.predict_ret_best()[0]
+        after = torch.randn(4)
+        torch.manual_seed(7)
+        x_T = torch.randn([K * len(z["node_ids"]), H, 2])
+        if mode == "cpu":
+            for _ in range(2):
+                torch.randn_like(x_T)
+        assert torch.equal(torch.randn(4), after), mode
+    np.testing.assert_array_equal(outs["cpu"], outs["cuda"])
+    np.testing.assert_array_equal(outs["cpu"], outs["auto"])
+    with pytest.raises(ValueError):
+        HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="numpy")
 
 
 def test_returned_arrays_are_fresh(tmp_path):
