@@ -7,14 +7,22 @@
 
 A "step" is ONE full predictor pass over one batch of synthetic scenes already resident in HBM:
 context encoder -> 50-step batched DDIM reverse-denoising loop -> integrator -> per-episode metrics
-(+ one RCCL gather of the metrics when N > 1).  Episodes are independent and shard across ranks
-(weak scaling: E episodes per GPU).  Metric: sampled trajectories / s = N_gpus * E * N * K / time.
+(+ one gather of the metrics when N > 1: RCCL on the GPU box, gloo with --dist-backend gloo).  Episodes are
+independent and shard across ranks (weak scaling: E episodes per GPU).  Metric: sampled trajectories / s =
+N_gpus * E * N * K / time.
 
-Default workload = BASELINE.json configs[2] ("256 parallel episodes x N=5 x K=20, 1 MI355X"), the
-configuration the throughput target and the roofline are quoted on; the single-scene case (configs[1], E=1)
-is measured in the same run and reported under "single_scene".  Prints ONE JSON line on rank 0.
+Default workload = BASELINE.json configs[2] ("256 parallel episodes x N=5 x K=20, 1 MI355X"), the configuration the
+throughput target and the roofline are quoted on; the single-scene case (configs[1], E=1) is measured in the same run
+and reported under "single_scene".
+
+Precision modes.  `value` is the mode named by --precision (default f16x3: fp32-class three-term split products, the
+mode the drop-in predictor class `HumanTrajectoryForecasterSim` runs by default).  Every mode listed in --modes
+(default "f16x3,f16x2") gets THE SAME measurement - W warm-up steps, one untimed profiling step, K timed steps between
+barriers, parity against the oracle on the same episodes - and is reported under `modes[<name>]` with the same keys;
+the top-level keys are a copy of modes[--precision].  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,14 +47,21 @@ WORKLOADS = {
     "cfg4": (1, 25, 64, 12, 50),     # configs[3]: dense crowd, one scene
     "cfg5": (512, 5, 20, 12, 50),    # configs[4]: 4096 episodes sharded 512 / GPU
 }
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0, "f16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 # MFMA FLOPs spent per algorithmic FLOP; f16x2: 2 in the GEMMs, (3 + 2) / 2 in attention (logits keep all three terms)
-MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2, "f16": 1}
-MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.5, "f16": 1}
-# PMC summaries of the mode (tools/round_profile.sh, tools/mfma_busy.sh): (HBM traffic, MFMA busy); absent file = field omitted
-PMC_FILES = {"f16x3": ("r01_pmc_traffic.json", "r01_mfma_busy.json"),
-             "f16x2": ("r01_pmc_traffic_f16x2.json", "r01_mfma_busy_f16x2.json"),
-             "f32": ("r01_pmc_traffic_f32.json", "r01_mfma_busy_f32.json")}
+MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2}
+MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.5}
+DTYPE_TEXT = {
+    "f32": "f32",
+    "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate",
+    "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; softmax logits, "
+             "residual stream, LayerNorm and DDIM state at f32-class precision",
+}
+PROF_CLASSES = ["gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_ff", "gemm_tail", "attention"]
+# kernel class -> substring of the kernel names of that class in the per-call PMC summary (tools/pmc_call.sh)
+PMC_KERNEL_OF_CLASS = {"attention": "attn_f16x3_dma_kernel", "gemm_qkv": "gemm_f16x3_dma256x256_kernel<0, 2",
+                       "gemm_ff1": "gemm_f16x3_dma256x256_kernel<1, 1", "gemm_ff": "ff_ln_f16x3_kernel",
+                       "gemm_attn_out": "gemm_ln", "gemm_ff2": "gemm_ln"}
 
 
 def algorithmic_flops(dims: NetDims, joint: bool, E, A, K, T):
@@ -54,7 +69,7 @@ def algorithmic_flops(dims: NetDims, joint: bool, E, A, K, T):
     d, ff, dm, dl = dims.d_model, dims.d_ff, dims.d_mid, dims.d_low
     M = E * K * A * T
     S = K * A * T if joint else T
-    return {
+    fl = {
         "gemm_qkv": 2.0 * M * d * 3 * d * dims.tf_layer,
         "gemm_attn_out": 2.0 * M * d * d * dims.tf_layer,
         "gemm_ff1": 2.0 * M * d * ff * dims.tf_layer,
@@ -62,6 +77,28 @@ def algorithmic_flops(dims: NetDims, joint: bool, E, A, K, T):
         "gemm_tail": 2.0 * M * (d * dm + dm * dl),
         "attention": 4.0 * M * S * d * dims.tf_layer,
     }
+    fl["gemm_ff"] = fl["gemm_ff1"] + fl["gemm_ff2"]      # the fused linear1 -> linear2 + LayerNorm kernel, when it runs
+    return fl
+
+
+def git_blob_sha1(path):
+    """`git hash-object` of a file: lets a reader check which committed profile a bench field was taken from."""
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_summary(mode):
+    """Newest committed per-call PMC summary of this mode (tools/pmc_call.sh -> profiles/rNN_pmc_call_<mode>.json)."""
+    pdir = os.path.join(REPO, "profiles")
+    cands = sorted((f for f in os.listdir(pdir) if f.endswith(f"_pmc_call_{mode}.json")), reverse=True) \
+        if os.path.isdir(pdir) else []
+    for f in cands:
+        try:
+            p = os.path.join(pdir, f)
+            return json.load(open(p)), {"file": f"profiles/{f}", "git_blob_sha1": git_blob_sha1(p)}
+        except Exception:
+            continue
+    return None, None
 
 
 _T0 = time.perf_counter()
@@ -79,7 +116,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--episodes-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16x2"], help="the mode `value` is quoted on")
+    ap.add_argument("--modes", default="f16x3,f16x2",
+                    help="comma list of modes measured identically in this run (the --precision mode is always included)")
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
     ap.add_argument("--cpu-episodes", type=int, default=12, help="episodes timed on the host for cpu_baseline (0 = skip)")
@@ -87,6 +126,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=1,
                     help="chunks of the denoise loop in flight at once (1..4); > 1 is ~5 %% faster but not bit-reproducible")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one rank per GPU); gloo = host gather (lets several ranks share one GPU)")
+    ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (-1 = LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -95,11 +137,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_id = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    coll_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
     E, N, K, H, steps50 = WORKLOADS[args.workload]
     if args.episodes_per_gpu > 0:
@@ -107,9 +155,13 @@ def main():
     joint = args.net == "jmid"
     dims = NetDims(ctx_dim=256)
     weights = JMIDWeights.from_seed(dims, args.seed)
-    eng = JmidEngine(weights, joint=joint, device_id=local_rank, step=steps50)
+    eng = JmidEngine(weights, joint=joint, device_id=dev_id, step=steps50)
     eng.set_chunk_episodes(args.chunk)
     eng.set_tuning("lanes", args.lanes)
+    modes = [args.precision] + [m for m in args.modes.split(",") if m and m != args.precision]
+    for m in modes:
+        if m not in PEAK_TFLOPS:
+            raise SystemExit(f"unknown mode {m}")
 
     # ---- synthetic scene batches, resident in HBM before the timed region
     syn = synthetic_episodes(E, N, seed=args.seed * 1000 + rank, horizon=H)
@@ -123,9 +175,9 @@ def main():
         args.seed + rank * E + e)) for e in range(E)])
     x_T = x_T_host.to(dev)
 
-    def one_step(e_slice=slice(None)):
+    def one_step(precision):
         ctx = eng.encode(x_st, nbr, emask)
-        vel, pos = eng.denoise(x_T, ctx.view(E, A, -1), p0, dt=0.25, precision=args.precision, want_vel=False)
+        vel, pos = eng.denoise(x_T, ctx.view(E, A, -1), p0, dt=0.25, precision=precision, want_vel=False)
         met = eng.episode_metrics(pos, gt)
         eng.synchronize()            # the library runs on its own stream
         allm = gather_metrics(met, E * world)
@@ -137,44 +189,116 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log(f"inputs resident: E={E} A={A} K={K} H={H} precision={args.precision}")
-    for _ in range(args.warmup):
-        one_step()
-        log("warmup step done")
-    prof_classes = ["gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_tail", "attention"]
-    # HIP-event profiling serialises the launches it brackets (about 3 % of a cfg3 step when every GEMM and attention
-    # launch carries events), and with two chunks in flight (--lanes 2) a kernel shares the GPU with the other lane's
-    # kernels, so its launch duration says nothing about the kernel itself.  So: ONE untimed step with one chunk in
-    # flight and events on all classes gives the exclusive per-class table, names the dominant class and feeds
-    # `roofline`; the timed region then brackets only that class (reported under roofline.timed_region).
-    prof_all, dom_cls = {}, None
-    if not args.no_profile:
-        eng.set_tuning("lanes", 1)
-        eng.profile_enable(prof_classes)
-        eng.profile_reset()
-        one_step()
-        prof_all = eng.profile_get()
+    fl = algorithmic_flops(dims, joint, E, A, K, H)
+    traj = world * E * A * K
+
+    def measure(precision):
+        """W warm-up steps, one untimed profiling step, K timed steps between barriers: identical for every mode."""
+        for _ in range(args.warmup):
+            one_step(precision)
+        log(f"[{precision}] warm-up done")
+        # HIP-event profiling serialises the launches it brackets (~3 % of a cfg3 step when every GEMM and attention
+        # launch carries events).  So: ONE untimed step with events on all classes gives the per-class table and names
+        # the dominant class; the timed region then brackets only that class.
+        prof_all, dom = {}, None
+        if not args.no_profile:
+            eng.set_tuning("lanes", 1)
+            eng.profile_enable(PROF_CLASSES)
+            eng.profile_reset()
+            one_step(precision)
+            prof_all = eng.profile_get()
+            eng.profile_disable()
+            eng.set_tuning("lanes", args.lanes)
+            dom = max(PROF_CLASSES, key=lambda c: prof_all.get(c, (0, 0.0))[1])
+            eng.profile_enable([dom])
+            eng.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pos, met, allm = one_step(precision)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        prof = eng.profile_get() if not args.no_profile else {}
         eng.profile_disable()
-        eng.set_tuning("lanes", args.lanes)
-        dom_cls = max(prof_classes, key=lambda c: prof_all[c][1])
-        log(f"profiling step done, dominant class: {dom_cls}")
-        eng.profile_enable([dom_cls])
-        eng.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pos, met, allm = one_step()
-        log("timed step done")
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    log(f"timed region: {elapsed:.3f}s")
-    prof = eng.profile_get() if not args.no_profile else {}
-    eng.profile_disable()
-    log("profile collected")
+        log(f"[{precision}] timed region: {elapsed:.3f}s for {args.steps} steps")
+        res = {"value": round(traj * args.steps / elapsed, 2), "unit": "traj/s", "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "dtype": DTYPE_TEXT[precision]}
+        if prof and rank == 0:
+            per = {}
+            for cls in PROF_CLASSES:       # untimed profiling step (one pass over the batch)
+                n, ms = prof_all.get(cls, (0, 0.0))
+                if n:
+                    per[cls] = {"launches": n, "avg_ms": ms / n, "total_ms": ms,
+                                "tflops": fl[cls] * steps50 / (ms * 1e-3) / 1e12}
+            n, ms = prof[dom]              # the dominant class again, inside the timed region
+            dom_t = {"launches": n, "avg_ms": ms / n, "total_ms": ms,
+                     "tflops": fl[dom] * steps50 * args.steps / (ms * 1e-3) / 1e12}
+            peak = PEAK_TFLOPS[precision]
+            passes = (MFMA_PASSES_ATTN if dom == "attention" else MFMA_PASSES)[precision]
+            # one chunk in flight: the timed region's own events ARE the kernel's exclusive launch durations (contract);
+            # with lanes > 1 they are inflated by the overlap, so the exclusive untimed pass is quoted instead
+            dom_x = dom_t if args.lanes == 1 else per[dom]
+            # every GEMM / attention class runs in every layer; fused classes absorb the ones they replace
+            ran = [c for c in PROF_CLASSES if c in per]
+            path_flops = sum(fl[c] for c in ran if not (c == "gemm_ff" and "gemm_ff1" in per))
+            path_tflops = path_flops * steps50 * args.steps / elapsed / 1e12
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_x["tflops"], 2), "peak": peak,
+                    "unit": "TFLOP/s", "frac": round(dom_x["tflops"] / peak, 4), "traffic": None,
+                    "frac_of_split_peak": round(dom_x["tflops"] * passes / peak, 4),
+                    "mfma_passes_per_product": passes,
+                    "flops_per_launch": fl[dom] * steps50 * (args.steps if args.lanes == 1 else 1) / dom_x["launches"],
+                    "avg_launch_ms": round(dom_x["avg_ms"], 4), "launches": dom_x["launches"],
+                    "measured": ("HIP events on the library's stream around every launch of this kernel class in the "
+                                 "timed region" if args.lanes == 1 else
+                                 "HIP events on the library's stream, one full pass over the batch with ONE chunk "
+                                 "in flight (the kernel has the GPU to itself), untimed, in this run"),
+                    "path_achieved": round(path_tflops, 2), "path_frac": round(path_tflops / peak, 4),
+                    "peak_sustained_random_operands": 1660.0,
+                    "note": "peak = dense fp16 MFMA of MI355X_MICROARCH.md; a pure MFMA loop with fresh random operands "
+                            "sustains 1.66 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip, warm clocks); this mode "
+                            f"spends {passes} MFMA FLOPs per algorithmic FLOP of this kernel; path_achieved = algorithmic "
+                            "FLOPs of all MFMA kernel classes / wall time of the timed region"}
+            # PMC-derived fields are NOT measured in this run: they come from the newest committed per-call PMC summary of
+            # this mode (separate rocprofv3 --pmc passes, tools/pmc_call.sh) and say so, with the file's git blob hash
+            pmc, src = pmc_summary(precision)
+            if pmc and joint and (N, K, H, steps50) == (5, 20, 12, 50):
+                kname = PMC_KERNEL_OF_CLASS.get(dom)
+                rows = [v for k, v in pmc.get("kernels", {}).items() if kname and kname in k and v.get("launches", 0) >= 50]
+                if rows:
+                    r = max(rows, key=lambda v: v["hbm_bytes_per_launch"])
+                    chunks_per_step = dom_t["launches"] / (steps50 * args.steps * dims.tf_layer)
+                    tokens_per_launch = E * A * K * H / chunks_per_step
+                    roof["traffic"] = r["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
+                    roof["traffic_source"] = dict(src, kernel=r.get("name"), measured_at_tokens=pmc["tokens"],
+                                                  note="HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of the production "
+                                                       "kernel inside one whole predictor call, scaled to this run's tokens per launch")
+                    if "mfma_busy" in r:
+                        roof["mfma_busy"] = {"dominant_kernel": r["mfma_busy"], "whole_call": pmc.get("whole_call_mfma_busy"),
+                                             "source": src}
+                bpt = pmc["call"]["hbm_bytes_per_trajectory"]
+                res["hbm"] = {"bytes_per_trajectory": bpt, "GBps": round(bpt * res["value"] / world / 1e9, 1),
+                              "peak_GBps": 8000.0, "frac": round(bpt * res["value"] / world / 8e12, 4), "source": src,
+                              "note": "PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of one whole predictor call on one chunk, "
+                                      "per trajectory, times this run's per-GPU traj/s",
+                              "model_bytes_per_trajectory": {"layer_streamed_bf16": 34.9e6, "minimal": 9600}}
+            res["roofline"] = roof
+            res["kernels"] = {c: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
+                                  "total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 2)}
+                              for c, v in per.items()}
+        if rank == 0:
+            res["sweep_metrics"] = {"episodes": int(allm.shape[0]), "mean_ADE_m": float(np.nanmean(allm[:, 0])),
+                                    "mean_minADE_m": float(np.nanmean(allm[:, 1])),
+                                    "mean_FDE_m": float(np.nanmean(allm[:, 2]))}
+        return res, pos
+
+    log(f"inputs resident: E={E} A={A} K={K} H={H} modes={modes} world={world} backend={args.dist_backend}")
+    results, last_pos = {}, {}
+    for m in modes:
+        results[m], last_pos[m] = measure(m)
 
     if rank != 0:
         if world > 1:
@@ -182,154 +306,67 @@ def main():
             dist.destroy_process_group()
         return
 
-    traj = world * E * A * K
-    value = traj * args.steps / elapsed
+    head = results[args.precision]
     out = {
         "metric": "sampled trajectories/sec (N x K, 50 denoise steps)",
-        "value": round(value, 2), "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": {"f32": "f32", "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate",
-                  "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; softmax "
-                           "logits, residual stream, LayerNorm and DDIM state at f32-class precision"}[args.precision],
-        "data": "synthetic",
+        "value": head["value"], "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {E} episodes/GPU x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
                    "episodes_per_gpu": E, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
-                   "net": args.net, "precision": args.precision, "lanes": args.lanes},
+                   "net": args.net, "precision": args.precision, "lanes": args.lanes,
+                   "dist_backend": args.dist_backend if world > 1 else None},
     }
-    # ---- roofline of the dominant kernel class (HIP events on the library's stream, timed region only)
-    if prof:
-        fl = algorithmic_flops(dims, joint, E, A, K, H)
-        per = {}
-        for cls in prof_classes:       # untimed profiling step (one pass over the batch)
-            n, ms = prof_all[cls]
-            if n:
-                per[cls] = {"launches": n, "avg_ms": ms / n, "total_ms": ms,
-                            "tflops": fl[cls] * steps50 / (ms * 1e-3) / 1e12}
-        dom = dom_cls
-        n, ms = prof[dom]              # the dominant class again, inside the timed region
-        dom_t = {"launches": n, "avg_ms": ms / n, "total_ms": ms,
-                 "tflops": fl[dom] * steps50 * args.steps / (ms * 1e-3) / 1e12}
-        peak = PEAK_TFLOPS[args.precision]
-        passes = (MFMA_PASSES_ATTN if dom == "attention" else MFMA_PASSES)[args.precision]
-        traffic = None
-        try:   # PMC-measured HBM bytes per launch of this kernel class (separate rocprofv3 --pmc passes, profiles/)
-            pmc = json.load(open(os.path.join(REPO, "profiles", PMC_FILES[args.precision][0])))
-            if dom in pmc:
-                launches_per_step = dom_t["launches"] / (steps50 * args.steps * dims.tf_layer)   # chunks per step
-                tokens_per_launch = E * A * K * H / launches_per_step
-                traffic = pmc[dom]["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
-        except Exception:
-            traffic = None
-        # one chunk in flight: the timed region's own events ARE the kernel's exclusive launch durations (contract);
-        # with lanes > 1 they are inflated by the overlap, so the exclusive untimed pass is quoted instead
-        dom_x = dom_t if args.lanes == 1 else per[dom]
-        path_tflops = sum(fl.values()) * steps50 * args.steps / elapsed / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(dom_x["tflops"], 2), "peak": peak,
-                           "unit": "TFLOP/s", "frac": round(dom_x["tflops"] / peak, 4), "traffic": traffic,
-                           "frac_of_split_peak": round(dom_x["tflops"] * passes / peak, 4),
-                           "mfma_passes_per_product": passes,
-                           "flops_per_launch": fl[dom] * steps50 * (args.steps if args.lanes == 1 else 1) / dom_x["launches"],
-                           "avg_launch_ms": round(dom_x["avg_ms"], 4), "launches": dom_x["launches"],
-                           "measured": ("HIP events on the library's stream around every launch of this kernel class in the "
-                                        "timed region" if args.lanes == 1 else
-                                        "HIP events on the library's stream, one full pass over the batch with ONE chunk "
-                                        "in flight (the kernel has the GPU to itself), untimed, in this run"),
-                           "timed_region": {"lanes": args.lanes, "launches": dom_t["launches"],
-                                            "avg_launch_ms": round(dom_t["avg_ms"], 4),
-                                            "achieved": round(dom_t["tflops"], 2),
-                                            "path_achieved": round(path_tflops, 2),
-                                            "path_frac": round(path_tflops / peak, 4),
-                                            "note": "HIP events inside the timed region: with lanes > 1 two chunks are in "
-                                                    "flight and every kernel shares the GPU with the other lane's kernels, "
-                                                    "so its launch takes about twice as long; path_achieved = algorithmic "
-                                                    "FLOPs of all MFMA kernel classes / wall time of the region"},
-                           "peak_sustained_random_operands": 1660.0,
-                           "note": "peak = dense fp16 MFMA of MI355X_MICROARCH.md; a pure MFMA loop with fresh random "
-                                   "operands sustains 1.66 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip, warm clocks), and "
-                                   f"this mode spends {passes} MFMA FLOPs per algorithmic FLOP of this kernel"}
-        try:   # PMC: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs), tools/mfma_busy.sh
-            busy = json.load(open(os.path.join(REPO, "profiles", PMC_FILES[args.precision][1])))
-            if joint:
-                out["roofline"]["mfma_busy"] = {
-                    "whole_call": round(busy["whole_call_mfma_busy"], 4),
-                    "dominant_kernel": round(next(v["mfma_busy"] for k, v in busy["kernels"].items() if "attn_f16x3" in k), 4),
-                    "source": f"rocprofv3 PMC over one 51-episode predictor call (profiles/{PMC_FILES[args.precision][1]}): fraction "
-                              "of the shader cycles of a dispatch in which a SIMD's MFMA pipe is busy"}
-        except Exception:
-            pass
-        out["kernels"] = {c: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
-                              "total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 2)}
-                          for c, v in per.items()}
-        out["kernels_note"] = "per-class HIP-event times of ONE untimed pass over the same batch with one chunk in flight"
-    # ---- HBM side of the roofline (north_star asks for it): PMC bytes of one whole predictor call, per trajectory
-    try:
-        call = json.load(open(os.path.join(REPO, "profiles", PMC_FILES[args.precision][0])))["call"]
-        if joint and (N, K, H, steps50) == (5, 20, 12, 50):
-            bpt = call["hbm_bytes_per_trajectory"]
-            out["hbm"] = {"bytes_per_trajectory": bpt, "GBps": round(bpt * value / 1e9, 1), "peak_GBps": 8000.0,
-                          "frac": round(bpt * value / 8e12, 4), "source": "rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE over one "
-                          f"51-episode call (profiles/{PMC_FILES[args.precision][0]}), scaled by this run's traj/s",
-                          "model_bytes_per_trajectory": {"layer_streamed_bf16": call[
-                              "model_bytes_per_trajectory_layer_streamed_bf16"], "minimal": call[
-                              "model_bytes_per_trajectory_minimal"]}}
-    except Exception:
-        pass
-    out["sweep_metrics"] = {"episodes": int(allm.shape[0]), "mean_ADE_m": float(np.nanmean(allm[:, 0])),
-                            "mean_minADE_m": float(np.nanmean(allm[:, 1])), "mean_FDE_m": float(np.nanmean(allm[:, 2])),
-                            "note": "random-init weights: displacement vs the constant-velocity future is not meaningful"}
+    for k in ("roofline", "kernels", "hbm", "sweep_metrics"):
+        if k in head:
+            out[k] = head[k]
+    out["kernels_note"] = "per-class HIP-event times of ONE untimed pass over the same batch with one chunk in flight"
+    out["sweep_metrics_note"] = "random-init weights: displacement vs the constant-velocity future is not meaningful"
+    out["modes"] = results
+    out["modes_note"] = ("every mode: same batch, same warm-up, same number of timed steps between the same barriers, same "
+                         "parity sample; `value` and the top-level keys are modes[config.precision]")
+    if len(modes) > 1:
+        a, b = modes[0], modes[1]
+        out["mean_ADE_between_modes_m"] = {f"{a}_vs_{b}": float(np.linalg.norm(
+            (last_pos[a] - last_pos[b]).cpu().numpy(), axis=-1).mean())}
 
-    # ---- single scene (BASELINE configs[1]) latency in the same run
+    # ---- single scene (BASELINE configs[1]) latency in the same run, every mode
     if world == 1:
-        eng1 = eng
-        ctx1 = eng1.encode(x_st[:A], nbr[:A], emask[:A]).view(1, A, -1)
-        for _ in range(2):
-            eng1.denoise(x_T[:1], ctx1, p0[:1], dt=0.25, precision=args.precision, want_vel=False)
-        eng1.synchronize()
-        t1 = time.perf_counter()
-        reps = 5
-        for _ in range(reps):
-            c1 = eng1.encode(x_st[:A], nbr[:A], emask[:A]).view(1, A, -1)
-            eng1.denoise(x_T[:1], c1, p0[:1], dt=0.25, precision=args.precision, want_vel=False)
-        eng1.synchronize()
-        dt1 = (time.perf_counter() - t1) / reps
-        out["single_scene"] = {"workload": f"cfg2: 1 scene x N={N} x K={K} x H={H}, {steps50} steps",
-                               "ms_per_call": round(1e3 * dt1, 3), "traj_per_s": round(A * K / dt1, 1)}
-
-        # the other split-fp16 mode on the same batch, one warm pass + one timed pass (not part of `value`)
-        other = {"f16x2": "f16x3", "f16x3": "f16x2"}.get(args.precision)
-        if other:
-            ctx_o = eng.encode(x_st, nbr, emask).view(E, A, -1)
-            eng.denoise(x_T, ctx_o, p0, dt=0.25, precision=other, want_vel=False)
+        ctx1 = eng.encode(x_st[:A], nbr[:A], emask[:A]).view(1, A, -1)
+        ss = {}
+        for m in modes:
+            for _ in range(3):
+                eng.denoise(x_T[:1], ctx1, p0[:1], dt=0.25, precision=m, want_vel=False)
             eng.synchronize()
-            t2 = time.perf_counter()
-            ctx_o = eng.encode(x_st, nbr, emask).view(E, A, -1)
-            _, pos_other = eng.denoise(x_T, ctx_o, p0, dt=0.25, precision=other, want_vel=False)
-            met_o = eng.episode_metrics(pos_other, gt)
+            t1 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                c1 = eng.encode(x_st[:A], nbr[:A], emask[:A]).view(1, A, -1)
+                eng.denoise(x_T[:1], c1, p0[:1], dt=0.25, precision=m, want_vel=False)
             eng.synchronize()
-            dt2 = time.perf_counter() - t2
-            out["other_modes"] = {other: {"value": round(E * A * K / dt2, 2), "unit": "traj/s", "ms_per_step": round(1e3 * dt2, 3),
-                                          "mean_ADE_between_modes_m": float(np.linalg.norm(
-                                              (pos_other - pos).cpu().numpy(), axis=-1).mean()),
-                                          "note": "same batch, one pass, same run; f16x3 = three-term split products "
-                                                  "(fp32-class everywhere), f16x2 = activation-lo terms left out"}}
-
+            dt1 = (time.perf_counter() - t1) / reps
+            ss[m] = {"ms_per_call": round(1e3 * dt1, 3), "traj_per_s": round(A * K / dt1, 1)}
+        out["single_scene"] = dict(ss[args.precision], workload=f"cfg2: 1 scene x N={N} x K={K} x H={H}, {steps50} steps",
+                                   modes=ss)
     log("single-scene done")
+
     # ---- CPU baseline (the oracle, a port of the reference; bounded sample) + parity on the same episodes
     if world == 1 and args.cpu_episodes > 0:
         from oracle import jmid_oracle as O
         ne = min(args.cpu_episodes, E)
+        # the parity sample is spread over the whole batch, so every chunk of the call (incl. a ragged last one) is
+        # held against the oracle, not just the first
+        pick = sorted(set(int(round(v)) for v in np.linspace(0, E - 1, ne)))
+        ne = len(pick)
         wt = weights.tensors
-        # torch's default intra-op thread count (affinity / cgroup aware); os.cpu_count() can exceed the cores
-        # this process may actually use and oversubscription makes the oracle crawl
         # calibrate the intra-op thread count on a 2-step run: more threads than the small GEMMs can use makes the
         # CPU path slower, and the baseline should be the CPU's best
         avail = len(os.sched_getaffinity(0))
         best = (float("inf"), torch.get_num_threads())
         with torch.no_grad():
             ctx_cal = O.encode_context(wt, x_st[:A].cpu(), nbr[:A].cpu(), emask[:A].cpu())
-            for nt in (8, 16, 32, 64, 128, 256):
+            for nt in (8, 16, 32, 64, 128):
                 if nt > avail:
                     break
                 torch.set_num_threads(nt)
@@ -342,29 +379,28 @@ def main():
         cores = best[1]
         torch.set_num_threads(cores)
         log(f"cpu baseline on {cores} threads (os.cpu_count={os.cpu_count()}, affinity={avail})")
-        xs_c, nb_c, em_c = x_st[: ne * A].cpu(), nbr[: ne * A].cpu(), emask[: ne * A].cpu()
+        xs_c, nb_c, em_c = x_st.cpu(), nbr.cpu(), emask.cpu()
         with torch.no_grad():
             O.denoise(wt, O.encode_context(wt, xs_c[:A], nb_c[:A], em_c[:A]), x_T_host[0], sample=K, step=2,
                       joint=joint)       # warm-up
             tc = time.perf_counter()
             pos_ref = []
-            for e in range(ne):
+            for e in pick:
                 ctx_c = O.encode_context(wt, xs_c[e * A:(e + 1) * A], nb_c[e * A:(e + 1) * A], em_c[e * A:(e + 1) * A])
                 v = O.denoise(wt, ctx_c, x_T_host[e], sample=K, step=steps50, joint=joint)
                 pos_ref.append(O.integrate(v, p0[e].cpu(), 0.25))
-                log(f"cpu episode {e} done")
             cpu_s = time.perf_counter() - tc
+        log(f"cpu baseline: {ne} episodes in {cpu_s:.1f}s")
         pos_ref = torch.stack(pos_ref).numpy()
-        ade = float(np.linalg.norm(pos[:ne].cpu().numpy() - pos_ref, axis=-1).mean())
         out["cpu_baseline"] = {"value": round(ne * A * K / cpu_s, 2), "unit": "traj/s", "cores": torch.get_num_threads(),
                                "kind": "port",
                                "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, "
                                          f"{cpu_s:.1f} s; oracle/jmid_oracle.py, torch-CPU fp32)"}
-        out["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4,
-                         "precision": args.precision}
-        if "other_modes" in out:
-            for m, o in out["other_modes"].items():
-                o["mean_ADE_vs_oracle_m"] = float(np.linalg.norm(pos_other[:ne].cpu().numpy() - pos_ref, axis=-1).mean())
+        for m in modes:
+            ade = float(np.linalg.norm(last_pos[m][pick].cpu().numpy() - pos_ref, axis=-1).mean())
+            results[m]["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4,
+                                    "episode_ids": pick, "precision": m}
+        out["parity"] = results[args.precision]["parity"]
     print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -26,6 +26,8 @@ def gather_metrics(local: torch.Tensor, total: int, dst: int = 0) -> Optional[np
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local.detach().cpu().numpy()
     world, rank = dist.get_world_size(), dist.get_rank()
+    if dist.get_backend() == "gloo" and local.is_cuda:     # host collective (CPU tests; several ranks sharing one GPU)
+        local = local.detach().cpu()
     width = local.shape[1]
     cap = max(shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world))
     buf = torch.full((cap, width), float("nan"), dtype=local.dtype, device=local.device)

@@ -1,6 +1,7 @@
 """bench.py prints ONE JSON line with the fields the driver and the judge read (contract in the task statement)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -8,16 +9,21 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODE_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "kernels", "sweep_metrics")
+
+
+def _one_json_line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
 
 
 def test_bench_json_contract():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--episodes-per-gpu", "6", "--chunk", "2", "--cpu-episodes", "1"],
+                          "--episodes-per-gpu", "6", "--chunk", "2", "--cpu-episodes", "3"],
                          capture_output=True, text=True, timeout=600, cwd=REPO)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    j = _one_json_line(out)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -29,8 +35,48 @@ def test_bench_json_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
-    # the default run is the two-term mode; the three-term mode is timed and checked against the oracle in the same run
-    assert j["config"]["precision"] == "f16x2" and j["parity"]["precision"] == "f16x2"
-    o = j["other_modes"]["f16x3"]
-    assert o["value"] > 0 and o["mean_ADE_vs_oracle_m"] <= 1e-5 and o["mean_ADE_between_modes_m"] <= 1e-4
+    # the headline is the mode the drop-in predictor class runs by default (fp32-class three-term products) ...
+    assert j["config"]["precision"] == "f16x3" and j["parity"]["precision"] == "f16x3"
+    assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-5
+    # ... and both split modes are measured the same way and reported under the same keys
+    assert set(j["modes"]) == {"f16x3", "f16x2"}
+    for m, v in j["modes"].items():
+        for k in MODE_KEYS + ("parity",):
+            assert k in v, (m, k)
+        assert v["steps"] == 1 and v["warmup"] == 1 and v["value"] > 0
+        assert v["parity"]["pass"] is True and v["parity"]["episodes"] == 3
+        assert v["parity"]["episode_ids"] == [0, 2, 5]          # spread over the batch: every chunk of 2 is sampled
+    assert j["value"] == j["modes"]["f16x3"]["value"] and j["ms_per_step"] == j["modes"]["f16x3"]["ms_per_step"]
+    assert j["modes"]["f16x2"]["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
+    assert j["mean_ADE_between_modes_m"]["f16x3_vs_f16x2"] <= 1e-4
+    assert set(j["single_scene"]["modes"]) == {"f16x3", "f16x2"}
+    # PMC-derived fields name the committed profile they were read from
+    for k in ("traffic_source", "mfma_busy"):
+        if k in r:
+            src = r[k]["source"] if k == "mfma_busy" else r[k]
+            assert src["file"].startswith("profiles/") and len(src["git_blob_sha1"]) == 40
+
+
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 path of bench.py, for real, on the one GPU of the test box: two ranks (both on device 0) launched the
+    way the driver launches them, host collectives over gloo.  Exercises process-group init, per-rank seeds and episode
+    shards, the barrier / MAX all-reduce bracketing of the timed region, gather_metrics of device tensors in episode
+    order, and the rank != 0 exit.  (The RCCL flavour of the same calls needs two GPUs)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--episodes-per-gpu", "5", "--chunk", "2",
+                          "--dist-backend", "gloo", "--device", "0", "--modes", "f16x3", "--cpu-episodes", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    j = _one_json_line(out)
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak"
+    assert j["config"]["dist_backend"] == "gloo" and j["config"]["episodes_per_gpu"] == 5
+    sm = j["sweep_metrics"]
+    assert sm["episodes"] == 10                      # 5 episodes of rank 0 followed by 5 of rank 1
+    assert sm["mean_ADE_m"] > 0 and sm["mean_ADE_m"] == sm["mean_ADE_m"]     # no NaN padding rows leaked through
+    # whole-job rate: 2 ranks x 5 episodes x 5 humans x 20 samples per step
+    assert abs(j["value"] - 2 * 5 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
