@@ -202,6 +202,60 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
         return np.concatenate((pose, forecasts), axis=2), logw
 
 
+def predict_batch(engine: JmidEngine, human_xy: np.ndarray, robot_xy: np.ndarray, seeds, *, num_samples: int,
+                  num_ret_samples: int, horizon: int, time_step: float, precision: str = "f16x3"
+                  ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """``predict_ret_best()`` for E independent episodes in as few device calls as their cluster sizes allow: the feed
+    of the multi-episode evaluation sweeps.
+
+    human_xy [E, F, N, 2], robot_xy [E, F, 2] on the ``time_step`` grid (oldest first); ``seeds[e]`` seeds the torch
+    generator episode e draws its x_T from (== ``torch.manual_seed(seeds[e])`` before the per-episode call).
+    The host batch comes from ``scene.build_scenes_batched`` with the reference's own clustering (the pedestrians
+    within 3 m of the cluster nearest the robot go through the network, mid_sim_wrapper.py:335-355; the others get
+    constant-velocity forecasts, :413-429); episodes with the same number A of in-cluster pedestrians share one
+    ``encode`` + ``denoise`` call (the C ABI takes one A per call).  Returns (forecasts [E, N, k, H+1, 2] float64,
+    log-weights [E, N, k] float64, in_cluster [E, N] bool), each episode as ``predict_ret_best`` would return it.
+    """
+    E, F, N, _ = human_xy.shape
+    K, k, H = int(num_samples), int(num_ret_samples), int(horizon)
+    b = SC.build_scenes_batched(human_xy, robot_xy, time_step, horizon=H)
+    inc = b["in_cluster"]
+    forecasts = np.zeros((E, N, k, H, 2), dtype=np.float64)
+    logw = np.zeros((E, N, k), dtype=np.float64)
+    n_in = inc.sum(axis=1)
+    for A in np.unique(n_in):
+        eps = np.nonzero(n_in == A)[0]
+        A = int(A)
+        rows = np.stack([np.nonzero(inc[e])[0] for e in eps])                       # [Eg, A] ascending track ids
+        ei = eps[:, None]
+        x_T = torch.stack([torch.randn([K * A, H, 2], generator=torch.Generator().manual_seed(int(seeds[e])))
+                           for e in eps]).numpy()
+        ctx = engine.encode(b["x_st"][ei, rows].reshape(len(eps) * A, F, 6),
+                            b["nbr_sum"][ei, rows].reshape(len(eps) * A, 2, F, 6),
+                            b["edge_mask"][ei, rows].reshape(len(eps) * A, 2)).reshape(len(eps), A, -1)
+        p0 = np.ascontiguousarray(b["p0"][ei, rows])
+        try:
+            _, pos = engine.denoise(x_T, ctx, p0, dt=time_step, precision=precision, want_vel=False)
+        except JmidError as e:
+            if e.code != -5 or precision == "f32":
+                raise
+            _, pos = engine.denoise(x_T, ctx, p0, dt=time_step, precision="f32", want_vel=False)
+        for g, e in enumerate(eps):                                                # pos [Eg, K, A, H, 2]
+            if k < K:
+                sel, lw = most_likely_samples(pos[g], k)                          # [A, k, H, 2], [A, k]
+                lw = lw.astype(np.float64)
+            else:
+                sel = pos[g].transpose(1, 0, 2, 3)
+                lw = np.log(np.ones((A, K), dtype=np.float64) / K)
+            forecasts[e, rows[g]] = sel
+            logw[e, rows[g]] = lw
+            out_rows = np.nonzero(~inc[e])[0]
+            forecasts[e, out_rows] = b["cv"][e, out_rows][:, None]
+            logw[e, out_rows] = lw[0]
+    pose = np.repeat(human_xy[:, -1][:, :, None, None, :], k, axis=2)              # [E, N, k, 1, 2]
+    return np.concatenate((pose, forecasts), axis=3), logw, inc
+
+
 def write_configs(directory: str, *, joint: bool, ctx_dim: int, N: int, K: int, k_ret: int, H: int, step: int,
                   past: int = 6, time_step: float = 0.25, model_path: str = "weights.npz"):
     """Helper for tests / demos: writes an env.config + MID yaml pair with the keys the predictor reads

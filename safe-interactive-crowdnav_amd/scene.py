@@ -215,7 +215,7 @@ def build_scene(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float, ho
 
 # --------------------------------------------------------------------------------------------- batched builder
 def build_scenes_batched(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float,
-                         force_all_in_cluster: bool = False) -> Dict[str, np.ndarray]:
+                         force_all_in_cluster: bool = False, horizon: Optional[int] = None) -> Dict[str, np.ndarray]:
     """``build_scene`` for E independent episodes at once (no Python loop over episodes): the feed of the
     256-4096-episode evaluation sweeps.
 
@@ -224,6 +224,8 @@ def build_scenes_batched(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: 
     Returns x, x_st [E, N, F, 6], nbr_sum [E, N, 2, F, 6], edge_mask [E, N, 2], p0 [E, N, 2] (all float32),
     in_cluster [E, N] bool, robot_in_cluster [E] bool.  Rows outside the cluster are computed as if they had no
     neighbours in the graph (they are not graph nodes in the reference).  Bit-identical to ``build_scene`` per episode.
+    With ``horizon`` the constant-velocity forecasts of EVERY pedestrian (what the reference returns for the ones
+    outside the cluster, mid_sim_wrapper.py:413-429) come back as ``cv`` [E, N, horizon, 2] float64.
     """
     E, F, N, _ = human_xy.shape
     dt = time_step
@@ -274,8 +276,12 @@ def build_scenes_batched(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: 
         w = conn[:, 1:, j].astype(np.float32)[:, :, None, None]
         e_idx = 1 if j == 0 else 0                                                  # robot -> edge type PED->ROBOT
         nbr_sum[:, :, e_idx] = nbr_sum[:, :, e_idx] + relj * w
-    return dict(x=xs.astype(np.float32), x_st=x_st.astype(np.float32), nbr_sum=nbr_sum, edge_mask=edge_mask,
-                p0=xs[:, :, -1, 0:2].astype(np.float32), in_cluster=inc[:, 1:], robot_in_cluster=inc[:, 0])
+    out = dict(x=xs.astype(np.float32), x_st=x_st.astype(np.float32), nbr_sum=nbr_sum, edge_mask=edge_mask,
+               p0=xs[:, :, -1, 0:2].astype(np.float32), in_cluster=inc[:, 1:], robot_in_cluster=inc[:, 0])
+    if horizon is not None:      # same operations, in the same order, as build_scene's per-pedestrian loop
+        step = np.repeat((xs[:, :, -1, 2:4] * dt)[:, :, None, :], horizon, axis=2)     # [E, N, H, 2]
+        out["cv"] = xs[:, :, -1:, 0:2] + np.cumsum(step, axis=2)
+    return out
 
 
 # --------------------------------------------------------------------------------------------- synthetic feeds

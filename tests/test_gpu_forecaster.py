@@ -136,3 +136,80 @@ def test_forecaster_falls_back_to_fp32_when_fp16_range_is_exceeded(tmp_path):
     assert np.isfinite(outs[0]).all()
     np.testing.assert_array_equal(outs[0], outs[2])
     np.testing.assert_array_equal(outs[1], outs[2])
+
+
+@pytest.mark.parametrize("ctx_dim,joint,k_ret", [(32, True, 6), (32, False, 6), (256, True, 6), (32, True, 3)])
+def test_predict_batch_with_natural_clusters_matches_per_episode_forecaster(ctx_dim, joint, k_ret, tmp_path):
+    """SURVEY 8f row f2 on the device path: a multi-episode batch with the reference's own clustering (the number of
+    in-cluster pedestrians differs from episode to episode) through build_scenes_batched -> engine, against one
+    HumanTrajectoryForecasterSim per episode fed the same histories and the same seed."""
+    from safe_interactive_crowdnav_amd.forecaster import predict_batch
+    E, F, N, K, H, dt = 24, 6, 6, 6, 8, 0.25
+    rng = np.random.default_rng(17)
+    pos0 = rng.uniform(-5.0, 5.0, (E, N, 2))
+    vel = rng.uniform(-1.0, 1.0, (E, N, 2))
+    t = np.arange(F) * dt
+    hum = pos0[:, None] + vel[:, None] * t[None, :, None, None] + 0.01 * rng.standard_normal((E, F, N, 2))
+    rob = np.array([0.0, -3.0])[None, None] + 0.02 * rng.standard_normal((E, F, 2))
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), 5)
+    env, ypath = write_configs(str(tmp_path), joint=joint, ctx_dim=ctx_dim, N=N, K=K, k_ret=k_ret, H=H, step=2)
+    ref_f, ref_w, ref_in = [], [], []
+    for e in range(E):
+        f = HumanTrajectoryForecasterSim(env, ypath, weights=w)
+        for i in range(F):
+            f.update_state_hists(State(rob[e, i]), [State(p) for p in hum[e, i]], float(t[i]))
+        torch.manual_seed(1000 + e)
+        a, b = f.predict_ret_best()
+        ref_f.append(a)
+        ref_w.append(b)
+    eng = f.engine
+    fc, lw, inc = predict_batch(eng, hum, rob, [1000 + e for e in range(E)], num_samples=K, num_ret_samples=k_ret,
+                                horizon=H, time_step=dt, precision=f.precision)
+    sizes = inc.sum(axis=1)
+    assert len(np.unique(sizes)) >= 3 and sizes.min() >= 1 and sizes.max() <= N      # a genuinely ragged batch
+    assert fc.shape == (E, N, k_ret, H + 1, 2) and fc.dtype == np.float64 and lw.shape == (E, N, k_ret)
+    ref_f, ref_w = np.stack(ref_f), np.stack(ref_w)
+    if ctx_dim == 32:
+        # head_dim 16: one episode alone and the same episode inside a group run the very same arithmetic
+        np.testing.assert_array_equal(fc, ref_f)
+        np.testing.assert_array_equal(lw, ref_w)
+    else:
+        # head_dim 128: the split-KV factor of attention depends on the episode count of the call (include/jmid_hip.h)
+        assert np.linalg.norm(fc - ref_f, axis=-1).mean() <= 1e-6
+        np.testing.assert_allclose(lw, ref_w, rtol=0, atol=1e-9)
+    out = ~inc
+    np.testing.assert_array_equal(fc[out], ref_f[out])          # constant-velocity rows: host arithmetic, bit-exact
+
+
+def test_predictor_output_feeds_the_mpc_parameter_layout(tmp_path):
+    """SURVEY 8f row f1 end to end on the device path: predict_ret_best() of the drop-in class -> mpc_glue -> the
+    per-stage Acados parameter vectors, against the reference capture's forecasts for the same scene (the wrapper
+    golden holds what the reference's predictor returned; the arithmetic after it is pinned bit-exactly on the host by
+    tests/test_host_logic.py::test_mpc_glue_matches_reference_capture)."""
+    import einops
+    from safe_interactive_crowdnav_amd.mpc_glue import mpc_forecast_inputs, stage_parameter_blocks
+    z = np.load(os.path.join(GOLDEN, "wrapper_jmid_together.npz"))
+    N, K, k_ret, H = int(z["N"]), int(z["K"]), int(z["k_ret"]), int(z["H"])
+    env, ypath = write_configs(str(tmp_path), joint=True, ctx_dim=int(z["ctx_dim"]), N=N, K=K, k_ret=k_ret, H=H,
+                               step=int(z["step"]))
+    f = HumanTrajectoryForecasterSim(env, ypath, weights=JMIDWeights.from_seed(NetDims(ctx_dim=int(z["ctx_dim"])),
+                                                                                 int(z["wseed"])), rng_compat="cpu")
+    for r, h, t in zip(z["robot_xy"], z["human_xy"], z["stamps"]):
+        f.update_state_hists(State(r), [State(p) for p in h], float(t))
+    torch.manual_seed(int(z["dseed"]))
+    top, w = f.predict_ret_best()
+    horiz = H - 1
+    rng = np.random.default_rng(0)
+    nx, nu = 4 + 4 * N, 2
+    gs, ga = rng.standard_normal((nx, horiz + 1)), rng.standard_normal((nu, horiz))
+    Q, R, TQ = rng.uniform(0.1, 1, nx), rng.uniform(0.1, 1, nu), rng.uniform(0.1, 1, nx)
+    ours = mpc_forecast_inputs(top, w, horiz, f.time_step, joint=True)
+    ref = mpc_forecast_inputs(z["forecasts"], z["logw"], horiz, f.time_step, joint=True)
+    p = stage_parameter_blocks(ours.samples_by_stage, gs, ga, Q, R, TQ, horiz)
+    p_ref = stage_parameter_blocks(ref.samples_by_stage, gs, ga, Q, R, TQ, horiz)
+    assert p.shape == (horiz + 1, nx + nu + 2 * nx + nu + 4 * N * k_ret)
+    np.testing.assert_array_equal(ours.samples_by_stage,
+                                  einops.rearrange(top[:, :, 1:, :], "h s t d -> t (h s) d")[: horiz + 1])
+    assert np.abs(p - p_ref).max() <= 5e-4 and np.abs(p - p_ref).mean() <= 1e-4     # forecasts within the ADE gate
+    np.testing.assert_allclose(ours.goal_xy, ref.goal_xy, atol=1e-4)
+    np.testing.assert_allclose(ours.v_pref, ref.v_pref, atol=2e-3)

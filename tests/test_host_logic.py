@@ -110,3 +110,31 @@ def test_mpc_glue_matches_caller_arithmetic():
         assert out.goal_xy[h, 1] == pytest.approx(np.mean(forecasts[h, :, 0, 1]))
         assert out.v_pref[h] == pytest.approx(np.max(np.linalg.norm(np.diff(forecasts[h], axis=1), axis=2) / dt))
     assert mpc_forecast_inputs(top, w, horiz, dt, joint=False).init_weights.shape == (N, k)
+
+
+@pytest.mark.parametrize("case", ["mpc_glue_joint.npz", "mpc_glue_indep_outdoor.npz", "mpc_glue_exact_horizon.npz"])
+def test_mpc_glue_matches_reference_capture(case, golden_dir):
+    """SURVEY 8f row f1 pinned by captures of the reference's own lines (tests/golden/make_golden_mpc.py executes
+    sicnav_acados.py:1639-1682 and :1388-1413 against recording stand-ins): forecast slicing, initial weights, the
+    't (h s) d' stage layout, goal point / preferred speed / heading per human, and the per-stage Acados parameter
+    vectors p_0 .. p_horiz, bit for bit."""
+    import os
+    from safe_interactive_crowdnav_amd.mpc_glue import human_headings, mpc_forecast_inputs, stage_parameter_blocks
+
+    z = np.load(os.path.join(golden_dir, case))
+    horiz, joint, outdoor = int(z["horiz"]), bool(z["joint"]), bool(z["outdoor"])
+    out = mpc_forecast_inputs(z["top_k_forecasts"], z["top_k_weights"], horiz, float(z["time_step"]), joint=joint)
+    np.testing.assert_array_equal(out.forecasts, z["forecasts"])
+    np.testing.assert_array_equal(out.init_weights, z["forecasts_init_weights"])
+    np.testing.assert_array_equal(out.samples_by_stage, z["forecasts_reshaped"])
+    np.testing.assert_array_equal(out.goal_xy[:, 0], z["gx"])
+    np.testing.assert_array_equal(out.goal_xy[:, 1], z["gy"])
+    np.testing.assert_array_equal(out.v_pref, z["v_pref"])
+    np.testing.assert_array_equal(human_headings(z["human_pxpyvxvy"][:, 2], z["human_pxpyvxvy"][:, 3]), z["theta"])
+    p = stage_parameter_blocks(out.samples_by_stage, z["goal_states"], z["goal_actions"], z["Q_diag"], z["R_diag"],
+                               z["term_Q_diag"], horiz, static_obs=z["static_obs"] if outdoor else None)
+    assert p.shape == z["p_stages"].shape and p.dtype == np.float64
+    np.testing.assert_array_equal(p, z["p_stages"])
+    with pytest.raises(IndexError):          # the reference indexes MID_samples[horiz] and fails the same way
+        stage_parameter_blocks(out.samples_by_stage[:horiz], z["goal_states"], z["goal_actions"], z["Q_diag"],
+                               z["R_diag"], z["term_Q_diag"], horiz)
