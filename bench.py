@@ -36,7 +36,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from safe_interactive_crowdnav_amd.engine import JmidEngine  # noqa: E402
-from safe_interactive_crowdnav_amd.scene import synthetic_episodes  # noqa: E402
+from safe_interactive_crowdnav_amd.scene import build_scenes_batched, synthetic_episodes  # noqa: E402
 from safe_interactive_crowdnav_amd.sweep import gather_metrics  # noqa: E402
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims  # noqa: E402
 
@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=1,
                     help="chunks of the denoise loop in flight at once (1..4); > 1 is ~5 %% faster but not bit-reproducible")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--scenes", default="cv", choices=["cv", "orca"],
+                    help="synthetic histories: cv = constant-velocity agents (SURVEY 8d), orca = batched circle-crossing "
+                         "crowds of ORCA agents (episodes.py, SURVEY 8f row f3); all agents forced in-cluster either way")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = host gather (lets several ranks share one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (-1 = LOCAL_RANK)")
@@ -164,7 +167,15 @@ def main():
             raise SystemExit(f"unknown mode {m}")
 
     # ---- synthetic scene batches, resident in HBM before the timed region
-    syn = synthetic_episodes(E, N, seed=args.seed * 1000 + rank, horizon=H)
+    if args.scenes == "orca":
+        from safe_interactive_crowdnav_amd.episodes import history_windows, simulate_circle_crossing
+        frame = 12                       # 3 s into the crossing: the crowd is interacting around the centre
+        sim = simulate_circle_crossing(E, N, frame + H, seed=args.seed * 1000 + rank)
+        hum, rob = history_windows(sim, frame)
+        syn = build_scenes_batched(hum, rob, 0.25, force_all_in_cluster=True)
+        syn["gt"] = np.ascontiguousarray(sim["human_xy"][:, frame + 1:frame + 1 + H].transpose(0, 2, 1, 3), np.float32)
+    else:
+        syn = synthetic_episodes(E, N, seed=args.seed * 1000 + rank, horizon=H)
     A = N
     x_st = torch.from_numpy(syn["x_st"].reshape(E * A, 6, 6)).to(dev)
     nbr = torch.from_numpy(syn["nbr_sum"].reshape(E * A, 2, 6, 6)).to(dev)
@@ -315,7 +326,7 @@ def main():
         "config": {"workload": f"{args.workload}: {E} episodes/GPU x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
                    "episodes_per_gpu": E, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
-                   "net": args.net, "precision": args.precision, "lanes": args.lanes,
+                   "net": args.net, "precision": args.precision, "lanes": args.lanes, "scenes": args.scenes,
                    "dist_backend": args.dist_backend if world > 1 else None},
     }
     for k in ("roofline", "kernels", "hbm", "sweep_metrics"):

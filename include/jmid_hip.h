@@ -179,8 +179,7 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "fuse_embed"      0 = separate embedding kernel at the start of every step instead of the fused output kernel
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
  *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
- *   "persist"         one persistent kernel per denoise step for small token counts: 0 auto, 1 always, 2 never
- *   "ff_fuse"         linear1 -> ReLU -> linear2 + residual + LayerNorm in one kernel: 0 auto, 1 always, 2 never
+ *   "attn_nsplit"     split-KV factor of the head_dim-128 attention launches: 0 auto (attn_pick_nsplit), 1..16 forced
  *   "gemm_ng", "print_occupancy"   diagnostics used by tools/
  *   "gemm_abl", "attn_abl"         timing ablations (WRONG results): exist only in builds with -DJMID_ABLATIONS
  * Every knob belongs to the handle it is set on.  All variants of a key compute the same values (bit-identical for

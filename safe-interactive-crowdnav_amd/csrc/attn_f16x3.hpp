@@ -554,7 +554,10 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t M
 }
 
 // number of key-range splits for a launch with `base_blocks` workgroups.
-//  * few workgroups (a scene or two): fill ~2 workgroups per CU, >= 4 tiles each;
+//  * at most half a round of the 512 resident workgroups (a scene or a few): the largest split count that still
+//    leaves ONE workgroup per CU (<= 256 workgroups) with >= 4 key tiles each - one scene (40 base workgroups) gets
+//    6 splits = 240 workgroups: measured 13.6 ms per 50-step call against 13.9 (4), 14.3 (8) and 19.1 (1)
+//    (tools/single_scene_sweep.py);
 //  * more than one "round" of the 512 resident workgroups: the smallest split count (<= 8, >= 4 tiles each) that
 //    fills the last round to >= 90 % - one dense scene (N=25, K=64: 600 workgroups = 1.17 rounds, 59 % efficient)
 //    becomes 2400 workgroups = 4.7 rounds (94 %).
@@ -562,7 +565,7 @@ inline int attn_pick_nsplit(int base_blocks, int S) {
     const int ntiles = (S + 31) / 32;
     if (base_blocks * 2 <= 512) {
         int ns = 1;
-        while (ns < 8 && base_blocks * ns * 2 <= 512 && ntiles / (ns * 2) >= 4) ns *= 2;
+        while (ns < 8 && base_blocks * (ns + 1) <= 256 && ntiles / (ns + 1) >= 4) ++ns;
         return ns;
     }
     auto eff = [&](int ns) {

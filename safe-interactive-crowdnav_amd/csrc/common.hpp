@@ -79,8 +79,7 @@ struct Tuning {
     int no_vt_direct = 0;    // 1: V row-major + v_transpose_kernel even when the fused V^T epilogue applies
     int attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
     int attn_pack = 1;       // 0 = one short sequence per wave even when S <= 16
-    int persist = 0;         // small-M persistent step kernel: 0 auto, 1 always (when applicable), 2 never
-    int ff_fuse = 0;         // fused linear1 -> ReLU -> linear2 + residual + LayerNorm: 0 auto, 1 always, 2 never
+    int attn_nsplit = 0;     // split-KV factor of the head_dim-128 attention launches: 0 auto, 1..16 forced
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS
     int gemm_abl = 0;
 };

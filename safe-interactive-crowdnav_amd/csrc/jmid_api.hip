@@ -643,6 +643,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     if (h->net_kind == JMID_NET_JMID && precision != JMID_PREC_F32 && h->d / h->nhead == 128) {
         const int S = K * A * T;
         ns_call = attn_pick_nsplit(((S + 127) / 128) * h->nhead * auto_chunk(h, E, S), S);
+        if (tune().attn_nsplit > 0) ns_call = std::min(tune().attn_nsplit, (S + 31) / 32);
     }
     // ---- workspace
     size_t io_off;
@@ -1201,8 +1202,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"no_vt_direct", &Tuning::no_vt_direct, 0, 1},         // 1: always V row-major + v_transpose_kernel
         {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
-        {"persist", &Tuning::persist, 0, 2},                   // small-M persistent step kernel: 0 auto, 1 always, 2 never
-        {"ff_fuse", &Tuning::ff_fuse, 0, 2},                   // fused linear1 -> linear2 + LayerNorm: 0 auto, 1 always, 2 never
+        {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
         {"gemm_abl", &Tuning::gemm_abl, 0, 1 << 30},

@@ -1,0 +1,274 @@
+"""Batched episode generator for the multi-episode evaluation sweeps.
+
+The reference produces the histories the predictor sees by stepping ``CrowdSimPlus`` one episode at a time
+(``crowd_sim_plus/envs/crowd_sim_plus.py:609-765`` reset, ``:1025-1258`` step), every human choosing its velocity
+with ORCA through Python-RVO2 (``crowd_sim_plus/envs/policy/orca.py:82-133``: a fresh simulator per step and per
+human, the human as agent 0, everybody else's preferred velocity (0, 0)).  For BASELINE configs 3 and 5 (256 - 4096
+parallel episodes) this module does the same for E episodes at once, in NumPy on the host: circle-crossing
+placement (``crowd_sim_plus.py:454-481``), agent-agent ORCA for every (episode, agent) pair in one vectorised pass
+(half-plane construction and the incremental 2-D linear programs of RVO2's ``Agent::computeNewVelocity`` /
+``linearProgram1-3``; van den Berg et al., ISRR 2011), holonomic position update.  It stays on the host like the
+rest of the simulator: a few thousand 2-D LPs with <= 10 constraints per step are microseconds of work next to the
+denoise loop, and the MPC side that consumes the same states lives there too.
+
+PARITY UNPINNED: rvo2 (RVO2 Library 2.0.2 behind Python-RVO2) is an un-vendored C++ dependency, absent from the
+reference tree and from this image, so no output of the reference's simulator exists to compare with.  What is
+checked (``tests/test_episodes.py``): equality with a scalar restatement of the published algorithm
+(``oracle/orca_oracle.py``), optimality against a brute-force search of the velocity disc, collision-freeness and
+goal progress of the generated crowds.  The shipped scenarios of the reference (``hallway*``, ``env.config:16-17``)
+additionally need RVO2's obstacle ORCA lines, door sub-goals and wall-constrained actions
+(``crowd_sim_plus.py:869-990``); those are not built - only the obstacle-free circle crossing is.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+RVO_EPSILON = 0.00001
+
+
+def _det(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    return a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+
+
+def _dot(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    return a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]
+
+
+# ------------------------------------------------------------------------------------------------ ORCA half-planes
+def orca_lines(pos, vel, radius, opos, ovel, orad, time_horizon: float, time_step: float):
+    """pos, vel [B, 2], radius [B]; the other agents opos, ovel [B, L, 2], orad [B, L].  Returns (point, direction)
+    [B, L, 2] each, neighbours ordered nearest first (RVO2 keeps its neighbour list sorted by distance)."""
+    rp = opos - pos[:, None, :]
+    dist_sq = _dot(rp, rp)
+    order = np.argsort(dist_sq, axis=1, kind="stable")
+    take = lambda a: np.take_along_axis(a, order if a.ndim == 2 else order[..., None], axis=1)
+    rp, dist_sq, ovel, orad = take(rp), take(dist_sq), take(ovel), take(orad)
+    rv = vel[:, None, :] - ovel
+    cr = radius[:, None] + orad
+    cr_sq = cr * cr
+    apart = dist_sq > cr_sq
+    inv_t = np.where(apart, 1.0 / time_horizon, 1.0 / time_step)[..., None]
+    w = rv - inv_t * rp
+    w_len_sq = _dot(w, w)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        w_len = np.sqrt(w_len_sq)
+        uw = w / w_len[..., None]
+        dp1 = _dot(w, rp)
+        # projection on the cut-off circle (also the whole collision case, with 1 / time_step)
+        circle = ~apart | ((dp1 < 0.0) & (dp1 * dp1 > cr_sq * w_len_sq))
+        dir_c = np.stack([uw[..., 1], -uw[..., 0]], axis=-1)
+        u_c = (cr * inv_t[..., 0] - w_len)[..., None] * uw
+        # projection on a leg of the velocity obstacle
+        leg = np.sqrt(np.where(apart, dist_sq - cr_sq, 1.0))
+        left = _det(rp, w) > 0.0
+        dl = np.stack([rp[..., 0] * leg - rp[..., 1] * cr, rp[..., 0] * cr + rp[..., 1] * leg], axis=-1) / dist_sq[..., None]
+        dr = -np.stack([rp[..., 0] * leg + rp[..., 1] * cr, -rp[..., 0] * cr + rp[..., 1] * leg], axis=-1) / dist_sq[..., None]
+        dir_l = np.where(left[..., None], dl, dr)
+        u_l = _dot(rv, dir_l)[..., None] * dir_l - rv
+    direction = np.where(circle[..., None], dir_c, dir_l)
+    u = np.where(circle[..., None], u_c, u_l)
+    return vel[:, None, :] + 0.5 * u, direction
+
+
+# ------------------------------------------------------------------------------------------------ linear programs
+def _lp1(P, D, active, i: int, radius, opt, direction_opt: bool, mask):
+    """linearProgram1 on constraint line i for the rows in ``mask``: the point of line i, inside the speed disc and
+    all earlier (active) lines, that is optimal.  Returns (ok [B], result [B, 2])."""
+    p, d = P[:, i], D[:, i]
+    dp = _dot(p, d)
+    disc = dp * dp + radius * radius - _dot(p, p)
+    ok = mask & (disc >= 0.0)
+    sq = np.sqrt(np.where(disc >= 0.0, disc, 0.0))
+    t_left, t_right = -dp - sq, -dp + sq
+    for j in range(i):
+        pj, dj = P[:, j], D[:, j]
+        den = _det(d, dj)
+        num = _det(dj, p - pj)
+        live = ok & active[:, j]
+        par = np.abs(den) <= RVO_EPSILON
+        ok = ok & ~(live & par & (num < 0.0))
+        upd = live & ~par & ok
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t = num / den
+        t_right = np.where(upd & (den >= 0.0), np.minimum(t_right, t), t_right)
+        t_left = np.where(upd & (den < 0.0), np.maximum(t_left, t), t_left)
+        ok = ok & ~(upd & (t_left > t_right))
+    if direction_opt:
+        t = np.where(_dot(opt, d) > 0.0, t_right, t_left)
+    else:
+        t = _dot(d, opt - p)
+        t = np.where(t < t_left, t_left, np.where(t > t_right, t_right, t))
+    return ok, p + t[:, None] * d
+
+
+def _lp2(P, D, active, radius, opt, direction_opt: bool, mask):
+    """linearProgram2 for the rows in ``mask``.  Returns (failed [B], fail_index [B], result [B, 2]); rows outside the
+    mask come back with failed = False and an unspecified result."""
+    L = P.shape[1]
+    if direction_opt:
+        result = opt * radius[:, None]
+    else:
+        n2 = _dot(opt, opt)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            scaled = opt / np.sqrt(n2)[:, None] * radius[:, None]
+        result = np.where((n2 > radius * radius)[:, None], scaled, opt)
+    alive = mask.copy()
+    failed = np.zeros_like(mask)
+    fail_idx = np.full(mask.shape, L, dtype=np.int64)
+    for i in range(L):
+        viol = alive & active[:, i] & (_det(D[:, i], P[:, i] - result) > 0.0)
+        if not viol.any():
+            continue
+        ok, r = _lp1(P, D, active, i, radius, opt, direction_opt, viol)
+        result = np.where((viol & ok)[:, None], r, result)
+        bad = viol & ~ok
+        failed |= bad
+        fail_idx = np.where(bad, i, fail_idx)
+        alive &= ~bad
+    return failed, fail_idx, result
+
+
+def _lp3(P, D, begin, radius, result, mask):
+    """linearProgram3: for rows whose program is infeasible, the velocity that violates the half-planes least."""
+    B, L, _ = P.shape
+    distance = np.zeros(B)
+    idx = np.arange(L)
+    for i in range(L):
+        pi, di = P[:, i], D[:, i]
+        cond = mask & (begin <= i) & (_det(di, pi - result) > distance)
+        if not cond.any():
+            continue
+        determinant = _det(di[:, None, :], D)                                   # [B, L]
+        par = np.abs(determinant) <= RVO_EPSILON
+        same = _dot(di[:, None, :], D) > 0.0
+        act = (idx[None, :] < i) & ~(par & same)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            t = _det(D, pi[:, None, :] - P) / determinant
+            point = np.where(par[..., None], 0.5 * (pi[:, None, :] + P), pi[:, None, :] + t[..., None] * di[:, None, :])
+            dd = D - di[:, None, :]
+            dd = dd / np.sqrt(_dot(dd, dd))[..., None]
+        point = np.where(act[..., None], point, 0.0)
+        dd = np.where(act[..., None], dd, 0.0)
+        opt = np.stack([-di[:, 1], di[:, 0]], axis=-1)
+        failed, _, r = _lp2(point, dd, act, radius, opt, True, cond)
+        result = np.where((cond & ~failed)[:, None], r, result)
+        distance = np.where(cond, _det(di, pi - result), distance)
+    return result
+
+
+def orca_velocities(pos, vel, radius, pref, max_speed, time_horizon: float = 2.0, time_step: float = 0.25):
+    """New ORCA velocity of EVERY agent of every episode, each as the ego of its own program (``orca.py:96-131``).
+
+    pos, vel, pref [E, n, 2]; radius, max_speed [E, n] (the radius already holds the + 0.01 + safety space the reference
+    adds).  Returns [E, n, 2].  n = 1 returns the preferred velocity clipped to the speed limit."""
+    E, n, _ = pos.shape
+    B = E * n
+    others = np.array([[j for j in range(n) if j != i] for i in range(n)], dtype=np.int64).reshape(n, max(n - 1, 0))
+    ego = lambda a: a.reshape((B,) + a.shape[2:])
+    oth = lambda a: a[:, others].reshape((B, n - 1) + a.shape[2:])
+    P, D = orca_lines(ego(pos), ego(vel), ego(radius), oth(pos), oth(vel), oth(radius), time_horizon, time_step)
+    active = np.ones((B, n - 1), dtype=bool)
+    allrows = np.ones(B, dtype=bool)
+    failed, fail_idx, result = _lp2(P, D, active, ego(max_speed), ego(pref), False, allrows)
+    if failed.any():
+        result = _lp3(P, D, fail_idx, ego(max_speed), result, failed)
+    return result.reshape(E, n, 2)
+
+
+# ------------------------------------------------------------------------------------------------ scenario + rollout
+@dataclass
+class CrowdConfig:
+    """The fields of ``configs/env.config`` / ``orca.py`` the circle-crossing simulation reads."""
+    time_step: float = 0.25                 # [env] time_step
+    circle_radius: float = 4.0              # [sim] circle_radius (CrowdNav's circle crossing; the shipped 1.0 is the hallway's)
+    human_radius: float = 0.20              # [humans] radius
+    human_v_pref: float = 1.5               # [humans] v_pref (drawn from U(0.5, 1.5) with randomize_attributes)
+    robot_radius: float = 0.25              # [robot] radius
+    robot_v_pref: float = 1.0               # [robot] v_pref
+    randomize_attributes: bool = True       # [env] randomize_attributes
+    discomfort_dist: float = 0.2            # [reward] discomfort_dist
+    safety_space: float = 0.0               # orca.py:61
+    time_horizon: float = 2.0               # orca.py:64
+    robot_visible: bool = True              # [robot] visible
+
+
+def circle_crossing_starts(E: int, N: int, rng: np.random.Generator, cfg: CrowdConfig) -> Dict[str, np.ndarray]:
+    """``generate_circle_crossing_human`` (``crowd_sim_plus.py:454-481``) for E episodes at once: humans one after the
+    other on a circle with positional noise, goal at the antipode, re-drawn while closer than radius + radius +
+    discomfort distance to any earlier agent's start or goal.  The robot starts at (0, -R), goal (0, R)."""
+    pos = np.zeros((E, N + 1, 2))
+    goal = np.zeros((E, N + 1, 2))
+    rad = np.full((E, N + 1), cfg.human_radius)
+    vp = np.full((E, N + 1), cfg.human_v_pref)
+    pos[:, 0] = (0.0, -cfg.circle_radius)
+    goal[:, 0] = (0.0, cfg.circle_radius)
+    rad[:, 0], vp[:, 0] = cfg.robot_radius, cfg.robot_v_pref
+    if cfg.randomize_attributes:
+        vp[:, 1:] = rng.uniform(0.5, 1.5, (E, N))
+    for h in range(1, N + 1):
+        todo = np.ones(E, dtype=bool)
+        for _ in range(10000):
+            k = int(todo.sum())
+            if k == 0:
+                break
+            angle = rng.random(k) * np.pi * 2
+            noise = (rng.random((k, 2)) - 0.5) * vp[todo, h][:, None]
+            p = cfg.circle_radius * np.stack([np.cos(angle), np.sin(angle)], axis=1) + noise
+            min_dist = cfg.human_radius + rad[todo, :h] + cfg.discomfort_dist
+            d_pos = np.linalg.norm(p[:, None, :] - pos[todo, :h], axis=2)
+            d_goal = np.linalg.norm(p[:, None, :] - goal[todo, :h], axis=2)
+            ok = ~((d_pos < min_dist) | (d_goal < min_dist)).any(axis=1)
+            rows = np.nonzero(todo)[0][ok]
+            pos[rows, h] = p[ok]
+            goal[rows, h] = -p[ok]
+            todo[rows] = False
+        else:
+            raise RuntimeError("circle crossing placement did not converge (circle too small for the crowd?)")
+    return dict(pos=pos, goal=goal, radius=rad, v_pref=vp)
+
+
+def simulate_circle_crossing(E: int, N: int, steps: int, seed: int, cfg: Optional[CrowdConfig] = None
+                             ) -> Dict[str, np.ndarray]:
+    """E independent circle-crossing episodes with N ORCA humans and an ORCA robot, ``steps`` simulator steps.
+
+    Returns human_xy [E, steps + 1, N, 2], robot_xy [E, steps + 1, 2], human_vel [E, steps + 1, N, 2], stamps
+    [steps + 1] and the start record (goals, radii, v_pref): what ``update_state_hists`` is fed step by step in the
+    reference's loop, for all episodes at once."""
+    cfg = cfg or CrowdConfig()
+    rng = np.random.default_rng(seed)
+    st = circle_crossing_starts(E, N, rng, cfg)
+    pos, goal = st["pos"].copy(), st["goal"]
+    vel = np.zeros_like(pos)
+    orca_rad = st["radius"] + 0.01 + cfg.safety_space               # orca.py:104-108
+    traj = np.zeros((E, steps + 1, N + 1, 2))
+    vels = np.zeros((E, steps + 1, N + 1, 2))
+    traj[:, 0] = pos
+    sl = slice(None) if cfg.robot_visible else slice(1, None)
+    for s in range(steps):
+        to_goal = goal - pos
+        speed = np.linalg.norm(to_goal, axis=2, keepdims=True)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            pref = np.where(speed > 1.0, to_goal / speed, to_goal)  # orca.py:113-115
+        new_vel = vel.copy()
+        new_vel[:, sl] = orca_velocities(pos[:, sl], vel[:, sl], orca_rad[:, sl], pref[:, sl], st["v_pref"][:, sl],
+                                         cfg.time_horizon, cfg.time_step)
+        if not cfg.robot_visible:       # humans do not see the robot; it still heads for its goal
+            new_vel[:, 0] = pref[:, 0] * np.minimum(1.0, st["v_pref"][:, 0])[:, None]
+        vel = new_vel
+        pos = pos + vel * cfg.time_step                             # holonomic step (agent.py compute_position)
+        traj[:, s + 1] = pos
+        vels[:, s + 1] = vel
+    return dict(human_xy=traj[:, :, 1:], robot_xy=traj[:, :, 0], human_vel=vels[:, :, 1:],
+                stamps=np.arange(steps + 1) * cfg.time_step, goal=goal, radius=st["radius"], v_pref=st["v_pref"])
+
+
+def history_windows(sim: Dict[str, np.ndarray], frame: int, num_hist_frames: int = 6) -> Tuple[np.ndarray, np.ndarray]:
+    """The last ``num_hist_frames`` frames ending at simulator step ``frame``: human_xy [E, F, N, 2], robot_xy [E, F, 2]
+    - the input of ``scene.build_scenes_batched`` / ``forecaster.predict_batch``."""
+    lo = frame - num_hist_frames + 1
+    if lo < 0:
+        raise ValueError("not enough simulated frames for a full history window")
+    return sim["human_xy"][:, lo:frame + 1], sim["robot_xy"][:, lo:frame + 1]

@@ -138,13 +138,13 @@ def test_forecaster_falls_back_to_fp32_when_fp16_range_is_exceeded(tmp_path):
     np.testing.assert_array_equal(outs[1], outs[2])
 
 
-@pytest.mark.parametrize("ctx_dim,joint,k_ret", [(32, True, 6), (32, False, 6), (256, True, 6), (32, True, 3)])
+@pytest.mark.parametrize("ctx_dim,joint,k_ret", [(32, True, 16), (32, False, 16), (256, True, 16), (32, True, 5)])
 def test_predict_batch_with_natural_clusters_matches_per_episode_forecaster(ctx_dim, joint, k_ret, tmp_path):
     """SURVEY 8f row f2 on the device path: a multi-episode batch with the reference's own clustering (the number of
     in-cluster pedestrians differs from episode to episode) through build_scenes_batched -> engine, against one
     HumanTrajectoryForecasterSim per episode fed the same histories and the same seed."""
     from safe_interactive_crowdnav_amd.forecaster import predict_batch
-    E, F, N, K, H, dt = 24, 6, 6, 6, 8, 0.25
+    E, F, N, K, H, dt = 24, 6, 6, 16, 8, 0.25
     rng = np.random.default_rng(17)
     pos0 = rng.uniform(-5.0, 5.0, (E, N, 2))
     vel = rng.uniform(-1.0, 1.0, (E, N, 2))
@@ -213,3 +213,26 @@ def test_predictor_output_feeds_the_mpc_parameter_layout(tmp_path):
     assert np.abs(p - p_ref).max() <= 5e-4 and np.abs(p - p_ref).mean() <= 1e-4     # forecasts within the ADE gate
     np.testing.assert_allclose(ours.goal_xy, ref.goal_xy, atol=1e-4)
     np.testing.assert_allclose(ours.v_pref, ref.v_pref, atol=2e-3)
+
+
+def test_predict_batch_on_generated_orca_crowds(tmp_path):
+    """SURVEY 8f rows f3 + f2 together on the device path: histories from the batched ORCA circle-crossing generator
+    (episodes.py), the reference's clustering, through the engine - against one forecaster per episode."""
+    from safe_interactive_crowdnav_amd.episodes import history_windows, simulate_circle_crossing
+    from safe_interactive_crowdnav_amd.forecaster import predict_batch
+    E, N, K, H, dt = 16, 5, 12, 8, 0.25
+    sim = simulate_circle_crossing(E, N, 14, seed=9)
+    hum, rob = history_windows(sim, 14)
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=32), 5)
+    env, ypath = write_configs(str(tmp_path), joint=True, ctx_dim=32, N=N, K=K, k_ret=K, H=H, step=2)
+    ref = []
+    for e in range(E):
+        f = HumanTrajectoryForecasterSim(env, ypath, weights=w)
+        for i in range(hum.shape[1]):
+            f.update_state_hists(State(rob[e, i]), [State(p) for p in hum[e, i]], float(sim["stamps"][14 - 5 + i]))
+        torch.manual_seed(77 + e)
+        ref.append(f.predict_ret_best()[0])
+    fc, lw, inc = predict_batch(f.engine, hum, rob, [77 + e for e in range(E)], num_samples=K, num_ret_samples=K,
+                                horizon=H, time_step=dt)
+    assert len(set(inc.sum(axis=1).tolist())) >= 2
+    np.testing.assert_array_equal(fc, np.stack(ref))

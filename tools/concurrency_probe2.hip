@@ -26,9 +26,9 @@ int run(AttnHArgs a, int nqt, int nblk, const float* x, float* y, size_t n, hipS
     int bad = 0; size_t nel = 0;
     for (int it = 0; it < niter; ++it) {
         hipMemsetAsync(y, 0xff, n * 4, s2); hipDeviceSynchronize();
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(victim<KIND>, dim3(4096), dim3(256), 0, s2, x, y, n);
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
         hipDeviceSynchronize();
         hipMemcpy(cur.data(), y, n * 4, hipMemcpyDeviceToHost);
         size_t d = 0; for (size_t i = 0; i < n; ++i) d += memcmp(&cur[i], &ref[i], 4) != 0;
@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
     a.Ohi = dev_rand_h(blk_plane_elems(M, d), 1.f); a.Olo = dev_rand_h(blk_plane_elems(M, d), 1.f);
     a.S = S; a.Spad = Spad; a.d = d; a.nhead = nhead; a.scale = 1.f; a.nsplit = 1;
     hipMalloc(&a.range_flag, 4); hipMemset(a.range_flag, 0, 4);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
     const size_t n = (size_t)4 << 20;
     std::vector<float> hx(n); for (size_t i = 0; i < n; ++i) hx[i] = 4.0f * ((rand() & 65535) - 32768) / 32768.0f;
     float *x, *y; hipMalloc(&x, n * 4); hipMalloc(&y, n * 4); hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice);

@@ -58,12 +58,12 @@ void run(AttnHArgs a, int nqt, int nblk, EmbedArgs e, float* out32, size_t M, in
     int bad = 0;
     for (int it = 0; it < niter; ++it) {
         hipMemsetAsync(buf, 0xff, nbytes, s2); hipDeviceSynchronize();
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
         hipLaunchKernelGGL(embed_var<FLAGS>, dim3(eblocks), dim3(256), 0, s2, e, out32);
         if (GKIND == 1) (void)launch_gemm_h_dma256<EPI_BIAS, OUT_F32>(G, s2);
         else if (GKIND == 2) (void)launch_gemm_h_cfg<2, 2, EPI_BIAS, OUT_F32>(G, s2);
         else if (GKIND == 3) (void)launch_gemm_h_dma256x256<EPI_BIAS, OUT_F32>(G, s2);
-        hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
+        hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
         hipDeviceSynchronize();
         hipMemcpy(cur.data(), buf, nbytes, hipMemcpyDeviceToHost);
         bad += memcmp(cur.data(), ref.data(), nbytes) != 0;
@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
     e.X = nullptr; e.M = (int)M; e.d = d; e.hyp_ld = hyp_ld; e.goff = 0; e.boff = d; e.rmap = RowMap{T, A, K * A};
     hipMalloc(&e.Xh, blk_plane_elems(M, d) * 2); hipMalloc(&e.Xl, blk_plane_elems(M, d) * 2);
     float* out32; hipMalloc(&out32, M * d * 4);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
     hipStream_t s1, s2; hipStreamCreate(&s1); hipStreamCreate(&s2);
     const int nqt = (S + 127) / 128, nblk = nqt * nhead * nseq, niter = argc > 1 ? atoi(argv[1]) : 300;
     GKIND = argc > 2 ? atoi(argv[2]) : 1;
@@ -107,5 +107,11 @@ int main(int argc, char** argv) {
     printf("consumer GEMM kind %d (0 none, 1 dma256, 2 register-staged 128x128, 3 dma256x256)\n", GKIND);
     run<0>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);
     run<1 | 2 | 4 | 16>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);
+    run<1>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);     // no sigmoid
+    run<2>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);     // fixed hyp row (no integer divisions for the row map)
+    run<4>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);     // no positional table
+    run<8>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);     // fp32 output, no split
+    run<16>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);    // no W1 / x part
+    run<1 | 2>(a, nqt, nblk, e, out32, M, d, s1, s2, niter);
     return 0;
 }

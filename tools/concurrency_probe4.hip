@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     a.Ohi = dev_rand_h(blk_plane_elems(M, d), 1.f); a.Olo = dev_rand_h(blk_plane_elems(M, d), 1.f);
     a.S = S; a.Spad = Spad; a.d = d; a.nhead = nhead; a.scale = 1.f; a.nsplit = 1;
     hipMalloc(&a.range_flag, 4); hipMemset(a.range_flag, 0, 4);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
     const size_t n = (size_t)4 << 20;
     std::vector<unsigned> hx(n), ref(n), cur(n);
     for (size_t i = 0; i < n; ++i) hx[i] = (unsigned)i;
@@ -62,9 +62,9 @@ int main(int argc, char** argv) {
         int bad = 0, shown = 0;
         for (int it = 0; it < niter; ++it) {
             hipMemsetAsync(y, 0xee, n * 4, s2); hipDeviceSynchronize();
-            hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
             launch();
-            hipLaunchKernelGGL(attn_f16x3_dma_kernel<false>, dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), dim3(nblk), dim3(256), ATT_DMA_LDS, s1, a, nqt, 0, (unsigned long long*)nullptr);
             hipDeviceSynchronize();
             hipMemcpy(cur.data(), y, n * 4, hipMemcpyDeviceToHost);
             size_t dcount = 0;
