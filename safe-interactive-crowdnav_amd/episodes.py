@@ -13,9 +13,9 @@ denoise loop, and the MPC side that consumes the same states lives there too.
 
 PARITY UNPINNED: rvo2 (RVO2 Library 2.0.2 behind Python-RVO2) is an un-vendored C++ dependency, absent from the
 reference tree and from this image, so no output of the reference's simulator exists to compare with.  What is
-checked (``tests/test_episodes.py``): equality with a scalar restatement of the published algorithm
-(``oracle/orca_oracle.py``), optimality against a brute-force search of the velocity disc, collision-freeness and
-goal progress of the generated crowds.  The shipped scenarios of the reference (``hallway*``, ``env.config:16-17``)
+checked (``tests/test_episodes.py``): equality with a scalar, one-agent-at-a-time restatement of the published
+algorithm kept with the test infrastructure, optimality against a brute-force search of the velocity disc,
+collision-freeness and goal progress of the generated crowds.  The shipped scenarios of the reference (``hallway*``, ``env.config:16-17``)
 additionally need RVO2's obstacle ORCA lines, door sub-goals and wall-constrained actions
 (``crowd_sim_plus.py:869-990``); those are not built - only the obstacle-free circle crossing is.
 """
