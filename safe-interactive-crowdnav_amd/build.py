@@ -20,7 +20,8 @@ def _newest_source_mtime() -> float:
 
 
 def library_path() -> str:
-    return LIB
+    """The in-tree library; JMID_LIB overrides it with an experimental build (tools/ only: A/B of kernel variants)."""
+    return os.environ.get("JMID_LIB") or LIB
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
