@@ -15,9 +15,9 @@ Default workload = BASELINE.json configs[2] ("256 parallel episodes x N=5 x K=20
 throughput target and the roofline are quoted on; the single-scene case (configs[1], E=1) is measured in the same run
 and reported under "single_scene".
 
-Precision modes.  `value` is the mode named by --precision (default f16x3: fp32-class three-term split products, the
-mode the drop-in predictor class `HumanTrajectoryForecasterSim` runs by default).  Every mode listed in --modes
-(default "f16x3,f16x2") gets THE SAME measurement - W warm-up steps, one untimed profiling step, K timed steps between
+Precision modes.  `value` is the mode named by --precision (default f16x2: fp16 activation x split-fp16 weight, the
+mode the drop-in predictor class `HumanTrajectoryForecasterSim` runs by default; >= the bf16 BASELINE.json names).
+Every mode listed in --modes (default "f16x2,f16x3"; f16x3 = fp32-class three-term products) gets THE SAME measurement - W warm-up steps, one untimed profiling step, K timed steps between
 barriers, parity against the oracle on the same episodes - and is reported under `modes[<name>]` with the same keys;
 the top-level keys are a copy of modes[--precision].  Prints ONE JSON line on rank 0.
 """
@@ -116,8 +116,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--episodes-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "f16x2"], help="the mode `value` is quoted on")
-    ap.add_argument("--modes", default="f16x3,f16x2",
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2"], help="the mode `value` is quoted on")
+    ap.add_argument("--modes", default="f16x2,f16x3",
                     help="comma list of modes measured identically in this run (the --precision mode is always included)")
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
