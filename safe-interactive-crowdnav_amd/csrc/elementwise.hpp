@@ -157,14 +157,11 @@ struct OutArgs {
     float c0, c1, sigma;
 };
 
-// one wave per token.  EMBED_NEXT: the wave goes on with the next step's embedding of its token (same arithmetic as
-// embed_kernel, with the next step's time parts `nxt.thyp`): one launch and one pass over x less per denoise step.
+// One token (one wave): final ConcatSquash + sampler update of x [+ EMBED_NEXT: the next step's embedding of the token,
+// same arithmetic as embed_kernel with the next step's time parts `nxt.thyp`].  `y` = the token's gated Y4 row (global
+// memory in out_ddim_kernel, the LDS tile of tail_f16x3_kernel).
 template <bool EMBED_NEXT>
-__global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (m >= a.M) return;
-    const float* y = a.Y4 + (size_t)m * a.dl;
+__device__ __forceinline__ void out_ddim_row(const OutArgs& a, const EmbedArgs& nxt, int m, int lane, const float* y) {
     float s0 = 0.f, s1 = 0.f;
     for (int c = lane; c < a.dl; c += 64) {
         const float v = y[c];
@@ -204,6 +201,15 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt)
         const float* hrow = nxt.hyp + (size_t)nxt.rmap.ea(m) * nxt.hyp_ld;
         for (int j = lane * 4; j < nxt.d; j += 256) embed_store(nxt, m, j, t, x0, x1, hrow);
     }
+}
+
+// one wave per token.  EMBED_NEXT: one launch and one pass over x less per denoise step.
+template <bool EMBED_NEXT>
+__global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    out_ddim_row<EMBED_NEXT>(a, nxt, m, lane, a.Y4 + (size_t)m * a.dl);
 }
 
 // ------------------------------------------------------------------------------------------------ integrator

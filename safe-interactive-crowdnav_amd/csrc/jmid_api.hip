@@ -20,6 +20,7 @@
 #include "gemm_f16x3.hpp"
 #include "gemm_ln_f16x3.hpp"
 #include "gemm_f32.hpp"
+#include "tail_f16x3.hpp"
 
 using namespace jmid;
 
@@ -384,6 +385,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     // embed_done: the previous step's output kernel already embedded x for this step; next_step >= 0: this step's
     // output kernel does the same for step `next_step` (same chunk, same buffers)
     const bool split = precision != JMID_PREC_F32;
+    bool tail_fused = false;
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
@@ -517,6 +519,10 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                     return rc;
             }
         }
+        // concat3 -> concat4 -> output layer -> sampler update -> next embedding in ONE kernel (tail_f16x3.hpp; bit-identical
+        // to the three launches below it replaces) at the shipped width
+        tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse != 2;
+        if (!tail_fused) {
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
         const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
@@ -529,9 +535,10 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
         g.goff = h->hl.g4; g.boff = h->hl.b4;
         if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
+        }
     }
     {
-        ProfScope ps(h, KC_OUT_DDIM);
+        ProfScope ps(h, tail_fused ? KC_GEMM_TAIL : KC_OUT_DDIM);
         OutArgs oa{sb.Y4, W(h, "linear._layer.weight"), W(h, "linear._layer.bias"), hyp_chunk, thyp, x_chunk, e_out,
                    M, h->dlow, h->hl.total, h->hl.go, h->hl.bo,
                    h->c_e[step_idx], h->c_x[step_idx], h->n_x[step_idx], h->n_e[step_idx], rm,
@@ -543,7 +550,17 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.c1 = h->p_c1[step_idx];
             oa.sigma = h->p_sigma[step_idx];
         }
-        if (next_step >= 0 && !e_out)
+        if (tail_fused) {
+            const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
+            const HalfPair& w4 = h->wsplit["concat4._layer.weight"];
+            TailArgs ta{sb.Xh, sb.Xl, w3.hi, w3.lo, w4.hi, w4.lo, W(h, "concat3._layer.bias"), W(h, "concat4._layer.bias"),
+                        hyp_chunk, thyp, h->hl.total, h->hl.g3, h->hl.b3, h->hl.g4, h->hl.b4, rm, M, h->range_flag};
+            const bool en = next_step >= 0 && !e_out;
+            // 32-row tiles while 64-row ones would leave CUs idle (a few scenes), 64-row tiles otherwise
+            const int rows = tune().tail_rows ? tune().tail_rows : (M < 64 * 256 ? 32 : 64);
+            HIPCHK(h, launch_tail(ta, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, rows,
+                                  h->x2 != 0, h->stream));
+        } else if (next_step >= 0 && !e_out)
             hipLaunchKernelGGL(out_ddim_kernel<true>, dim3((M + 3) / 4), dim3(256), bystander_lds(out_ddim_kernel<true>),
                                h->stream, oa, embed_args(h->thyp + (size_t)next_step * h->hl.total));
         else
@@ -1202,7 +1219,9 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"no_vt_direct", &Tuning::no_vt_direct, 0, 1},         // 1: always V row-major + v_transpose_kernel
         {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
-        {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
+        {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
+        {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 0 / 1 on, 2 off
+        {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
         {"gemm_abl", &Tuning::gemm_abl, 0, 1 << 30},
@@ -1228,7 +1247,8 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     }
     for (const Knob& kn : knobs)
         if (k == kn.name) {
-            if (value < kn.lo || value > kn.hi || (k == "ln_rows" && value != 0 && value != 64 && value != 128))
+            if (value < kn.lo || value > kn.hi || (k == "ln_rows" && value != 0 && value != 64 && value != 128) ||
+                (k == "tail_rows" && value != 0 && value != 32 && value != 64))
                 return fail(h, JMID_EINVAL, k + " out of range");
             h->tune.*(kn.field) = value;
             return JMID_OK;

@@ -114,3 +114,38 @@ def test_cfg4_full_geometry_matches_oracle(cfg4, precision):
     assert a <= ADE_GATE
     vel2, _ = cfg4["eng"].denoise(cfg4["x_T"].cuda(), cfg4["ctx"].cuda(), precision=precision, want_pos=False)
     assert torch.equal(vel, vel2)            # rerun determinism of the split-KV path
+
+
+def test_cfg5_one_gpu_shard_matches_oracle_on_every_chunk():
+    """BASELINE configs[4] as far as one GPU goes: the 512-episode shard one rank of the 8-GPU sweep processes (rank 3's
+    seeds: bench.py draws x_T of episode e on rank r from seed r * E + e), 50 steps, default mode.  One episode per chunk
+    of the call (512 = 2 x 52 + 8 x 51) against the oracle, per-episode sweep metrics against a host evaluation of the
+    same definition (MID/evaluation/evaluation.py:11-28)."""
+    E, A, K, T, rank = 512, 5, 20, 12, 3
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=256), 0)
+    eng = JmidEngine(w, joint=True, step=50)
+    syn = synthetic_episodes(E, A, seed=rank, horizon=T)
+    x_st = torch.from_numpy(syn["x_st"].reshape(E * A, 6, 6))
+    nbr = torch.from_numpy(syn["nbr_sum"].reshape(E * A, 2, 6, 6))
+    em = torch.from_numpy(syn["edge_mask"].reshape(E * A, 2))
+    p0, gt = torch.from_numpy(syn["p0"]), torch.from_numpy(syn["gt"])
+    x_T = torch.stack([torch.randn([K * A, T, 2], generator=torch.Generator().manual_seed(rank * E + e)) for e in range(E)])
+    ctx = eng.encode(x_st.cuda(), nbr.cuda(), em.cuda()).view(E, A, -1)
+    _, pos = eng.denoise(x_T.cuda(), ctx, p0.cuda(), dt=0.25, precision="f16x2", want_vel=False)
+    met = eng.episode_metrics(pos, gt.cuda()).cpu().numpy()
+    pos = pos.cpu().numpy()
+    picks = [25, 80, 130, 181, 232, 283, 334, 385, 436, 487, 511]      # one inside each of the 10 chunks + the last episode
+    _cpu_threads()
+    worst = 0.0
+    with torch.no_grad():
+        for e in picks:
+            c = O.encode_context(w.tensors, x_st[e * A:(e + 1) * A], nbr[e * A:(e + 1) * A], em[e * A:(e + 1) * A])
+            v = O.denoise(w.tensors, c, x_T[e], sample=K, step=50, joint=True)
+            ref = O.integrate(v, p0[e], 0.25).numpy()
+            worst = max(worst, ade(pos[e], ref))
+            d = np.linalg.norm(ref - gt[e].numpy()[None], axis=-1)                  # [K, A, T]
+            want = [d.mean(), d.mean(axis=(1, 2)).min(), d[:, :, -1].mean(), d[:, :, -1].mean(axis=1).min()]
+            np.testing.assert_allclose(met[e], want, rtol=2e-4, atol=2e-4)
+    print(f"cfg5 shard [f16x2]: worst sampled episode ADE vs oracle = {worst:.3e}")
+    assert worst <= ADE_GATE
+    eng.close()

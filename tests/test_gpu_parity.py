@@ -373,3 +373,34 @@ def test_output_kernel_with_fused_next_embedding_is_bit_identical(case, precisio
         eng.set_tuning("fuse_embed", 1)
         eng.set_step(int(z["step"]), "ddim")
     np.testing.assert_array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("precision", SPLIT_MODES)
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz",
+                                  "net_jmid_w256_a7k9t24_s10.npz", "ddpm_jmid_w256_a5k20t12_s10.npz"])
+def test_fused_tail_kernel_is_bit_identical_to_the_three_launches(case, precision):
+    """tail_f16x3_kernel (concat3 -> concat4 -> output layer -> DDIM / DDPM update -> next embedding, intermediates in
+    LDS) against concat3 GEMM + concat4 GEMM + out_ddim_kernel: same arithmetic in the same order, for both row tiles,
+    for the sampling loop and for a single net evaluation (e_theta out, no update)."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    ddpm = case.startswith("ddpm")
+    eng.set_step(int(z["step"]), "ddpm" if ddpm else "ddim")
+    kw = {"z": z["z"][:, None]} if ddpm else {}
+    out, e = {}, {}
+    try:
+        for fuse, rows in ((2, 0), (1, 32), (1, 64), (0, 0)):
+            eng.set_tuning("tail_fuse", fuse)
+            eng.set_tuning("tail_rows", rows)
+            out[(fuse, rows)] = eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False, **kw)[0][0]
+            if not ddpm:
+                e[(fuse, rows)] = eng.net_eval(z["x_T"][None], z["ctx"][None], step_idx=0, precision=precision)[0]
+    finally:
+        eng.set_tuning("tail_fuse", 0)
+        eng.set_tuning("tail_rows", 0)
+        eng.set_step(int(z["step"]), "ddim")
+    for k in ((1, 32), (1, 64), (0, 0)):
+        np.testing.assert_array_equal(out[k], out[(2, 0)])
+        if not ddpm:
+            np.testing.assert_array_equal(e[k], e[(2, 0)])
+    assert ade(out[(0, 0)], z["vel"]) <= ADE_GATE
