@@ -179,8 +179,9 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "fuse_embed"      0 = separate embedding kernel at the start of every step instead of the fused output kernel
  *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
  *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
- *   "tail_fuse"       concat3 -> concat4 -> output layer -> sampler update -> next embedding in one kernel (d_model 512):
- *                     0 / 1 on, 2 = the three separate launches; "tail_rows" its row tile (0 auto, 32, 64)
+ *   "tail_fuse"       1 = concat3 -> concat4 -> output layer -> sampler update -> next embedding in one kernel (d_model
+ *                     512; bit-identical, two launches fewer per step, measured slower: off by default), 0 / 2 = the three
+ *                     separate launches; "tail_rows" its row tile (0 auto, 32, 64)
  *   "attn_nsplit"     split-KV factor of the head_dim-128 attention launches: 0 auto (attn_pick_nsplit), 1..16 forced
  *   "gemm_ng", "print_occupancy"   diagnostics used by tools/
  *   "gemm_abl", "attn_abl"         timing ablations (WRONG results): exist only in builds with -DJMID_ABLATIONS

@@ -157,12 +157,14 @@ struct OutArgs {
     float c0, c1, sigma;
 };
 
-// One token (one wave): final ConcatSquash + sampler update of x [+ EMBED_NEXT: the next step's embedding of the token,
-// same arithmetic as embed_kernel with the next step's time parts `nxt.thyp`].  `y` = the token's gated Y4 row (global
-// memory in out_ddim_kernel, the LDS tile of tail_f16x3_kernel).
-template <bool EMBED_NEXT>
-__device__ __forceinline__ void out_ddim_row(const OutArgs& a, const EmbedArgs& nxt, int m, int lane, const float* y) {
-    float s0 = 0.f, s1 = 0.f;
+// The three pieces of the output stage of one token, shared by out_ddim_kernel (one wave per token, lane 0 updates) and
+// tail_f16x3_kernel (a wave works on several tokens at once, lane q updates token q): the same expressions, so the same bits.
+//   out_dot     partial dot products of the gated Y4 row `y` with the two rows of the output layer + wave reduction
+//   out_update  (one lane) final ConcatSquash gate / bias, then e_theta out or the DDIM / DDPM update of x in place
+//   embed_row   (whole wave) the next step's embedding of the token: embed_kernel's arithmetic with `nxt.thyp`
+__device__ __forceinline__ void out_dot(const OutArgs& a, const float* y, int lane, float& s0, float& s1) {
+    s0 = 0.f;
+    s1 = 0.f;
     for (int c = lane; c < a.dl; c += 64) {
         const float v = y[c];
         s0 += v * a.Wo[c];
@@ -170,37 +172,44 @@ __device__ __forceinline__ void out_ddim_row(const OutArgs& a, const EmbedArgs& 
     }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
-    float xn0 = 0.f, xn1 = 0.f;      // the updated x of this token (lane 0)
-    if (lane == 0) {
-        const float* hrow = a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld;
-        const float e0 = (s0 + a.bo[0]) * sigmoidf_(hrow[a.goff] + a.thyp[a.goff]) + hrow[a.boff] + a.thyp[a.boff];
-        const float e1 = (s1 + a.bo[1]) * sigmoidf_(hrow[a.goff + 1] + a.thyp[a.goff + 1]) + hrow[a.boff + 1] +
-                         a.thyp[a.boff + 1];
-        if (a.e_out) {
-            a.e_out[2 * (size_t)m] = e0;
-            a.e_out[2 * (size_t)m + 1] = e1;
+}
+__device__ __forceinline__ void out_update(const OutArgs& a, int m, float s0, float s1, float& xn0, float& xn1) {
+    const float* hrow = a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld;
+    const float e0 = (s0 + a.bo[0]) * sigmoidf_(hrow[a.goff] + a.thyp[a.goff]) + hrow[a.boff] + a.thyp[a.boff];
+    const float e1 = (s1 + a.bo[1]) * sigmoidf_(hrow[a.goff + 1] + a.thyp[a.goff + 1]) + hrow[a.boff + 1] +
+                     a.thyp[a.boff + 1];
+    if (a.e_out) {
+        a.e_out[2 * (size_t)m] = e0;
+        a.e_out[2 * (size_t)m + 1] = e1;
+    } else {
+        // x0 = (x - e*sqrt(1-abar_t))/sqrt(abar_t) ; x <- sqrt(abar_next)*x0 + sqrt(1-abar_next)*e
+        const float x0 = a.x[2 * (size_t)m], x1 = a.x[2 * (size_t)m + 1];
+        if (a.ddpm) {
+            const float z0 = a.z ? a.z[2 * (size_t)m] : 0.f, z1 = a.z ? a.z[2 * (size_t)m + 1] : 0.f;
+            a.x[2 * (size_t)m] = a.c0 * (x0 - a.c1 * e0) + a.sigma * z0;
+            a.x[2 * (size_t)m + 1] = a.c0 * (x1 - a.c1 * e1) + a.sigma * z1;
         } else {
-            // x0 = (x - e*sqrt(1-abar_t))/sqrt(abar_t) ; x <- sqrt(abar_next)*x0 + sqrt(1-abar_next)*e
-            const float x0 = a.x[2 * (size_t)m], x1 = a.x[2 * (size_t)m + 1];
-            if (a.ddpm) {
-                const float z0 = a.z ? a.z[2 * (size_t)m] : 0.f, z1 = a.z ? a.z[2 * (size_t)m + 1] : 0.f;
-                a.x[2 * (size_t)m] = a.c0 * (x0 - a.c1 * e0) + a.sigma * z0;
-                a.x[2 * (size_t)m + 1] = a.c0 * (x1 - a.c1 * e1) + a.sigma * z1;
-            } else {
-                const float p0 = (x0 - e0 * a.c_e) / a.c_x, p1 = (x1 - e1 * a.c_e) / a.c_x;
-                a.x[2 * (size_t)m] = a.n_x * p0 + a.n_e * e0;
-                a.x[2 * (size_t)m + 1] = a.n_x * p1 + a.n_e * e1;
-            }
-            xn0 = a.x[2 * (size_t)m];
-            xn1 = a.x[2 * (size_t)m + 1];
+            const float p0 = (x0 - e0 * a.c_e) / a.c_x, p1 = (x1 - e1 * a.c_e) / a.c_x;
+            a.x[2 * (size_t)m] = a.n_x * p0 + a.n_e * e0;
+            a.x[2 * (size_t)m + 1] = a.n_x * p1 + a.n_e * e1;
         }
+        xn0 = a.x[2 * (size_t)m];
+        xn1 = a.x[2 * (size_t)m + 1];
     }
-    if (EMBED_NEXT) {
-        const float x0 = __shfl(xn0, 0, 64), x1 = __shfl(xn1, 0, 64);
-        const int t = m % nxt.rmap.T;
-        const float* hrow = nxt.hyp + (size_t)nxt.rmap.ea(m) * nxt.hyp_ld;
-        for (int j = lane * 4; j < nxt.d; j += 256) embed_store(nxt, m, j, t, x0, x1, hrow);
-    }
+}
+__device__ __forceinline__ void embed_row(const EmbedArgs& nxt, int m, int lane, float x0, float x1) {
+    const int t = m % nxt.rmap.T;
+    const float* hrow = nxt.hyp + (size_t)nxt.rmap.ea(m) * nxt.hyp_ld;
+    for (int j = lane * 4; j < nxt.d; j += 256) embed_store(nxt, m, j, t, x0, x1, hrow);
+}
+
+template <bool EMBED_NEXT>
+__device__ __forceinline__ void out_ddim_row(const OutArgs& a, const EmbedArgs& nxt, int m, int lane, const float* y) {
+    float s0, s1;
+    out_dot(a, y, lane, s0, s1);
+    float xn0 = 0.f, xn1 = 0.f;      // the updated x of this token (lane 0)
+    if (lane == 0) out_update(a, m, s0, s1, xn0, xn1);
+    if (EMBED_NEXT) embed_row(nxt, m, lane, __shfl(xn0, 0, 64), __shfl(xn1, 0, 64));
 }
 
 // one wave per token.  EMBED_NEXT: one launch and one pass over x less per denoise step.

@@ -520,8 +520,10 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             }
         }
         // concat3 -> concat4 -> output layer -> sampler update -> next embedding in ONE kernel (tail_f16x3.hpp; bit-identical
-        // to the three launches below it replaces) at the shipped width
-        tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse != 2;
+        // to the three launches below it replaces) at the shipped width.  Opt-in: it saves two launches per step but runs
+        // four waves per CU, and measured slower than the three well-occupied kernels at every batch size (one scene
+        // 13.65 vs 13.23 ms per call, a 51-episode chunk +1.3 %; tools/single_scene_sweep.py tail_fuse=2,1)
+        tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse == 1;
         if (!tail_fused) {
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
@@ -551,8 +553,8 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.sigma = h->p_sigma[step_idx];
         }
         if (tail_fused) {
-            const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
-            const HalfPair& w4 = h->wsplit["concat4._layer.weight"];
+            const HalfPair& w3 = h->w16["concat3._layer.weight"];
+            const HalfPair& w4 = h->w16["concat4._layer.weight"];
             TailArgs ta{sb.Xh, sb.Xl, w3.hi, w3.lo, w4.hi, w4.lo, W(h, "concat3._layer.bias"), W(h, "concat4._layer.bias"),
                         hyp_chunk, thyp, h->hl.total, h->hl.g3, h->hl.b3, h->hl.g4, h->hl.b4, rm, M, h->range_flag};
             const bool en = next_step >= 0 && !e_out;
@@ -1038,10 +1040,19 @@ int jmid_finalize_weights(jmid_handle_t h) {
             HIPCHK(h, hipGetLastError());
             h->wsplit[nm] = hp;
         }
-        if (h->d == GLN_BN) {   // k16-panel copies for gemm_ln_f16x3_kernel (row-complete tiles need N == 512)
+        if (h->d == GLN_BN) {   // k16-panel copies for gemm_ln_f16x3_kernel (row-complete tiles need N == 512) and tail_f16x3_kernel
+            std::vector<std::string> k16names;
             for (int l = 0; l < h->tf_layer; ++l) {
                 const std::string p = "transformer_encoder.layers." + std::to_string(l);
-                for (const std::string nm : {p + ".self_attn.out_proj.weight", p + ".linear2.weight"}) {
+                k16names.push_back(p + ".self_attn.out_proj.weight");
+                k16names.push_back(p + ".linear2.weight");
+            }
+            if (h->dmid == TAIL_DM && h->dlow == TAIL_DL) {
+                k16names.push_back("concat3._layer.weight");
+                k16names.push_back("concat4._layer.weight");
+            }
+            {
+                for (const std::string& nm : k16names) {
                     const DevBuf& b = h->w[nm];
                     const std::vector<size_t>& shp = h->expected[nm];   // [512, K]
                     HalfPair hp;
@@ -1220,7 +1231,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
-        {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 0 / 1 on, 2 off
+        {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
