@@ -1,47 +1,44 @@
 #!/bin/bash
-# All measurements that profiles/ holds for a round, in one GPU-box call.  Output: gpurun_out/final/
-#   tools/round_profile.sh            (about 6-8 minutes)
-#   JMID_PREC=f16x3 SKIP_BENCH=1 tools/round_profile.sh   -> kernel stats and PMC traffic of the other mode
+# All measurements profiles/ holds for a round, in one GPU-box call (about 6 minutes).  Output: gpurun_out/$R/
+#   R=r02 tools/round_profile.sh ; then python tools/update_profiles.py r02
 export TMPDIR=/tmp
-export JMID_PREC=${JMID_PREC:-f16x2}
-P=$JMID_PREC
-O=gpurun_out/final
+R=${R:-r02}
+O=gpurun_out/$R
 mkdir -p $O
-if [ -z "$SKIP_BENCH" ]; then
-timeout 400 python bench.py --precision f16x2 --cpu-episodes 3 > $O/bench_cfg3_f16x2.log 2>&1
-timeout 400 python bench.py --precision f16x3 --cpu-episodes 3 > $O/bench_cfg3_f16x3.log 2>&1
-timeout 300 python bench.py --precision f32 --cpu-episodes 0 --steps 2 > $O/bench_cfg3_f32.log 2>&1
-timeout 300 python bench.py --workload cfg2 --cpu-episodes 0 --steps 20 --warmup 3 > $O/bench_cfg2.log 2>&1
-timeout 300 python bench.py --workload cfg4 --cpu-episodes 0 --steps 3 > $O/bench_cfg4.log 2>&1
-timeout 400 python bench.py --workload cfg5 --cpu-episodes 0 --steps 2 > $O/bench_cfg5_1gpu.log 2>&1
-timeout 300 python bench.py --net imid --cpu-episodes 0 --steps 2 > $O/bench_cfg3_imid.log 2>&1
-fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --precision $P --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$P.log 2>&1
-find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${P}_kernel_stats.csv \;
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_attn_$c -- python tools/attn_only.py > /dev/null 2>&1
-  timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_gemm_$c -- python tools/gemm_only.py 0 > /dev/null 2>&1
+# default bench (BASELINE configs[2]), both split modes measured identically, parity sample over all chunks
+timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
+timeout 300 python bench.py --precision f32 --modes f32 --cpu-episodes 0 --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
+timeout 300 python bench.py --workload cfg2 --cpu-episodes 0 --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
+timeout 300 python bench.py --workload cfg4 --cpu-episodes 0 --steps 3 > $O/bench_cfg4.json 2>/dev/null
+timeout 400 python bench.py --workload cfg5 --cpu-episodes 0 --steps 2 > $O/bench_cfg5_1gpu.json 2>/dev/null
+timeout 300 python bench.py --net imid --cpu-episodes 0 --steps 2 > $O/bench_cfg3_imid.json 2>/dev/null
+timeout 300 python bench.py --scenes orca --cpu-episodes 4 --steps 2 > $O/bench_cfg3_orca.json 2>/dev/null
+# episodes per call sweep (weak-scaling unit), both modes
+for e in 1 2 4 8 16 32 52 104 256 512; do
+  timeout 300 python bench.py --cpu-episodes 0 --episodes-per-gpu $e --steps 2 --warmup 1 --no-profile 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('episodes/call', $e, {m: (v['value'], v['ms_per_step']) for m, v in d['modes'].items()})"
+done > $O/episode_sweep.log
+# rocprofv3 kernel stats of one step on a 51-episode chunk, per mode
+for m in f16x2 f16x3; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
+  find $O/prof_$m -name "*kernel_stats.csv" -exec cp {} $O/${m}_kernel_stats.csv \;
+  rm -rf $O/prof_$m
 done
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_call_$c -- python tools/step_only.py 51 > /dev/null 2>&1
-done
-python - <<'PY'
-import csv, glob, json, collections
-out = {}
-for tag in ("attn", "gemm", "call"):
-    for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        acc = collections.defaultdict(list)
-        for f in glob.glob(f"gpurun_out/final/pmc_{tag}_{c}/**/*counter_collection.csv", recursive=True):
-            for r in csv.DictReader(open(f)):
-                if r.get("Counter_Name") == c:
-                    acc[r["Kernel_Name"][:60]].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            out[f"{tag}:{c}:{k}"] = {"launches": len(v), "avg": sum(v) / len(v)}
-        if tag == "call":
-            out[f"call_total:{c}"] = sum(sum(v) for v in acc.values())
-import os
-json.dump(out, open(f"gpurun_out/final/pmc_raw_{os.environ['JMID_PREC']}.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in out.items() if not k.startswith('call:')}, indent=1)[:4000])
-PY
-for f in $O/bench_*.log; do echo "== $f"; tail -1 $f | cut -c1-260; done
-rm -rf $O/prof $O/pmc_attn_* $O/pmc_gemm_* $O/pmc_call_*
+# single-scene kernel stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --workload cfg2 --modes f16x2 --steps 20 --warmup 3 --cpu-episodes 0 --no-profile > $O/prof_bench_cfg2.log 2>&1
+find $O/prof_ss -name "*kernel_stats.csv" -exec cp {} $O/cfg2_f16x2_kernel_stats.csv \;
+rm -rf $O/prof_ss
+# PMC: HBM bytes and MFMA busy per production kernel over one whole call
+JMID_PREC=f16x2 tools/pmc_call.sh > $O/pmc_x2.log 2>&1
+JMID_PREC=f16x3 tools/pmc_call.sh > $O/pmc_x3.log 2>&1
+cp gpurun_out/pmc/pmc_call_f16x2.json gpurun_out/pmc/pmc_call_f16x3.json $O/
+# reproducibility soak of the default path + the documented multi-lane disturbance
+python tools/rerun_soak.py f16x2 20 103 1 > $O/soak.log 2>&1
+python tools/rerun_soak.py f16x3 20 103 1 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16x2 6 103 2 2>&1 | tail -3 >> $O/soak.log
+python tools/rerun_soak.py f16x2 6 103 2 0 bystander_lds=98304 2>&1 | tail -1 >> $O/soak.log
+for f in $O/bench_*.json; do echo "== $f"; python -c "
+import json,sys
+d=json.load(open('$f')); print(d['value'], d['ms_per_step'], d.get('single_scene',{}).get('ms_per_call'), {m:(v['value'], v.get('parity',{}).get('mean_ADE_vs_oracle_m')) for m,v in d['modes'].items()})"; done
+cat $O/episode_sweep.log; grep -v amdgpu $O/soak.log | tail -8
