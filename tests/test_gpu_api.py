@@ -97,3 +97,61 @@ def test_two_engines_coexist():
     assert np.abs(a1 - b).max() > 1e-3
     e1.close()
     e2.close()
+
+
+def test_device_mode_calls_are_ordered_against_the_callers_stream():
+    """JMID_MEM_DEVICE buffers are produced and consumed on the CALLER's stream (include/jmid_hip.h, Conventions): the
+    library's private stream waits for what the caller enqueued before the call and the caller's stream waits for the
+    call's last kernel.  Inputs that are still being computed on a non-default torch stream when the call is made, and
+    outputs consumed on that stream right after it, must give the synchronous answer."""
+    import torch
+    from safe_interactive_crowdnav_amd.engine import JmidEngine
+    from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=32), 3)
+    eng = JmidEngine(w, joint=True, step=10)
+    E, A, K, T = 6, 3, 4, 6
+    g = torch.Generator().manual_seed(2)
+    ctx0 = torch.randn([E, A, 32], generator=g).cuda()
+    x0 = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    p0 = torch.randn([E, A, 2], generator=g).cuda()
+    big = torch.randn([4096, 4096], device="cuda")
+    torch.cuda.synchronize()
+    ref_vel, ref_pos = eng.denoise(x0 * 2.0 - x0, ctx0 + 0.0, p0, precision="f32")     # default stream, synchronous reference
+    eng.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(8):                      # keep the side stream busy: the inputs below are produced behind this
+                big = (big @ big).clamp_(-1.0, 1.0)
+            x_in = x0 * 2.0 - x0                    # producer kernels of the inputs, on the side stream
+            c_in = ctx0 + 0.0
+            vel, pos = eng.denoise(x_in, c_in, p0, precision="f32")    # f32: returns without a host sync
+            chk = (pos - ref_pos).abs().max() + (vel - ref_vel).abs().max()     # consumer on the side stream
+        assert float(chk.item()) == 0.0
+    eng.close()
+
+
+def test_tuning_knobs_belong_to_their_handle():
+    """jmid_set_tuning acts on the handle it is called on, never on another engine of the process."""
+    import numpy as np
+    import torch
+    from safe_interactive_crowdnav_amd.engine import JmidEngine
+    from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=256), 3)
+    a, b = JmidEngine(w, joint=True, step=4), JmidEngine(w, joint=True, step=4)
+    g = torch.Generator().manual_seed(4)
+    ctx = torch.randn([1, 5, 256], generator=g).numpy()
+    x_T = torch.randn([1, 40, 12, 2], generator=g).numpy()
+    base = b.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0]
+    a.set_tuning("attn_nsplit", 1)                  # changes the order a sequence's keys are summed in: rounding-level
+    a.set_tuning("lanes", 3)
+    a.set_chunk_episodes(1)
+    out_a = a.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0]
+    out_b = b.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0]
+    np.testing.assert_array_equal(out_b, base)      # engine b never saw engine a's knobs
+    assert not np.array_equal(out_a, base) and np.abs(out_a - base).max() < 1e-4
+    for key in ("attn_abl", "gemm_abl"):            # timing ablations (wrong results) do not exist in the production build
+        with pytest.raises(Exception):
+            a.set_tuning(key, 1)
+    a.close()
+    b.close()
