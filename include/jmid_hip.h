@@ -182,11 +182,12 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "tail_fuse"       1 = concat3 -> concat4 -> output layer -> sampler update -> next embedding in one kernel (d_model
  *                     512; bit-identical, two launches fewer per step, measured slower: off by default), 0 / 2 = the three
  *                     separate launches; "tail_rows" its row tile (0 auto, 32, 64)
+ *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T with direct 8-byte stores instead of full rows through LDS
  *   "attn_nsplit"     split-KV factor of the head_dim-128 attention launches: 0 auto (attn_pick_nsplit), 1..16 forced
  *   "gemm_ng", "print_occupancy"   diagnostics used by tools/
  *   "gemm_abl", "attn_abl"         timing ablations (WRONG results): exist only in builds with -DJMID_ABLATIONS
  * Every knob belongs to the handle it is set on.  All variants of a key compute the same values (bit-identical for
- * gemm_h_variant, ln_fuse, ln_rows, tail_fuse, tail_rows and no_vt_direct).  Unknown keys return JMID_EINVAL. */
+ * gemm_h_variant, ln_fuse, ln_rows, tail_fuse, tail_rows, vt_stage and no_vt_direct).  Unknown keys return JMID_EINVAL. */
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream.
  * mask: bit i enables class i (see jmid_kernel_class_name); 0 disables.  Timers accumulate until reset. */

@@ -573,6 +573,66 @@ inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// V^T through LDS (256x256 kernel, OUT_QKV, head_dim 128).  The direct V^T epilogue above writes 8 bytes per lane: one
+// wave instruction touches 32 V^T rows with 16 contiguous bytes each, and a 128-byte line is assembled from eight such
+// pieces - the V^T stores alone cost 40 us (F16X2) / 87 us (F16X3) of a 61 200-token QKV launch (a build without them:
+// 172.5 -> 166.4 / 215.7 -> 202.6 ms per 51-episode call).  Here a wave's 64 keys x 128 head-dim tile is transposed in
+// the wave's own 16 KB of the (finished) operand ring - rows = head dim, 128 contiguous bytes = 64 keys in the
+// vt_key_pos order, 16-byte chunks XOR-swizzled by the row - and written with 16 bytes per lane: eight lanes cover the
+// 128 contiguous bytes of one V^T row.  Same values as the direct path (same arithmetic per element).
+// Needs the wave's 64 tokens inside one sequence, starting at a multiple of 16 keys; otherwise returns false.
+template <bool X2>
+__device__ __forceinline__ bool vt_staged_store(const GemmHArgs& g, f32x16 (&acc)[2][4], int mrow0, int ncol0, half_t* wlds,
+                                                int l31, int hi, int lane) {
+    const int seq = mrow0 / g.S, key0 = mrow0 - seq * g.S;
+    if (mrow0 + 64 > g.M || key0 + 64 > g.S || (key0 & 15) != 0) return false;
+    const int nn0 = ncol0 - 2 * g.d, head = nn0 / g.hd, nh = g.d / g.hd;
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = g.bias ? g.bias[ncol0 + j * 32 + l31] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
+    bool overflow = false;
+    half_t* dst_base[2] = {g.Vthi, g.Vtlo};
+#pragma unroll
+    for (int plane = 0; plane < (X2 ? 1 : 2); ++plane) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int vc = j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f16x4 pv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[j]);
+                        half_t hh, ll;
+                        split_f32_unscaled(v, hh, ll);
+                        if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax);
+                        pv[e] = plane == 0 ? hh : ll;
+                    }
+                    const int pos = vt_key_pos(i * 32 + 8 * q + 4 * hi);      // first of 4 consecutive stored positions
+                    *reinterpret_cast<f16x4*>(wlds + vc * 64 + ((((pos >> 3) ^ (vc & 7)) << 3) | (pos & 4))) = pv;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        half_t* dst = dst_base[plane] + (((size_t)seq * nh + head) * g.hd) * g.Spad + key0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int row = t * 8 + (lane >> 3), c = lane & 7;
+            const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 64 + ((c ^ (row & 7)) << 3));
+            *reinterpret_cast<f16x8*>(dst + (size_t)row * g.Spad + c * 8) = v8;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 256x256 LDS-DMA variant (N a multiple of 256: in_proj 1536, linear1 1024): 8 waves (4 along M x 2 along N), wave tile
 // 64 x 128 - possible since the product needs ONE accumulator set (128 VGPRs).  A third fewer operand bytes per FLOP
 // through L2 -> LDS and a quarter fewer fragment reads per MFMA than the 256x128 tile.  64 KB stages, 2-stage ring
@@ -582,7 +642,7 @@ constexpr int DMA3_STAGE = 8 * DMA_PLANE;                 // Ahi(2 images), Alo(
 constexpr size_t DMA3_LDS_BYTES = size_t(2) * DMA3_STAGE * sizeof(half_t);
 
 template <int EPI, int OUT, bool X2 = false>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int burst) {
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int burst, int stage_vt) {
     constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
@@ -686,6 +746,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (OUT == OUT_QKV) {
+        // a V tile (block-uniform: n0 is a multiple of 256 and d_model of 128): V^T goes out through LDS in full rows
+        if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && stage_vt) {
+            __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
+            if (vt_staged_store<X2>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
+        }
+    }
     gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
@@ -697,7 +764,8 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
     }
-    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (gemm_abl_bits() & 8) ? 0 : 1);
+    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (gemm_abl_bits() & 8) ? 0 : 1,
+                       tune().vt_stage != 2 ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -404,3 +404,30 @@ def test_fused_tail_kernel_is_bit_identical_to_the_three_launches(case, precisio
         if not ddpm:
             np.testing.assert_array_equal(e[k], e[(2, 0)])
     assert ade(out[(1, 0)], z["vel"]) <= ADE_GATE
+
+
+@pytest.mark.parametrize("precision", SPLIT_MODES)
+def test_vt_through_lds_is_bit_identical_to_direct_stores(precision):
+    """256x256 QKV kernel: V^T written in full rows through LDS (vt_staged_store) against the direct 8-byte stores and
+    against the row-major V + transpose kernel, on a batch whose 64-token wave tiles straddle sequence boundaries
+    (1200 = 18.75 x 64: those waves fall back to the direct path) and end in a partial row tile (E * 1200 % 256 != 0)."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(4)
+    E, A, K, T = 19, 5, 20, 12
+    g = torch.Generator().manual_seed(13)
+    ctx = torch.randn([E, A, 256], generator=g).cuda()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    out = {}
+    try:
+        for stage, novt in ((0, 0), (2, 0), (0, 1)):
+            eng.set_tuning("vt_stage", stage)
+            eng.set_tuning("no_vt_direct", novt)
+            out[(stage, novt)] = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
+    finally:
+        eng.set_tuning("vt_stage", 0)
+        eng.set_tuning("no_vt_direct", 0)
+    np.testing.assert_array_equal(out[(0, 0)], out[(2, 0)])
+    np.testing.assert_array_equal(out[(0, 0)], out[(0, 1)])
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True)
+    assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
