@@ -77,6 +77,14 @@ struct jmid_ctx {
     Tuning tune;         // jmid_set_tuning knobs of THIS handle (installed per call by TuneScope)
     hipStream_t caller_stream = nullptr;   // stream device-mode buffers are ordered on (jmid_set_caller_stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // captured denoise loops of small calls (one chunk): key = (E, A, K, T, precision) -> executable graph
+    struct LoopGraph {
+        hipGraphExec_t exec = nullptr;
+        char* arena = nullptr;      // the workspace the graph's kernels point into
+        bool warm = false;          // the loop ran eagerly once with this key (per-device kernel attributes are set)
+    };
+    std::map<std::string, LoopGraph> graphs;
+    int64_t graph_replays = 0;
     int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
@@ -224,8 +232,15 @@ int fetch_host(jmid_ctx* h, const std::string& name, std::vector<float>& out) {
 
 const float* W(jmid_ctx* h, const std::string& name) { return h->w[name].p; }
 
+void drop_graphs(jmid_ctx* h) {
+    for (auto& kv : h->graphs)
+        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+    h->graphs.clear();
+}
+
 int ensure_arena(jmid_ctx* h, size_t bytes) {
     if (bytes <= h->arena_bytes) return 0;
+    drop_graphs(h);
     if (h->arena) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipFree(h->arena));
@@ -251,6 +266,7 @@ struct Carver {
 
 // upload the per-step time part of the four hyper nets: thyp[i][j] = w0*beta + w1*sin(beta) + w2*cos(beta)
 int upload_time_table(jmid_ctx* h) {
+    drop_graphs(h);        // the captured loops hold the old table's pointer and the old step coefficients
     if (!h->finalized || h->beta.empty()) return 0;
     const int n = (int)h->beta.size(), tot = h->hl.total;
     std::vector<float> t((size_t)n * tot);
@@ -734,7 +750,31 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         for (int l = 1; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l - 1], h->ev_fork, 0));
     }
-    for (int c0 = 0; c0 < nchunks; c0 += lanes) {
+    // Small calls (one chunk, at most a few scenes): the whole denoise loop - n_steps x ~28 dependent launches on workspace
+    // buffers only - is captured into a hipGraph the second time a shape is seen and replayed afterwards: one graph launch
+    // instead of ~1400 kernel launches per call.  The GPU-side time is the same chain of kernels (a kernel boundary costs
+    // the same inside a graph); what goes away is the host's launch work (~3.5 us per launch), which the MPC solve that
+    // shares the host with the predictor gets back.  Inputs / outputs (copies, hyper-net GEMM, integrator) stay outside.
+    jmid_ctx::LoopGraph* lg = nullptr;
+    bool capturing = false;
+    if (single_step < 0 && lanes == 1 && nchunks == 1 && !h->prof_mask && !z_use && !h->ddpm && tune().graph != 2 &&
+        tune().bystander_lds == 0 && (M <= 16384 || tune().graph == 1)) {
+        const std::string key = std::to_string(E) + "," + std::to_string(A) + "," + std::to_string(K) + "," + std::to_string(T) +
+                                "," + std::to_string(precision);
+        lg = &h->graphs[key];
+        if (lg->exec && lg->arena != h->arena) {        // never true today (ensure_arena drops the graphs); cheap to keep
+            hipGraphExecDestroy(lg->exec);
+            lg->exec = nullptr;
+        }
+        if (lg->exec) {
+            HIPCHK(h, hipGraphLaunch(lg->exec, h->stream));
+            ++h->graph_replays;
+        } else if (lg->warm) {
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            capturing = true;
+        }
+    }
+    for (int c0 = 0; c0 < nchunks && !(lg && lg->exec); c0 += lanes) {
         if (single_step >= 0) {
             const int e0 = chunk_start[c0], ec = chunk_sizes[c0];
             float* eo = stage + (size_t)e0 * K * A * T * 2;
@@ -755,9 +795,31 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
                 const int rc = net_step(h, sbs[l], ec, A, K, T, i, xc, hc, nullptr, precision, zc, tune().fuse_embed && i > 0,
                                         tune().fuse_embed && i + 1 < n_steps ? i + 1 : -1);
                 if (l > 0) std::swap(h->stream, h->lane_stream[l - 1]);
-                if (rc) return rc;
+                if (rc) {
+                    if (capturing) {
+                        hipGraph_t dead = nullptr;
+                        (void)hipStreamEndCapture(h->stream, &dead);
+                        if (dead) hipGraphDestroy(dead);
+                    }
+                    return rc;
+                }
             }
         }
+    }
+    if (capturing) {
+        hipGraph_t graph = nullptr;
+        HIPCHK(h, hipStreamEndCapture(h->stream, &graph));
+        hipError_t ge = hipGraphInstantiate(&lg->exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ge != hipSuccess) {
+            lg->exec = nullptr;
+            return fail(h, JMID_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
+        }
+        lg->arena = h->arena;
+        HIPCHK(h, hipGraphLaunch(lg->exec, h->stream));
+        ++h->graph_replays;
+    } else if (lg && !lg->exec) {
+        lg->warm = true;
     }
     for (int l = 1; l < lanes; ++l) {
         HIPCHK(h, hipEventRecord(h->ev_join[l - 1], h->lane_stream[l - 1]));
@@ -856,6 +918,7 @@ int jmid_destroy(jmid_handle_t h) {
     if (!h) return JMID_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    drop_graphs(h);
     for (auto& kv : h->w) hipFree(kv.second.p);
     for (auto* m : {&h->wsplit, &h->w16})
         for (auto& kv : *m) {
@@ -901,6 +964,7 @@ int jmid_load_weight(jmid_handle_t h, const char* name, const float* host_data, 
     DevBuf& b = h->w[name];
     if (!b.p) HIPCHK(h, hipMalloc((void**)&b.p, n_elems * sizeof(float)));
     b.n = n_elems;
+    drop_graphs(h);
     HIPCHK(h, hipMemcpy(b.p, host_data, n_elems * sizeof(float), hipMemcpyHostToDevice));
     h->finalized = false;
     return JMID_OK;
@@ -1208,6 +1272,7 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
     if (!h || episodes < 0) return JMID_EINVAL;
     h->chunk_eps = episodes;
+    drop_graphs(h);
     return JMID_OK;
 }
 
@@ -1231,6 +1296,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
         {"vt_stage", &Tuning::vt_stage, 0, 2},                 // V^T of the 256x256 QKV kernel through LDS: 0 / 1 on, 2 off
+        {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop: 0 auto (one chunk, <= 16384 tokens), 1 any one-chunk call, 2 never
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
@@ -1263,10 +1329,13 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
                 (k == "tail_rows" && value != 0 && value != 32 && value != 64))
                 return fail(h, JMID_EINVAL, k + " out of range");
             h->tune.*(kn.field) = value;
+            drop_graphs(h);          // captured loops hold the kernel variants the old knobs selected
             return JMID_OK;
         }
     return fail(h, JMID_EINVAL, "unknown tuning key " + k);
 }
+
+int64_t jmid_graph_replays(jmid_handle_t h) { return h ? h->graph_replays : -1; }
 
 int jmid_set_caller_stream(jmid_handle_t h, void* stream) {
     if (!h) return JMID_EINVAL;

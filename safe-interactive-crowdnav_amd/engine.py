@@ -120,6 +120,10 @@ class JmidEngine:
             self._caller_stream = st
         return _lib.MEM_DEVICE
 
+    def graph_replays(self) -> int:
+        """Calls whose denoise loop ran as a replayed hipGraph (small one-chunk calls from their third repetition on)."""
+        return int(self._lib.jmid_graph_replays(self._h))
+
     def synchronize(self) -> None:
         self._check(self._lib.jmid_synchronize(self._h))
 

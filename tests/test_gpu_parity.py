@@ -431,3 +431,50 @@ def test_vt_through_lds_is_bit_identical_to_direct_stores(precision):
     with torch.no_grad():
         ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True)
     assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_captured_denoise_loop_replays_bit_identically(precision):
+    """Small one-chunk calls: the 50-step loop runs eagerly the first time a shape is seen, is captured into a hipGraph
+    the second time and replayed from then on - same kernels in the same order, so the same bits; a new step table, a
+    tuning knob or another shape must never replay a stale graph."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(10)
+    g = torch.Generator().manual_seed(21)
+    ctx = torch.randn([2, 5, 256], generator=g).numpy()
+    x_T = torch.randn([2, 100, 12, 2], generator=g).numpy()
+    p0 = torch.randn([2, 5, 2], generator=g).numpy()
+    try:
+        eng.set_tuning("graph", 2)
+        ref = eng.denoise(x_T, ctx, p0, precision=precision)
+        ref1 = eng.denoise(x_T[:1], ctx[:1], p0[:1], precision=precision)
+        eng.set_tuning("graph", 0)
+        n0 = eng.graph_replays()
+        outs = [eng.denoise(x_T, ctx, p0, precision=precision) for _ in range(4)]        # eager, capture + launch, replay, replay
+        assert eng.graph_replays() - n0 == 3
+        for o in outs:
+            np.testing.assert_array_equal(o[0], ref[0])
+            np.testing.assert_array_equal(o[1], ref[1])
+        # other inputs through the same graph (the graph holds workspace pointers, not the caller's data)
+        o2 = eng.denoise(x_T[::-1].copy(), ctx[::-1].copy(), p0[::-1].copy(), precision=precision)
+        np.testing.assert_array_equal(o2[0][::-1], ref[0])
+        # another shape gets its own graph
+        for _ in range(3):
+            o1 = eng.denoise(x_T[:1], ctx[:1], p0[:1], precision=precision)
+        np.testing.assert_array_equal(o1[0], ref1[0])
+        # a new step table drops the captured loops
+        eng.set_step(5)
+        eng.set_tuning("graph", 2)
+        ref5 = eng.denoise(x_T, ctx, p0, precision=precision)
+        eng.set_tuning("graph", 0)
+        for _ in range(3):
+            o5 = eng.denoise(x_T, ctx, p0, precision=precision)
+        np.testing.assert_array_equal(o5[0], ref5[0])
+        assert not np.array_equal(ref5[0], ref[0])
+        # device-mode call, same shape
+        od = eng.denoise(torch.from_numpy(x_T).cuda(), torch.from_numpy(ctx).cuda(), torch.from_numpy(p0).cuda(),
+                         precision=precision)
+        np.testing.assert_array_equal(od[0].cpu().numpy(), ref5[0])
+    finally:
+        eng.set_tuning("graph", 0)
+        eng.set_step(50)
