@@ -186,9 +186,10 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     512; bit-identical, two launches fewer per step, measured slower: off by default), 0 / 2 = the three
  *                     separate launches; "tail_rows" its row tile (0 auto, 32, 64)
  *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T with direct 8-byte stores instead of full rows through LDS
- *   "graph"           the denoise loop of a one-chunk call as a captured hipGraph, replayed from the third call with the same
- *                     (E, A, K, T, precision) on: 0 auto (<= 16384 tokens), 1 any one-chunk call, 2 never.  Same kernels in
- *                     the same order (bit-identical); one graph launch instead of ~28 x n_steps kernel launches per call
+ *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with
+ *                     the same (E, A, K, T, precision) on (same kernels in the same order: bit-identical; one graph launch
+ *                     instead of ~28 x n_steps kernel launches; measured 0-3 % SLOWER than the eager launches, so off by
+ *                     default), 0 / 2 = eager launches
  *   "attn_nsplit"     split-KV factor of the head_dim-128 attention launches: 0 auto (attn_pick_nsplit), 1..16 forced
  *   "gemm_ng", "print_occupancy"   diagnostics used by tools/
  *   "gemm_abl", "attn_abl"         timing ablations (WRONG results): exist only in builds with -DJMID_ABLATIONS

@@ -80,7 +80,7 @@ struct Tuning {
     int attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
     int attn_pack = 1;       // 0 = one short sequence per wave even when S <= 16
     int vt_stage = 0;        // 256x256 QKV kernel: V^T through LDS in full rows (0 / 1 on, 2 = direct 8-byte stores)
-    int graph = 0;           // captured denoise loop (hipGraph) of one-chunk calls: 0 auto (<= 16384 tokens), 1 always, 2 never
+    int graph = 0;           // captured denoise loop (hipGraph) of one-chunk calls: 1 on, 0 / 2 off (default: not faster, see jmid_api.hip)
     int attn_nsplit = 0;     // split-KV factor of the head_dim-128 attention launches: 0 auto, 1..16 forced
     int tail_fuse = 0;       // tail of the net in one kernel (tail_f16x3.hpp, d_model 512): 1 on, 0 / 2 off (default: slower, see jmid_api.hip)
     int tail_rows = 0;       // its row tile: 0 auto, 32, 64

@@ -750,15 +750,17 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
         for (int l = 1; l < lanes; ++l) HIPCHK(h, hipStreamWaitEvent(h->lane_stream[l - 1], h->ev_fork, 0));
     }
-    // Small calls (one chunk, at most a few scenes): the whole denoise loop - n_steps x ~28 dependent launches on workspace
-    // buffers only - is captured into a hipGraph the second time a shape is seen and replayed afterwards: one graph launch
-    // instead of ~1400 kernel launches per call.  The GPU-side time is the same chain of kernels (a kernel boundary costs
-    // the same inside a graph); what goes away is the host's launch work (~3.5 us per launch), which the MPC solve that
-    // shares the host with the predictor gets back.  Inputs / outputs (copies, hyper-net GEMM, integrator) stay outside.
+    // Opt-in (jmid_set_tuning "graph" = 1) for one-chunk calls: the whole denoise loop - n_steps x ~28 dependent launches on
+    // workspace buffers only - is captured into a hipGraph the second time a shape is seen and replayed afterwards: one
+    // graph launch instead of ~1400 kernel launches per call, bit-identical.  Measured on MI355X / ROCm 7.2
+    // (tools/graph_latency.py): it does not pay - the GPU-side time is the same chain of kernels (a kernel boundary costs
+    // the same inside a graph) and the replay itself is slower than the eager launches that run ahead of the GPU: one
+    // scene 13.51 vs 13.08 ms per call, 4 scenes 28.40 vs 28.29, 8 scenes equal.  Off by default.
+    // Inputs / outputs (copies, hyper-net GEMM, integrator) stay outside the graph.
     jmid_ctx::LoopGraph* lg = nullptr;
     bool capturing = false;
-    if (single_step < 0 && lanes == 1 && nchunks == 1 && !h->prof_mask && !z_use && !h->ddpm && tune().graph != 2 &&
-        tune().bystander_lds == 0 && (M <= 16384 || tune().graph == 1)) {
+    if (single_step < 0 && lanes == 1 && nchunks == 1 && !h->prof_mask && !z_use && !h->ddpm && tune().graph == 1 &&
+        tune().bystander_lds == 0) {
         const std::string key = std::to_string(E) + "," + std::to_string(A) + "," + std::to_string(K) + "," + std::to_string(T) +
                                 "," + std::to_string(precision);
         lg = &h->graphs[key];
@@ -1296,7 +1298,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
         {"vt_stage", &Tuning::vt_stage, 0, 2},                 // V^T of the 256x256 QKV kernel through LDS: 0 / 1 on, 2 off
-        {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop: 0 auto (one chunk, <= 16384 tokens), 1 any one-chunk call, 2 never
+        {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced

@@ -435,9 +435,9 @@ def test_vt_through_lds_is_bit_identical_to_direct_stores(precision):
 
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_captured_denoise_loop_replays_bit_identically(precision):
-    """Small one-chunk calls: the 50-step loop runs eagerly the first time a shape is seen, is captured into a hipGraph
-    the second time and replayed from then on - same kernels in the same order, so the same bits; a new step table, a
-    tuning knob or another shape must never replay a stale graph."""
+    """Opt-in ("graph" = 1) for one-chunk calls: the 50-step loop runs eagerly the first time a shape is seen, is captured
+    into a hipGraph the second time and replayed from then on - same kernels in the same order, so the same bits; a new
+    step table, a tuning knob or another shape must never replay a stale graph."""
     eng, w = get_engine(256, 23, True)
     eng.set_step(10)
     g = torch.Generator().manual_seed(21)
@@ -448,7 +448,7 @@ def test_captured_denoise_loop_replays_bit_identically(precision):
         eng.set_tuning("graph", 2)
         ref = eng.denoise(x_T, ctx, p0, precision=precision)
         ref1 = eng.denoise(x_T[:1], ctx[:1], p0[:1], precision=precision)
-        eng.set_tuning("graph", 0)
+        eng.set_tuning("graph", 1)
         n0 = eng.graph_replays()
         outs = [eng.denoise(x_T, ctx, p0, precision=precision) for _ in range(4)]        # eager, capture + launch, replay, replay
         assert eng.graph_replays() - n0 == 3
@@ -466,7 +466,7 @@ def test_captured_denoise_loop_replays_bit_identically(precision):
         eng.set_step(5)
         eng.set_tuning("graph", 2)
         ref5 = eng.denoise(x_T, ctx, p0, precision=precision)
-        eng.set_tuning("graph", 0)
+        eng.set_tuning("graph", 1)
         for _ in range(3):
             o5 = eng.denoise(x_T, ctx, p0, precision=precision)
         np.testing.assert_array_equal(o5[0], ref5[0])

@@ -14,7 +14,7 @@ g = torch.Generator().manual_seed(3)
 ctx = torch.randn([E, A, 256], generator=g).cuda()
 x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
 p0 = torch.randn([E, A, 2], generator=g).cuda()
-for mode, name in ((2, "eager launches"), (0, "captured graph")):
+for mode, name in ((2, "eager launches"), (1, "captured graph")):
     eng.set_tuning("graph", mode)
     for _ in range(5):
         eng.denoise(x_T, ctx, p0, precision=prec, want_vel=False)
