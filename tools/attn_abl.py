@@ -1,3 +1,8 @@
+# Timing ablations of the kernel (results are WRONG by construction).  NEEDS A BUILD WITH -DJMID_ABLATIONS - the production
+# library has no ablation knobs:
+#   (cd safe-interactive-crowdnav_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value \
+#        -ffp-contract=off -DJMID_ABLATIONS -o ../../build/libjmid_abl.so jmid_api.hip)
+#   JMID_LIB=build/libjmid_abl.so python tools/attn_abl.py
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
