@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = host gather (lets several ranks share one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (-1 = LOCAL_RANK)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run every collective even with one rank (exercises the RCCL calls "
+                         "of the N > 1 path on a one-GPU box)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,7 +147,8 @@ def main():
     torch.cuda.set_device(dev_id)
     dev = torch.device("cuda", dev_id)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -191,12 +195,12 @@ def main():
         vel, pos = eng.denoise(x_T, ctx.view(E, A, -1), p0, dt=0.25, precision=precision, want_vel=False)
         met = eng.episode_metrics(pos, gt)
         eng.synchronize()            # the library runs on its own stream
-        allm = gather_metrics(met, E * world)
+        allm = gather_metrics(met, E * world, force=args.force_dist)
         return pos, met, allm
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -229,7 +233,7 @@ def main():
             pos, met, allm = one_step(precision)
         barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
@@ -312,7 +316,7 @@ def main():
         results[m], last_pos[m] = measure(m)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -327,7 +331,7 @@ def main():
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
                    "episodes_per_gpu": E, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
                    "net": args.net, "precision": args.precision, "lanes": args.lanes, "scenes": args.scenes,
-                   "dist_backend": args.dist_backend if world > 1 else None},
+                   "dist_backend": args.dist_backend if use_dist else None},
     }
     for k in ("roofline", "kernels", "hbm", "sweep_metrics"):
         if k in head:
@@ -413,7 +417,7 @@ def main():
                                     "episode_ids": pick, "precision": m}
         out["parity"] = results[args.precision]["parity"]
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -20,10 +20,11 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_metrics(local: torch.Tensor, total: int, dst: int = 0) -> Optional[np.ndarray]:
+def gather_metrics(local: torch.Tensor, total: int, dst: int = 0, force: bool = False) -> Optional[np.ndarray]:
     """Gather per-episode metric rows [E_local, M] from every rank to ``dst`` in episode order.
-    One collective of a few KB (latency-bound; payload is independent of the model size)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    One collective of a few KB (latency-bound; payload is independent of the model size).  ``force`` runs the collective
+    even in a one-rank group (tests of the RCCL call on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return local.detach().cpu().numpy()
     world, rank = dist.get_world_size(), dist.get_rank()
     if dist.get_backend() == "gloo" and local.is_cuda:     # host collective (CPU tests; several ranks sharing one GPU)

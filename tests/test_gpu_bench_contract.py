@@ -83,3 +83,23 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert sm["mean_ADE_m"] > 0 and sm["mean_ADE_m"] == sm["mean_ADE_m"]     # no NaN padding rows leaked through
     # whole-job rate: 2 ranks x 5 episodes x 5 humans x 20 samples per step
     assert abs(j["value"] - 2 * 5 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+
+
+def test_bench_collectives_run_on_rccl_with_one_rank():
+    """The RCCL flavour of the N > 1 path, as far as one GPU allows: a one-rank "nccl" process group (torchrun, the
+    driver's launch line with --nproc-per-node 1) with --force-dist, so that init_process_group(device_id=...), the
+    barriers, the MAX all-reduce of a device tensor and gather_metrics' dist.gather of device tensors all go through
+    RCCL.  What is left for the driver's 8-GPU run is only that these same calls see more than one rank."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                          "--gpus", "1", "--steps", "2", "--warmup", "1", "--episodes-per-gpu", "4", "--force-dist",
+                          "--dist-backend", "nccl", "--modes", "f16x2", "--cpu-episodes", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    j = _one_json_line(out)
+    assert j["n_gpus"] == 1 and j["config"]["dist_backend"] == "nccl" and j["sweep_metrics"]["episodes"] == 4
+    assert j["value"] > 0
