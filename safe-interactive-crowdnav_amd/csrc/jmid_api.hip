@@ -860,7 +860,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* jmid_version(void) { return "jmid_hip 0.4.0 (gfx950; f32-mfma + f16x3 / f16x2 split-mfma)"; }
+const char* jmid_version(void) { return "jmid_hip 0.5.0 (gfx950; f32-mfma + f16x3 / f16x2 split-mfma)"; }
 
 int jmid_device_count(void) {
     int n = 0;
