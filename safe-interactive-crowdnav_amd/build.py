@@ -33,8 +33,14 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libjmid_hip.so")
+    # -packed-fp32-ops: no v_pk_{add,mul,fma}_f32 in the device code.  hipcc forms them with crossed operand selects
+    # (op_sel:[0,1] op_sel_hi:[1,0]) for float4 arithmetic, and on MI355X such an instruction returns wrong values in
+    # lanes 48-63 when its wave shares a CU with waves of the LDS-DMA attention kernel (tools/concurrency_probe8.hip: 397 of
+    # 400 overlaps, 0 with straight selects or other co-runners) - the cause of the run-to-run variation with several
+    # chunks in flight.  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
+    # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
-           "-o", LIB] + SOURCES
+           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

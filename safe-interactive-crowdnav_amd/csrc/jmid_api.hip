@@ -69,11 +69,12 @@ struct jmid_ctx {
     static constexpr int kMaxLanes = 4;
     hipStream_t lane_stream[kMaxLanes - 1] = {nullptr, nullptr, nullptr};   // extra lanes of the chunk loop
     hipEvent_t ev_fork = nullptr, ev_join[kMaxLanes - 1] = {nullptr, nullptr, nullptr};
-    // chunks in flight at once, 1..4 (jmid_set_tuning "lanes").  Default 1: two lanes are ~5 % faster, but kernels of
-    // different chunks running concurrently on two streams were seen to change a few episodes by 1e-4..1e-2 per run
-    // (not reproducible run to run; every kernel alone and every single-stream run is bit-reproducible; see
-    // tools/concurrency_probe.hip and DESIGN.md) - opt-in until that is understood.
-    int lanes = 1;
+    // chunks in flight at once, 1..4 (jmid_set_tuning "lanes").  Two by default: the partially filled last round of one
+    // chunk's kernels and its bandwidth-bound kernels overlap with the other chunk's MFMA kernels (+2-4 % traj/s), and the
+    // results are bit-identical to one chunk in flight.  (They were not in round 1: a row-wise kernel sharing a CU with
+    // attention workgroups of the other lane computed a few wrong values per run - packed-fp32 instructions with crossed
+    // operand selects, which the library is no longer built with; build.py)
+    int lanes = 2;
     Tuning tune;         // jmid_set_tuning knobs of THIS handle (installed per call by TuneScope)
     hipStream_t caller_stream = nullptr;   // stream device-mode buffers are ordered on (jmid_set_caller_stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;

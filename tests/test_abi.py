@@ -61,3 +61,28 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("# oracle-free", ""), f"{f} mentions the oracle"
+
+
+def test_device_code_holds_no_packed_fp32_instructions(tmp_path):
+    """build.py compiles with -packed-fp32-ops: v_pk_{add,mul,fma}_f32 with crossed operand selects go wrong in lanes 48-63
+    when their wave shares a CU with the LDS-DMA attention kernel (tools/concurrency_probe8.hip), and
+    hipcc forms exactly those for float4 arithmetic.  The shipped library must not contain any."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(REPO, "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(lib)):
+        pytest.skip("needs llvm-objdump and the built library")
+    work = tmp_path / "libjmid_hip.so"
+    shutil.copy(lib, work)
+    subprocess.run([objdump, "--offloading", str(work)], check=True, capture_output=True, cwd=tmp_path)
+    images = [p for p in os.listdir(tmp_path) if "amdgcn" in p]
+    assert images, "no device code object in the library"
+    n_kernels = 0
+    for img in images:
+        dis = subprocess.run([objdump, "-d", str(tmp_path / img)], check=True, capture_output=True, text=True).stdout
+        assert "v_mfma_f32_32x32x16_f16" in dis                  # it is the gfx950 code of the kernels
+        n_kernels += dis.count("<_ZN4jmid")
+        for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):
+            assert op not in dis, f"{op} found in the device code: build with -Xclang -target-feature -Xclang -packed-fp32-ops"
+    assert n_kernels > 50

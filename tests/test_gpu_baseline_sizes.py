@@ -149,3 +149,23 @@ def test_cfg5_one_gpu_shard_matches_oracle_on_every_chunk():
     print(f"cfg5 shard [f16x2]: worst sampled episode ADE vs oracle = {worst:.3e}")
     assert worst <= ADE_GATE
     eng.close()
+
+
+@pytest.mark.parametrize("precision", SPLIT_MODES)
+def test_cfg3_chunks_in_flight_do_not_change_a_bit(cfg3, precision):
+    """256 episodes at full width with 1, 2 (default), 3 and 4 chunks in flight on separate streams: the same bits, call after
+    call.  This is the regression test of the round-1 lane disturbance: a row-wise kernel next to the other
+    lane's attention workgroups computed wrong values in lanes 48-63 through packed-fp32 instructions with crossed operand
+    selects (tools/concurrency_probe8.hip); the library is built without packed-fp32 instructions."""
+    eng = cfg3["eng"]
+    try:
+        eng.set_tuning("lanes", 1)
+        ref = eng.denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision=precision, want_vel=False)[1].clone()
+        for lanes in (2, 2, 3, 4, 2):
+            eng.set_tuning("lanes", lanes)
+            pos = eng.denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision=precision, want_vel=False)[1]
+            assert torch.equal(pos, ref), f"lanes={lanes}: {int((pos != ref).any(dim=-1).sum())} points differ"
+    finally:
+        eng.set_tuning("lanes", 2)
+    per = {e: ade(ref[e].cpu().numpy(), cfg3["ref"][e]) for e in cfg3["picks"]}
+    assert max(per.values()) <= ADE_GATE

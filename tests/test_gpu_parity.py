@@ -301,10 +301,11 @@ def test_edge_shapes_match_oracle(shape, joint, precision):
     assert np.isfinite(vel).all() and a <= ADE_GATE
 
 
-def test_chunk_lanes_single_lane_is_reproducible_and_lanes_stay_close():
-    """One chunk in flight (the default): reruns are bit-identical.  Several chunks in flight on separate streams
-    (jmid_set_tuning "lanes", opt-in) compute the same thing, but concurrent kernels of different chunks were seen to
-    move a few episodes by up to 1e-2 on MI355X (tools/concurrency_probe.hip): held to that level only."""
+def test_chunk_lanes_are_bit_identical():
+    """Several chunks in flight on separate streams (jmid_set_tuning "lanes", 2 by default) compute the same bits as one
+    chunk in flight.  (In round 1 they did not: packed-fp32 instructions with crossed operand selects in the row-wise
+    kernels went wrong next to the other lane's attention workgroups - the library is built without them now, DESIGN.md
+    section 3; tests/test_abi.py checks the device code.)"""
     eng, w = get_engine(32, 77, True)
     eng.set_step(10)
     E, A, K, T = 7, 3, 4, 6
@@ -316,19 +317,19 @@ def test_chunk_lanes_single_lane_is_reproducible_and_lanes_stay_close():
         eng.set_tuning("lanes", 1)
         ref = eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0]
         np.testing.assert_array_equal(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref)
-        for lanes in (2, 3, 4):      # a single disturbed episode of the 7 (1e-2 at worst) must not fail the suite
+        for lanes in (2, 3, 4):
             eng.set_tuning("lanes", lanes)
-            assert ade(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref) <= 2e-3
-        # row-wise kernels kept off the CUs of the MFMA kernels by an LDS request they never use: same values
+            np.testing.assert_array_equal(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref)
+        # row-wise kernels kept off the CUs of the MFMA kernels by an LDS request they never use (round-1 workaround): same values
         eng.set_tuning("bystander_lds", 96 * 1024)
         for lanes in (1, 2):
             eng.set_tuning("lanes", lanes)
-            assert ade(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref) <= ADE_GATE
+            np.testing.assert_array_equal(eng.denoise(x_T, ctx, precision="f16x3", want_pos=False)[0], ref)
         with pytest.raises(Exception):
             eng.set_tuning("bystander_lds", 1 << 20)
     finally:
         eng.set_tuning("bystander_lds", 0)
-        eng.set_tuning("lanes", 1)
+        eng.set_tuning("lanes", 2)
         eng.set_chunk_episodes(0)
 
 
