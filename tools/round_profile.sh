@@ -21,7 +21,7 @@ d=json.loads(sys.stdin.read()); print('episodes/call', $e, {m: (v['value'], v['m
 done > $O/episode_sweep.log
 # rocprofv3 kernel stats of one step on a 51-episode chunk, per mode
 for m in f16x2 f16x3; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
   find $O/prof_$m -name "*kernel_stats.csv" -exec cp {} $O/${m}_kernel_stats.csv \;
   rm -rf $O/prof_$m
 done
@@ -34,10 +34,18 @@ JMID_PREC=f16x2 tools/pmc_call.sh > $O/pmc_x2.log 2>&1
 JMID_PREC=f16x3 tools/pmc_call.sh > $O/pmc_x3.log 2>&1
 cp gpurun_out/pmc/pmc_call_f16x2.json gpurun_out/pmc/pmc_call_f16x3.json $O/
 # reproducibility soak of the default path + the documented multi-lane disturbance
-python tools/rerun_soak.py f16x2 20 103 1 > $O/soak.log 2>&1
-python tools/rerun_soak.py f16x3 20 103 1 >> $O/soak.log 2>&1
-python tools/rerun_soak.py f16x2 6 103 2 2>&1 | tail -3 >> $O/soak.log
-python tools/rerun_soak.py f16x2 6 103 2 0 bystander_lds=98304 2>&1 | tail -1 >> $O/soak.log
+# reproducibility soak: one chunk in flight, and 2 / 3 / 4 chunks in flight against the one-chunk reference (bitwise)
+python tools/rerun_soak.py f16x2 20 256 1 > $O/soak.log 2>&1
+python tools/rerun_soak.py f16x3 20 256 1 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16x2 20 256 2 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16x3 20 256 2 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16x2 10 256 3 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16x3 10 256 4 >> $O/soak.log 2>&1
+# the instruction-level reproduction of what used to disturb them (needs build/concurrency_probe8, tools/concurrency_probe8.hip)
+if [ -x build/concurrency_probe8 ]; then for c in 3 1 0; do timeout 300 ./build/concurrency_probe8 300 $c; done > $O/packed_fp32_probe.log 2>&1; fi
+# lanes 1 / 2 / 3 on the default batch
+python tools/single_scene_sweep.py lanes=1,2,3 f16x2 256 2>/dev/null | grep ms > $O/lanes.log
+python tools/single_scene_sweep.py lanes=1,2,3 f16x3 256 2>/dev/null | grep ms >> $O/lanes.log
 for f in $O/bench_*.json; do echo "== $f"; python -c "
 import json,sys
 d=json.load(open('$f')); print(d['value'], d['ms_per_step'], d.get('single_scene',{}).get('ms_per_call'), {m:(v['value'], v.get('parity',{}).get('mean_ADE_vs_oracle_m')) for m,v in d['modes'].items()})"; done

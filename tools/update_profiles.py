@@ -4,14 +4,14 @@ import json, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = f"gpurun_out/{R}", "profiles"
 names = ["bench_cfg3.json", "bench_cfg3_f32.json", "bench_cfg2.json", "bench_cfg4.json", "bench_cfg5_1gpu.json", "bench_cfg3_imid.json",
-         "bench_cfg3_orca.json", "episode_sweep.log", "soak.log", "pmc_call_f16x2.json", "pmc_call_f16x3.json"]
+         "bench_cfg3_orca.json", "episode_sweep.log", "soak.log", "packed_fp32_probe.log", "lanes.log", "pmc_call_f16x2.json", "pmc_call_f16x3.json"]
 for n in names:
     if os.path.exists(f"{src}/{n}"):
         shutil.copy(f"{src}/{n}", f"{dst}/{R}_{n}")
 if os.path.exists(f"{src}/bench_cfg3.err"):
     shutil.copy(f"{src}/bench_cfg3.err", f"{dst}/{R}_bench_cfg3.stderr.log")
-hdr = {"f16x2": "python bench.py --precision f16x2 --modes f16x2 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
-       "f16x3": "python bench.py --precision f16x3 --modes f16x3 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
+hdr = {"f16x2": "python bench.py --precision f16x2 --modes f16x2 --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
+       "f16x3": "python bench.py --precision f16x3 --modes f16x3 --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
        "cfg2_f16x2": "python bench.py --workload cfg2 --modes f16x2 --steps 20 --warmup 3 --cpu-episodes 0 --no-profile"}
 for tag, cmd in hdr.items():
     f = f"{src}/{tag}_kernel_stats.csv"
