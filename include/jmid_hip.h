@@ -174,8 +174,8 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
  *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 8192 tokens), 1 always, 2 never
  *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
- *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 1; > 1 is ~5 %
- *                     faster but results were seen to vary from run to run - see DESIGN.md)
+ *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 2: +2-4 % on batches
+ *                     of several chunks; bit-identical to 1 - see DESIGN.md section 3 for what used to prevent that)
  *   "bystander_lds"   bytes of dynamic LDS (0..163840, default 0) the row-wise kernels request without using them, so
  *                     that they never share a CU with an attention / GEMM workgroup of another lane (>= 65536 made
  *                     lanes > 1 reproducible in every soak run so far)
