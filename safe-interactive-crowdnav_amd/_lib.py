@@ -12,8 +12,8 @@ Handle = C.c_void_p
 
 NET_IMID, NET_JMID = 0, 1
 MEM_HOST, MEM_DEVICE = 0, 1
-PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X2 = 0, 1, 2, 3
-PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16, "f16x2": PREC_F16X2}
+PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X2, PREC_F16MX = 0, 1, 2, 3, 4
+PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16, "f16x2": PREC_F16X2, "f16mx": PREC_F16MX}
 
 ERR_NAMES = {-1: "JMID_EINVAL", -2: "JMID_ENOWEIGHT", -3: "JMID_EHIP", -4: "JMID_ENOMEM", -5: "JMID_ERANGE"}
 

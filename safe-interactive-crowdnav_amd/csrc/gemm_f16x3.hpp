@@ -20,6 +20,7 @@
 // Q / K / V^T planes of the attention kernel (V is stored key-contiguous so that the PV product needs no
 // transpose on the way into the MFMA).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 #include "gemm_f32.hpp"
 
@@ -64,6 +65,8 @@ struct GemmHArgs {
     RowMap rmap;
     int* range_flag;          // set to 1 when an emitted fp16 operand would leave the fp16 range
     int x2;                   // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
+    const unsigned char* W8;  // JMID_PREC_F16MX: W_lo as block-scaled fp8 in MFMA-fragment order (w8_image_kernel), or null
+    int w8_scale;             // its E8M0 scale byte: W_lo = fp8 value x 2^(w8_scale - 127)
 };
 
 constexpr int GEMMH_BK = 32;
@@ -770,6 +773,211 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// JMID_PREC_F16MX: the F16X2 product  A_hi . (W_hi + W_lo)  with the correction term on the block-scaled fp8 matrix path:
+//     acc += A_hi . W_hi                 four v_mfma_f32_32x32x16_f16 per k64 and output tile, as before
+//     acc += bf8(A_hi) . fp8(W_lo)       ONE v_mfma_scale_f32_32x32x64_f8f6f4 per k64 and output tile (the time of two fp16 steps)
+// 1.5 instead of 2 MFMA passes per product.  The term is 2^-11 of the product, so 2-3 significand bits are plenty:
+//   * bf8 (e5m2) has the exponent field of fp16: bf8(A_hi) is the top byte of every fp16 value, rounded to nearest by adding
+//     0x80 below it - built from the A_hi fragments the wave already holds (one v_add + half a v_perm per dword), no extra
+//     operand plane and no extra LDS traffic;
+//   * fp8 (e4m3) of W_lo with ONE power-of-two scale per matrix is made at weight-load time (w8_image_kernel), already in the
+//     order the instruction wants it, half the bytes of the fp16 W_lo image it replaces in L2 -> LDS.
+// The instruction sums over its 64 k in any order as long as A and W agree: byte p of lane (row, h) is k = 16 (p / 8) + 8 h + p % 8
+// of the k64 block for both, i.e. exactly the fp16 fragments' assignment.
+// W8 layout: [K / 64][N / 32][2 pieces][64 lanes][16 bytes]: the 32-column blocks of a workgroup tile are contiguous per k64
+// block, a wave reads its block with two linear ds_read_b128.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned char e4m3_rn(float x) {      // OCP e4m3fn, round to nearest even, saturating at 448
+    const unsigned s = x < 0.f ? 0x80u : 0u;
+    const float a = fminf(fabsf(x), 448.f);
+    if (!(a > 0.f)) return (unsigned char)s;
+    int e;
+    (void)frexpf(a, &e);
+    int fl = e - 1;                       // floor(log2 a)
+    if (fl < -6) fl = -6;
+    const float q = rintf(ldexpf(a, 3 - fl));          // in units of 2^(fl - 3): [8, 16] for normals, [0, 8) for subnormals
+    int E = fl + 7, m;
+    if (fl == -6 && q < 8.f) { E = 0; m = (int)q; }
+    else if (q >= 16.f) { E += 1; m = 0; }
+    else m = (int)q - 8;
+    if (E > 15 || (E == 15 && m == 7)) { E = 15; m = 6; }
+    return (unsigned char)(s | (unsigned)(E << 3) | (unsigned)m);
+}
+
+// largest |W_lo| of a weight matrix (as fp32 bits: non-negative floats order like unsigned integers)
+__global__ void w_lo_absmax_kernel(const float* W, size_t n, float scale, unsigned* out_bits) {
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = W[i] * scale;
+        asm("" : "+v"(v));
+        const half_t h = (half_t)v;
+        mx = fmaxf(mx, fabsf(v - (float)h));
+    }
+    atomicMax(out_bits, __float_as_uint(mx));
+}
+
+// fp32 [N, K] -> fp8 image of W_lo = W * scale - fp16(W * scale), divided by 2^(scale_byte - 127)
+__global__ void w8_image_kernel(const float* W, unsigned char* out, int N, int K, float scale, int scale_byte) {
+    const size_t n = (size_t)N * K;
+    const int nb32 = N / 32;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / K), k = (int)(i % K);
+        float v = W[i] * scale;
+        asm("" : "+v"(v));
+        const half_t h = (half_t)v;
+        const float lo = v - (float)h;
+        const int kb = k >> 6, kk = k & 63, ksg = kk >> 4, hh = (kk >> 3) & 1, e = kk & 7;
+        const int p = ksg * 8 + e, lane = (r & 31) + 32 * hh;
+        const size_t o = ((((size_t)kb * nb32 + (r >> 5)) * 2 + (p >> 4)) * 64 + lane) * 16 + (p & 15);
+        out[o] = e4m3_rn(ldexpf(lo, 127 - scale_byte));
+    }
+}
+
+// bf8 (e5m2) images of the four fp16 values in two dwords: their top bytes after rounding to nearest
+__device__ __forceinline__ int bf8_of_f16x4(int d0, int d1) {
+    return (int)__builtin_amdgcn_perm((unsigned)(d1 + 0x00800080), (unsigned)(d0 + 0x00800080), 0x07050301u);
+}
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
+    constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int tm = swz / ntn, tn = swz - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = g.K / GEMMH_BK;                     // even: K is a multiple of 64
+    const int nrb = (g.M + 127) / 128;
+    const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
+    const half_t* src[4];
+    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[2] = g.Whi + (size_t)(2 * tn) * nk * 4096 + tid * 8;
+    src[3] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
+    const unsigned char* src8 = g.W8 + (size_t)tn * 8 * 2048 + tid * 16;
+    const size_t w8_kstride = (size_t)(g.N / 32) * 2048;
+    unsigned char* lds8 = lds_raw + (size_t)(DMA3_STAGE + 6 * DMA_PLANE) * sizeof(half_t);      // W_lo slot of stage 1
+    auto dma16 = [](const void* s, void* d) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    };
+    auto issue = [&](int kt) {
+        half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
+        dma16(src[0] + (size_t)kt * 4096, st);
+        dma16(src[1] + (size_t)kt * 4096, st + 4096);
+        dma16(src[2] + (size_t)kt * 4096, st + 4 * 4096);
+        dma16(src[3] + (size_t)kt * 4096, st + 5 * 4096);
+        if (kt & 1) {                                  // the k64 block's W_lo image arrives with its second k32 tile
+            const unsigned char* s8 = src8 + (size_t)(kt >> 1) * w8_kstride;
+            dma16(s8, lds8 + wid * 1024);
+            dma16(s8 + 8192, lds8 + 8192 + wid * 1024);
+        }
+    };
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int offA[WM][2], offW[WN][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = wr * 64 + i * 32 + l31, r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offA[i][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int row = wc * 128 + j * 32 + l31, r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offW[j][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+    const int sb = g.w8_scale * 0x01010101;
+    i32x8 a8[WM];
+    // one k32 tile: the fp16 product, and the bf8 image of its A fragments into half HALF of the fp8 operand
+    auto tile = [&](const half_t* st, auto half_c) {
+        constexpr int HALF = decltype(half_c)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[WM], wh[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const i32x4 d = __builtin_bit_cast(i32x4, ah[i]);
+                a8[i][HALF * 4 + ks * 2 + 0] = bf8_of_f16x4(d[0], d[1]);
+                a8[i][HALF * 4 + ks * 2 + 1] = bf8_of_f16x4(d[2], d[3]);
+            }
+        }
+    };
+    issue(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue(kt + 1);
+        tile(lds, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2);
+        tile(lds + DMA3_STAGE, std::integral_constant<int, 1>{});
+        {
+            i32x8 w8[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const unsigned char* p = lds8 + (size_t)((wc * 4 + j) * 2) * 1024 + lane * 16;
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
+                const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
+                w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)      // cbsz = 1: A is bf8 (e5m2); blgp = 0: W is fp8 (e4m3); scales: 2^0 and the matrix's
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (OUT == OUT_QKV) {
+        if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && stage_vt) {
+            __syncthreads();
+            if (vt_staged_store<true>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
+        }
+    }
+    gemm_h_epilogue<WM, WN, EPI, OUT, true>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
+}
+
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_mx_dma256x256(const GemmHArgs& g, hipStream_t st) {
+    const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_dma256x256_kernel<EPI, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
+    }
+    hipLaunchKernelGGL((gemm_mx_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn,
+                       tune().vt_stage != 2 ? 1 : 0);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // 64x64 LDS-DMA variant for small M (one scene: M = 1200 tokens): the K loop of a small tile is pure latency, so the
 // 4-stage ring (three 16 KB K-tiles in flight, 64 KB of LDS, two workgroups per CU) matters more here than anywhere.
 // A 64-row half of a 128-row panel image is a contiguous 4 KB piece: one DMA round per plane.
@@ -872,7 +1080,11 @@ inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     // too many registers next to the 128 accumulators
     if (EPI != EPI_CSL && g.N % 256 == 0) {
         const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
-        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
+        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) {
+            if constexpr (X2 && EPI != EPI_CSL)
+                if (g.W8 && g.K % 64 == 0) return launch_gemm_mx_dma256x256<EPI, OUT>(g, st);
+            return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
+        }
     }
     if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT, X2>(g, st);
     return launch_gemm_h_dma<EPI, OUT, X2>(g, st);

@@ -38,6 +38,8 @@ struct GemmLnArgs {
     float eps;
     int* range_flag;
     int x2;                       // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
+    const unsigned char* W8;      // JMID_PREC_F16MX: fp8 image of W_lo (gemm_f16x3.hpp::w8_image_kernel), or null
+    int w8_scale;
 };
 
 // fp32 row-major [512, K] -> k16-panel hi/lo planes
@@ -246,6 +248,94 @@ constexpr int GLN2_A_OFF = 3 * GLN_W_STAGE;
 constexpr size_t GLN2_LDS_BYTES = size_t(GLN2_A_OFF + 3 * GLN2_A_STAGE) * sizeof(half_t);   // 96 + 48 = 144 KB
 static_assert(size_t(64) * GLN_TILE_LD * sizeof(float) <= GLN2_LDS_BYTES, "epilogue tile must fit the ring");
 
+// epilogue of the 128-row kernels in two passes of 64 rows (same arithmetic as the 64-row kernel / add_ln_kernel<2, true>)
+__device__ __forceinline__ void gln128_epilogue(const GemmLnArgs& g, f32x16 (&acc)[4][2], unsigned char* lds_raw, int m0, int wid,
+                                                int wc, int lane, int l31, int hi) {
+    constexpr int WN = 2;
+    constexpr int d = GLN_BN;
+    float* tile = reinterpret_cast<float*>(lds_raw);
+    f32x4 gm[2], bt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gm[i] = *reinterpret_cast<const f32x4*>(g.gamma + (i * 64 + lane) * 4);
+        bt[i] = *reinterpret_cast<const f32x4*>(g.beta + (i * 64 + lane) * 4);
+    }
+    float bv[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bv[j] = g.bias[wc * 64 + j * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]));
+    bool overflow = false;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        f16x4 rph[8][2], rpl[8][2];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const size_t ob = blk_index(m0 + pass * 64 + wid * 8 + rr, (i * 64 + lane) * 4, d);
+                rph[rr][i] = *reinterpret_cast<const f16x4*>(g.Xh + ob);
+                rpl[rr][i] = *reinterpret_cast<const f16x4*>(g.Xl + ob);
+            }
+        __syncthreads();   // pass 0: everybody is done with the rings; pass 1: everybody has read the tile of pass 0
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(i2 * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
+                        fmaf(acc[pass * 2 + i2][j][r], kWInv, bv[j]);
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int trow = wid * 8 + rr, row = m0 + pass * 64 + trow;
+            f32x4 v[2];
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                f32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = (float)rph[rr][i][e] + (float)rpl[rr][i][e];
+                const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
+                v[i] = a + y;
+                sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            }
+            const float mean = wave_sum(sacc) / (float)d;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = v[i][e] - mean;
+                    q += t * t;
+                }
+            const float rstd = rsqrtf(wave_sum(q) / (float)d + g.eps);
+            if (row < g.M) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                        half_t hh, ll;
+                        split_f32(o, hh, ll);
+                        overflow |= !(fabsf(o) <= kHalfMax);
+                        vh[e] = hh;
+                        vl[e] = ll;
+                    }
+                    const size_t ob = blk_index(row, c, d);
+                    *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
+                    *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
+                }
+            }
+        }
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
+}
+
 template <bool X2>
 __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, int ntm) {
     constexpr int WM = 4, WN = 2;
@@ -334,91 +424,137 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
         step(s + 1, 1);
     }
 
-    // ---- epilogue in two passes of 64 rows (same arithmetic as above / add_ln_kernel<2, true>)
-    constexpr int d = GLN_BN;
-    float* tile = reinterpret_cast<float*>(lds_raw);
-    f32x4 gm[2], bt[2];
+    gln128_epilogue(g, acc, lds_raw, m0, wid, wc, lane, l31, hi);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// JMID_PREC_F16MX variant of the 128-row kernel (gemm_f16x3.hpp, gemm_mx_dma256x256_kernel): A_hi . W_hi in fp16 as above and
+// the correction term bf8(A_hi) . fp8(W_lo) as ONE block-scaled fp8 MFMA per k64 and output tile.  The W ring carries only the
+// hi slices (3 x 16 KB); the fp8 image of a k64 block (a wave's own 64 columns: 4 KB, four DMA instructions) has ONE buffer,
+// refilled right after the block's fp8 MFMAs have taken it out of LDS - four k16 steps ahead of its next use.  DMA
+// instructions younger than W(s) at the top of step s: W(s + 1) and one A tile = 3, plus the four of the fp8 image when it was
+// issued one or two steps ago (s % 4 <= 1).
+constexpr int GLNX_W_STAGE = GLN_BN * 16;                 // halfs per W stage: the hi plane of a k16 slice
+constexpr int GLNX_W8_OFF = 3 * GLNX_W_STAGE * 2;         // bytes
+constexpr int GLNX_A_OFF = (GLNX_W8_OFF + GLN_BN * 64) / 2;   // halfs
+constexpr int GLNX_A_STAGE = GLN2_BM * 32;                // halfs: the hi image of a k32 tile
+constexpr size_t GLNX_RING_BYTES = size_t(GLNX_A_OFF + 3 * GLNX_A_STAGE) * sizeof(half_t);        // 48 + 32 + 24 = 104 KB
+constexpr size_t GLNX_LDS_BYTES = GLNX_RING_BYTES > size_t(64) * GLN_TILE_LD * sizeof(float) ? GLNX_RING_BYTES
+                                                                                              : size_t(64) * GLN_TILE_LD * sizeof(float);
+
+__global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int ntm) {
+    constexpr int WM = 4, WN = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wc = wid;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int m0 = tm * GLN2_BM;
+    const int nk = g.K / 32, nsteps = 2 * nk, nkb = g.K / 64;
+
+    auto dma16 = [](const void* s, void* d) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    };
+    const half_t* a_hi = g.Ahi + (size_t)tm * nk * 4096 + tid * 8;
+    auto issueA = [&](int ka) {     // one wave-instruction; past the end: the last tile again into its own stage
+        const int kk = ka < nk ? ka : nk - 1;
+        dma16(a_hi + (size_t)kk * 4096, lds + GLNX_A_OFF + (kk % 3) * GLNX_A_STAGE + wid * 512);
+    };
+    auto issueW = [&](int s, int stage) {
+        half_t* st = lds + stage * GLNX_W_STAGE + wc * 64 * 16;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        gm[i] = *reinterpret_cast<const f32x4*>(g.gamma + (i * 64 + lane) * 4);
-        bt[i] = *reinterpret_cast<const f32x4*>(g.beta + (i * 64 + lane) * 4);
-    }
-    float bv[WN];
+        for (int q = 0; q < 2; ++q)
+            dma16(g.W16hi + ((size_t)s * GLN_BN + wc * 64 + q * 32) * 16 + lane * 8, st + q * 512);
+    };
+    unsigned char* w8buf = lds_raw + GLNX_W8_OFF + wc * 4096;      // [2 column blocks][2 pieces][64 lanes][16 B]
+    const unsigned char* w8src = g.W8 + (size_t)wc * 2 * 2048 + lane * 16;
+    auto issueW8 = [&](int kb) {
 #pragma unroll
-    for (int j = 0; j < WN; ++j) bv[j] = g.bias[wc * 64 + j * 32 + l31];
+        for (int q = 0; q < 4; ++q) dma16(w8src + (size_t)kb * (GLN_BN / 32) * 2048 + q * 1024, w8buf + q * 1024);
+    };
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]));
-    bool overflow = false;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        f16x4 rph[8][2], rpl[8][2];
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const size_t ob = blk_index(m0 + pass * 64 + wid * 8 + rr, (i * 64 + lane) * 4, d);
-                rph[rr][i] = *reinterpret_cast<const f16x4*>(g.Xh + ob);
-                rpl[rr][i] = *reinterpret_cast<const f16x4*>(g.Xl + ob);
-            }
-        __syncthreads();   // pass 0: everybody is done with the rings; pass 1: everybody has read the tile of pass 0
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int i2 = 0; i2 < 2; ++i2)
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int offA[WM][2], offW[WN];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tile[(i2 * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
-                        fmaf(acc[pass * 2 + i2][j][r], kWInv, bv[j]);
-        __syncthreads();
+    for (int i = 0; i < WM; ++i) {
+        const int row = i * 32 + l31;
 #pragma unroll
-        for (int rr = 0; rr < 8; ++rr) {
-            const int trow = wid * 8 + rr, row = m0 + pass * 64 + trow;
-            f32x4 v[2];
-            float sacc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                f32x4 a;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = (float)rph[rr][i][e] + (float)rpl[rr][i][e];
-                const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
-                v[i] = a + y;
-                sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-            }
-            const float mean = wave_sum(sacc) / (float)d;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = v[i][e] - mean;
-                    q += t * t;
-                }
-            const float rstd = rsqrtf(wave_sum(q) / (float)d + g.eps);
-            if (row < g.M) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int c = (i * 64 + lane) * 4;
-                    f16x4 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
-                        half_t hh, ll;
-                        split_f32(o, hh, ll);
-                        overflow |= !(fabsf(o) <= kHalfMax);
-                        vh[e] = hh;
-                        vl[e] = ll;
-                    }
-                    const size_t ob = blk_index(row, c, d);
-                    *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
-                    *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
-                }
-            }
-        }
+        for (int ks = 0; ks < 2; ++ks) offA[i][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
     }
-    if (overflow) atomicOr(g.range_flag, 1);
-}
+#pragma unroll
+    for (int j = 0; j < WN; ++j) offW[j] = (wc * 64 + j * 32 + l31) * 16 + hi * 8;
+    const int sb = g.w8_scale * 0x01010101;
+    i32x8 a8[WM];
 
+    issueW8(0);
+    issueA(0);
+    issueW(0, 0);
+    issueA(1);
+    issueW(1, 1);
+    int wst = 0, ast = 0;
+    auto step = [&](const int s, auto q_c) {
+        constexpr int Q = decltype(q_c)::value, ks = Q & 1;
+        if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (Q <= 1 && s >= 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (ks == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nsteps) issueW(s + 2, wst == 0 ? 2 : wst - 1);
+        if (ks == 0) issueA((s >> 1) + 2);
+        const half_t* stA = lds + GLNX_A_OFF + ast * GLNX_A_STAGE;
+        const half_t* stW = lds + wst * GLNX_W_STAGE;
+        f16x8 ah[WM], wh[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) ah[i] = *reinterpret_cast<const f16x8*>(stA + offA[i][ks]);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) wh[j] = *reinterpret_cast<const f16x8*>(stW + offW[j]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const i32x4 dw = __builtin_bit_cast(i32x4, ah[i]);
+            a8[i][Q * 2 + 0] = bf8_of_f16x4(dw[0], dw[1]);
+            a8[i][Q * 2 + 1] = bf8_of_f16x4(dw[2], dw[3]);
+        }
+        if (Q == 3) {
+            i32x8 w8[WN];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const unsigned char* p = w8buf + j * 2048 + lane * 16;
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
+                const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
+                w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((s >> 2) + 1 < nkb) issueW8((s >> 2) + 1);
+        }
+        wst = wst == 2 ? 0 : wst + 1;
+        if (ks == 1) ast = ast == 2 ? 0 : ast + 1;
+    };
+    for (int s = 0; s < nsteps; s += 4) {
+        step(s, std::integral_constant<int, 0>{});
+        step(s + 1, std::integral_constant<int, 1>{});
+        step(s + 2, std::integral_constant<int, 2>{});
+        step(s + 3, std::integral_constant<int, 3>{});
+    }
+    gln128_epilogue(g, acc, lds_raw, m0, wid, wc, lane, l31, hi);
+}
 
 template <bool X2>
 inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
@@ -444,7 +580,22 @@ inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+inline hipError_t launch_gemm_ln_mx(const GemmLnArgs& g, hipStream_t st) {
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)GLNX_LDS_BYTES);
+    const int ntm = (g.M + GLN2_BM - 1) / GLN2_BM;
+    hipLaunchKernelGGL(gemm_ln128_mx_kernel, dim3(ntm), dim3(512), GLNX_LDS_BYTES, st, g, ntm);
+    return hipGetLastError();
+}
+
 inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
+    if (g.x2 && g.W8 && g.K % 64 == 0) {
+        auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };
+        const long n128 = (g.M + GLN2_BM - 1) / GLN2_BM, n64 = (g.M + GLN_BM - 1) / GLN_BM;
+        if (tune().ln_rows == 128 || (tune().ln_rows == 0 && 1.04 * fill(n128) >= fill(n64))) return launch_gemm_ln_mx(g, st);
+    }
     return g.x2 ? launch_gemm_ln_mode<true>(g, st) : launch_gemm_ln_mode<false>(g, st);
 }
 

@@ -93,6 +93,9 @@ struct jmid_ctx {
     std::map<std::string, std::vector<size_t>> expected;  // name -> shape
     std::map<std::string, DevBuf> w;
     std::map<std::string, HalfPair> wsplit;  // hi/lo fp16 planes of the GEMM weights (F16X3 path)
+    struct W8Image { unsigned char* p = nullptr; int scale = 0; };
+    std::map<std::string, W8Image> w8;       // JMID_PREC_F16MX: fp8 images of W_lo (w8_image_kernel), keyed like wsplit
+    int mx = 0;          // the running call is JMID_PREC_F16MX (x2 is set as well: everything not on the fp8 path runs as F16X2)
     std::map<std::string, HalfPair> w16;     // k16-panel copies of out_proj / linear2 for the fused GEMM + LayerNorm
     int* range_flag = nullptr;               // device word: an fp16 operand left the fp16 range
     bool weights_in_half_range = true;
@@ -306,6 +309,39 @@ int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
     return 0;
 }
 
+// JMID_PREC_F16MX: hand the GEMM the fp8 image of this weight's lo plane (the kernels that have no fp8 path ignore it)
+void set_w8(jmid_ctx* h, GemmHArgs& g, const std::string& name) {
+    g.W8 = nullptr;
+    g.w8_scale = 0;
+    if (!h->mx) return;
+    auto it = h->w8.find(name);
+    if (it == h->w8.end()) return;
+    g.W8 = it->second.p;
+    g.w8_scale = it->second.scale;
+}
+
+// fp8 image of W_lo for a device-resident fp32 weight [N, K] (N % 32 == 0, K % 64 == 0)
+int make_w8(jmid_ctx* h, const float* dW, int N, int K, jmid_ctx::W8Image* out) {
+    unsigned* dmax = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dmax, sizeof(unsigned)));
+    HIPCHK(h, hipMemsetAsync(dmax, 0, sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(w_lo_absmax_kernel, dim3(256), dim3(256), 0, h->stream, dW, (size_t)N * K, kWScale, dmax);
+    unsigned bits = 0;
+    HIPCHK(h, hipMemcpyAsync(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipFree(dmax));
+    float mx;
+    memcpy(&mx, &bits, sizeof(float));
+    int e = -127;                                   // W_lo = fp8 x 2^e with the largest |W_lo| just inside the e4m3 range (448)
+    if (mx > 0.f) e = (int)ceilf(log2f(mx / 448.0f));
+    if (e < -127) e = -127;
+    out->scale = e + 127;
+    HIPCHK(h, hipMalloc((void**)&out->p, (size_t)N * K));
+    hipLaunchKernelGGL(w8_image_kernel, dim3(256), dim3(256), 0, h->stream, dW, out->p, N, K, kWScale, out->scale);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const float* bt, int M, int d,
                half_t* Xh = nullptr, half_t* Xl = nullptr) {
     ProfScope ps(h, KC_ADD_LN);
@@ -472,6 +508,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.rmap = rm; g.M = M;
             const HalfPair& win = h->wsplit[p + ".self_attn.in_proj_weight"];
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = win.hi; g.Wlo = win.lo;
+            set_w8(h, g, p + ".self_attn.in_proj_weight");
             g.bias = W(h, p + ".self_attn.in_proj_bias"); g.N = 3 * d; g.K = d;
             if (joint) {
                 // S % 4 == 0: the QKV epilogue writes V^T itself; otherwise V row-major + v_transpose_kernel
@@ -505,11 +542,16 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 const HalfPair& w16 = h->w16[p + ".self_attn.out_proj.weight"];
                 GemmLnArgs gl{sb.Ah, sb.Al, w16.hi, w16.lo, W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"),
                               W(h, p + ".norm1.bias"), sb.Xh, sb.Xl, M, d, 1e-5f, h->range_flag, h->x2};
+                if (h->mx) {
+                    auto it8 = h->w8.find(p + ".self_attn.out_proj.weight");
+                    if (it8 != h->w8.end()) { gl.W8 = it8->second.p; gl.w8_scale = it8->second.scale; }
+                }
                 ProfScope ps(h, KC_GEMM_OUT);
                 HIPCHK(h, launch_gemm_ln(gl, h->stream));
             } else {
                 const HalfPair& wout = h->wsplit[p + ".self_attn.out_proj.weight"];
                 g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
+                set_w8(h, g, p + ".self_attn.out_proj.weight");
                 g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
@@ -518,17 +560,23 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             }
             const HalfPair& w1 = h->wsplit[p + ".linear1.weight"];
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w1.hi; g.Wlo = w1.lo;
+            set_w8(h, g, p + ".linear1.weight");
             g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
             if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
             if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".linear2.weight"];
                 GemmLnArgs gl{sb.H1h, sb.H1l, w16.hi, w16.lo, W(h, p + ".linear2.bias"), W(h, p + ".norm2.weight"),
                               W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag, h->x2};
+                if (h->mx) {
+                    auto it8 = h->w8.find(p + ".linear2.weight");
+                    if (it8 != h->w8.end()) { gl.W8 = it8->second.p; gl.w8_scale = it8->second.scale; }
+                }
                 ProfScope ps(h, KC_GEMM_FF2);
                 HIPCHK(h, launch_gemm_ln(gl, h->stream));
             } else {
                 const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
                 g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
+                set_w8(h, g, p + ".linear2.weight");
                 g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
@@ -654,9 +702,10 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     if (int rc = check_ready(h)) return rc;
     if (E <= 0 || A <= 0 || K <= 0 || T <= 0) return fail(h, JMID_EINVAL, "E, A, K, T must be positive");
     if (T > 24) return fail(h, JMID_EINVAL, "T exceeds the positional-encoding table (max_len=24, diffusion.py:116-118)");
-    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2)
-        return fail(h, JMID_EINVAL, "precision must be JMID_PREC_F32, JMID_PREC_F16X3 or JMID_PREC_F16X2 (JMID_PREC_F16 is not built)");
-    h->x2 = precision == JMID_PREC_F16X2;
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2 && precision != JMID_PREC_F16MX)
+        return fail(h, JMID_EINVAL, "precision must be JMID_PREC_F32, JMID_PREC_F16X3, JMID_PREC_F16X2 or JMID_PREC_F16MX (JMID_PREC_F16 is not built)");
+    h->mx = precision == JMID_PREC_F16MX;
+    h->x2 = precision == JMID_PREC_F16X2 || h->mx;
     if (precision != JMID_PREC_F32 && !h->weights_in_half_range)
         return fail(h, JMID_ERANGE, "a weight exceeds the fp16 range: use JMID_PREC_F32");
     if (!x_in || !ctx) return fail(h, JMID_EINVAL, "null input");
@@ -928,6 +977,7 @@ int jmid_destroy(jmid_handle_t h) {
             hipFree(kv.second.hi);
             hipFree(kv.second.lo);
         }
+    for (auto& kv : h->w8) hipFree(kv.second.p);
     if (h->range_flag) hipFree(h->range_flag);
     if (h->ev_in) hipEventDestroy(h->ev_in);
     if (h->ev_out) hipEventDestroy(h->ev_out);
@@ -1076,6 +1126,8 @@ int jmid_finalize_weights(jmid_handle_t h) {
             hipFree(kv.second.lo);
         }
         h->wsplit.clear();
+        for (auto& kv : h->w8) hipFree(kv.second.p);
+        h->w8.clear();
         for (auto& kv : h->w16) {
             hipFree(kv.second.hi);
             hipFree(kv.second.lo);
@@ -1106,6 +1158,11 @@ int jmid_finalize_weights(jmid_handle_t h) {
                                (int)shp[0], (int)shp[1], h->range_flag, kWScale);
             HIPCHK(h, hipGetLastError());
             h->wsplit[nm] = hp;
+            if (shp[0] % 32 == 0 && shp[1] % 64 == 0) {
+                jmid_ctx::W8Image img;
+                if (int rc = make_w8(h, b.p, (int)shp[0], (int)shp[1], &img)) return rc;
+                h->w8[nm] = img;
+            }
         }
         if (h->d == GLN_BN) {   // k16-panel copies for gemm_ln_f16x3_kernel (row-complete tiles need N == 512) and tail_f16x3_kernel
             std::vector<std::string> k16names;
@@ -1402,9 +1459,10 @@ int jmid_synchronize(jmid_handle_t h) {
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
                   int precision, float* C) {
     if (!h || !A || !Wt || !C) return JMID_EINVAL;
-    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2)
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2 && precision != JMID_PREC_F16MX)
         return fail(h, JMID_EINVAL, "bad precision");
-    h->x2 = precision == JMID_PREC_F16X2;
+    h->mx = precision == JMID_PREC_F16MX;
+    h->x2 = precision == JMID_PREC_F16X2 || h->mx;
     HIPCHK(h, hipSetDevice(h->device));
     TuneScope tune_scope(&h->tune);
     if (!h->range_flag) {
@@ -1423,6 +1481,7 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
     }
     int rc = 0;
     half_t *ah = nullptr, *al = nullptr, *wh = nullptr, *wl = nullptr;
+    jmid_ctx::W8Image w8img;
     if (precision == JMID_PREC_F32) {
         GemmArgs g{};
         g.A = dA; g.lda = K; g.W = dW; g.ldw = K; g.bias = dB; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
@@ -1442,6 +1501,10 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
         GemmHArgs g{};
         g.Ahi = ah; g.Alo = al; g.Whi = wh; g.Wlo = wl; g.bias = dB; g.C = dC; g.ldc = N;
         g.M = M; g.N = N; g.K = K;
+        if (h->mx && N % 32 == 0 && K % 64 == 0) {
+            if (int rc8 = make_w8(h, dW, N, K, &w8img)) return rc8;
+            g.W8 = w8img.p; g.w8_scale = w8img.scale;
+        }
         rc = relu ? run_gemm_h<EPI_BIAS_RELU, OUT_F32>(h, KC_GEMM_QKV, g) : run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g);
     }
     if (!rc) {
@@ -1453,14 +1516,16 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
     if (dB) hipFree(dB);
     for (half_t* p : {ah, al, wh, wl})
         if (p) hipFree(p);
+    if (w8img.p) hipFree(w8img.p);
     return rc;
 }
 
 int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT) {
     if (!h || !QKV || !OUT) return JMID_EINVAL;
-    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2)
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2 && precision != JMID_PREC_F16MX)
         return fail(h, JMID_EINVAL, "bad precision");
-    h->x2 = precision == JMID_PREC_F16X2;
+    h->mx = precision == JMID_PREC_F16MX;
+    h->x2 = precision == JMID_PREC_F16X2 || h->mx;
     HIPCHK(h, hipSetDevice(h->device));
     TuneScope tune_scope(&h->tune);
     if (!h->range_flag) {
