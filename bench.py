@@ -47,15 +47,18 @@ WORKLOADS = {
     "cfg4": (1, 25, 64, 12, 50),     # configs[3]: dense crowd, one scene
     "cfg5": (512, 5, 20, 12, 50),    # configs[4]: 4096 episodes sharded 512 / GPU
 }
-PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0, "f16mx": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 # MFMA FLOPs spent per algorithmic FLOP; f16x2: 2 in the GEMMs, (3 + 2) / 2 in attention (logits keep all three terms)
-MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2}
-MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.5}
+MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2, "f16mx": 1.5}   # f16mx: the fp8 correction term costs half an fp16 pass
+MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.5, "f16mx": 2.5}
 DTYPE_TEXT = {
     "f32": "f32",
     "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate",
     "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; softmax logits, "
              "residual stream, LayerNorm and DDIM state at f32-class precision",
+    "f16mx": "f16x2 with the weight-lo correction term of every large GEMM as ONE block-scaled fp8 MFMA per k64 "
+             "(bf8 image of the fp16 activation x e4m3 image of W_lo): 1.5 MFMA passes per GEMM product, fp32 accumulate; "
+             "attention, residual stream, LayerNorm and DDIM state as in f16x2",
 }
 PROF_CLASSES = ["gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_ff", "gemm_tail", "attention"]
 # kernel class -> substring of the kernel names of that class in the per-call PMC summary (tools/pmc_call.sh)
@@ -116,7 +119,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--episodes-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2"], help="the mode `value` is quoted on")
+    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2", "f16mx"], help="the mode `value` is quoted on")
     ap.add_argument("--modes", default="f16x2,f16x3",
                     help="comma list of modes measured identically in this run (the --precision mode is always included)")
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])

@@ -772,6 +772,64 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+// Q / K planes of a wave's 64-token x 128-column tile through LDS, for accumulators of the TRANSPOSED product (W fragments as the
+// first MFMA operand): registers 4q..4q+3 of a lane are then 4 consecutive COLUMNS of one token, so a plane goes into the wave's
+// 16 KB of LDS with 8-byte writes (16-byte units XOR-swizzled by the row: conflict-free both ways) and out again as 16 bytes
+// per lane = 256 contiguous bytes per token row: 16 + 16 store instructions per wave instead of 256 two-byte ones.
+// Same arithmetic as gemm_h_epilogue (bias, Q pre-scaled by qscale, unscaled hi/lo split).
+__device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc)[2][4], int mw0, int nw0, half_t* wlds, int l31,
+                                                int hi, int lane) {
+    const int part = nw0 / g.d, nn0 = nw0 - part * g.d;
+    half_t* dst_base[2] = {part == 0 ? g.Chi : g.Khi, part == 0 ? g.Clo : g.Klo};
+    const float qs = part == 0 ? g.qscale : 1.0f;
+    f32x4 bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(g.bias + nw0 + j * 32 + 8 * q + 4 * hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[j][q]));
+    bool overflow = false;
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = i * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f16x4 pv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[j][q][e]);
+                        if (part == 0) v *= qs;
+                        half_t hh, ll;
+                        split_f32_unscaled(v, hh, ll);
+                        if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax);
+                        pv[e] = plane == 0 ? hh : ll;
+                    }
+                    const int c = (8 * j + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
+                    *reinterpret_cast<f16x4*>(wlds + row * 128 + c * 4) = pv;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        half_t* dst = dst_base[plane] + (size_t)mw0 * g.d + nn0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int row = t * 4 + (lane >> 4), u = lane & 15;
+            const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
+            if (mw0 + row < g.M) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // JMID_PREC_F16MX: the F16X2 product  A_hi . (W_hi + W_lo)  with the correction term on the block-scaled fp8 matrix path:
 //     acc += A_hi . W_hi                 four v_mfma_f32_32x32x16_f16 per k64 and output tile, as before
@@ -840,6 +898,16 @@ __device__ __forceinline__ int bf8_of_f16x4(int d0, int d1) {
     return (int)__builtin_amdgcn_perm((unsigned)(d1 + 0x00800080), (unsigned)(d0 + 0x00800080), 0x07050301u);
 }
 
+// LDS: THREE stages of [A_hi: 2 panel images][W_hi: 2 images] (32 KB; without the lo images there is room for a second tile of
+// look-ahead: one 1 KB DMA instruction lands ~1 us after its issue, longer than a k32 tile of MFMAs lasts), then two buffers
+// for the fp8 image of a k64 block, which travels in two halves: every k32 tile is exactly five DMA instructions per wave, so
+// the wait at the top of a tile is a constant vmcnt(5).
+// (A 128 x 256 tile with two workgroups per CU - one's epilogue under the other's K loop, 1.5x the operand bytes - measured
+// the same time as the 2-stage 256 x 256 version of this kernel and was dropped.)
+constexpr int MX_STAGE = 4 * DMA_PLANE;                                    // halfs
+constexpr size_t MX_W8_OFF = size_t(3) * MX_STAGE * sizeof(half_t);        // bytes: 96 KB
+constexpr size_t MX_LDS_BYTES = MX_W8_OFF + 2 * 16384;                     // 128 KB (= vt_staged_store's 8 x 16 KB)
+
 template <int EPI, int OUT>
 __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
     constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
@@ -863,21 +931,16 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
     src[3] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
     const unsigned char* src8 = g.W8 + (size_t)tn * 8 * 2048 + tid * 16;
     const size_t w8_kstride = (size_t)(g.N / 32) * 2048;
-    unsigned char* lds8 = lds_raw + (size_t)(DMA3_STAGE + 6 * DMA_PLANE) * sizeof(half_t);      // W_lo slot of stage 1
+    unsigned char* lds8 = lds_raw + MX_W8_OFF;
     auto dma16 = [](const void* s, void* d) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
     };
-    auto issue = [&](int kt) {
-        half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
-        dma16(src[0] + (size_t)kt * 4096, st);
-        dma16(src[1] + (size_t)kt * 4096, st + 4096);
-        dma16(src[2] + (size_t)kt * 4096, st + 4 * 4096);
-        dma16(src[3] + (size_t)kt * 4096, st + 5 * 4096);
-        if (kt & 1) {                                  // the k64 block's W_lo image arrives with its second k32 tile
-            const unsigned char* s8 = src8 + (size_t)(kt >> 1) * w8_kstride;
-            dma16(s8, lds8 + wid * 1024);
-            dma16(s8 + 8192, lds8 + 8192 + wid * 1024);
-        }
+    auto issue = [&](int kt, int stg) {                // five wave-instructions
+        half_t* st = lds + stg * MX_STAGE + wid * 512;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(src[i] + (size_t)kt * 4096, st + i * 4096);
+        // half (kt & 1) of the fp8 image of k64 block kt / 2, into buffer (kt / 2) & 1
+        dma16(src8 + (size_t)(kt >> 1) * w8_kstride + (kt & 1) * 8192, lds8 + ((kt >> 1) & 1) * 16384 + (kt & 1) * 8192 + wid * 1024);
     };
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -899,24 +962,28 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
         const int row = wc * 128 + j * 32 + l31, r = row & 127;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            offW[j][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+            offW[j][ks] = (2 + (row >> 7)) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
     }
     const int sb = g.w8_scale * 0x01010101;
     i32x8 a8[WM];
-    // one k32 tile: the fp16 product, and the bf8 image of its A fragments into half HALF of the fp8 operand
-    auto tile = [&](const half_t* st, auto half_c) {
+    // one k32 tile: the fp16 product, and the bf8 image of its A fragments into half HALF of the fp8 operand.
+    // SWAP: the W fragments go first, the accumulators hold the transposed tile (qk_staged_store)
+    auto tile = [&](const half_t* st, auto half_c, auto swap_c) {
         constexpr int HALF = decltype(half_c)::value;
+        constexpr bool SWAP = decltype(swap_c)::value;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 ah[WM], wh[WN];
 #pragma unroll
             for (int i = 0; i < WM; ++i) ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
+            for (int j = 0; j < WN; ++j) wh[j] = *reinterpret_cast<const f16x8*>(st + offW[j][ks]);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
                 const i32x4 d = __builtin_bit_cast(i32x4, ah[i]);
@@ -925,38 +992,58 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
             }
         }
     };
-    issue(0);
-    for (int kt = 0; kt < nk; kt += 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    auto top = [&](int kt, int stg_next) {             // tile kt has landed for everybody; stage of tile kt - 1 is free again
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue(kt + 1);
-        tile(lds, std::integral_constant<int, 0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) issue(kt + 2);
-        tile(lds + DMA3_STAGE, std::integral_constant<int, 1>{});
-        {
-            i32x8 w8[WN];
+        if (kt + 2 < nk) issue(kt + 2, stg_next);
+    };
+    auto kloop = [&](auto swap_c) {
+        constexpr bool SWAP = decltype(swap_c)::value;
+        issue(0, 0);
+        issue(1, 1);
+        int stg = 0;                                       // stage of tile kt
+        for (int kt = 0; kt < nk; kt += 2) {
+            const int s1 = stg == 2 ? 0 : stg + 1, s2 = s1 == 2 ? 0 : s1 + 1;
+            top(kt, s2);
+            tile(lds + stg * MX_STAGE, std::integral_constant<int, 0>{}, swap_c);
+            __builtin_amdgcn_sched_barrier(0);
+            top(kt + 1, stg);
+            tile(lds + s1 * MX_STAGE, std::integral_constant<int, 1>{}, swap_c);
+            {
+                const unsigned char* wb = lds8 + ((kt >> 1) & 1) * 16384;
+                i32x8 w8[WN];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const unsigned char* p = lds8 + (size_t)((wc * 4 + j) * 2) * 1024 + lane * 16;
-                const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
-                const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
-                w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                for (int j = 0; j < WN; ++j) {
+                    const unsigned char* p = wb + (size_t)((wc * 4 + j) * 2) * 1024 + lane * 16;
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
+                    const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
+                    w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)      // format selectors: 1 = bf8 (e5m2) for the activation, 0 = fp8 (e4m3) for W_lo; scales: 2^0 and the matrix's
+                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[j], a8[i], acc[i][j], 0, 1, 0, sb, 0, 0x7f7f7f7f)
+                                         : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
             }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)      // cbsz = 1: A is bf8 (e5m2); blgp = 0: W is fp8 (e4m3); scales: 2^0 and the matrix's
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
+            __builtin_amdgcn_sched_barrier(0);
+            stg = s2;
         }
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    };
     if (OUT == OUT_QKV) {
-        if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && stage_vt) {
+        // block-uniform: a Q or K tile (columns below 2 d) is computed transposed and leaves through LDS in full rows
+        if ((stage_vt & 2) && n0 < 2 * g.d && g.d % 128 == 0) {
+            kloop(std::true_type{});
+            __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
+            qk_staged_store(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
+            return;
+        }
+    }
+    kloop(std::false_type{});
+    if (OUT == OUT_QKV) {
+        if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && (stage_vt & 1)) {
             __syncthreads();
             if (vt_staged_store<true>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
         }
@@ -970,10 +1057,11 @@ inline hipError_t launch_gemm_mx_dma256x256(const GemmHArgs& g, hipStream_t st) 
     static bool attr_seen[64] = {};
     if (first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_dma256x256_kernel<EPI, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)MX_LDS_BYTES);
     }
-    hipLaunchKernelGGL((gemm_mx_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn,
-                       tune().vt_stage != 2 ? 1 : 0);
+    const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only
+    hipLaunchKernelGGL((gemm_mx_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), MX_LDS_BYTES, st, g, ntm, ntn,
+                       vs == 2 ? 0 : (vs == 3 ? 1 : 3));
     return hipGetLastError();
 }
 

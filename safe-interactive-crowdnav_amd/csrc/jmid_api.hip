@@ -1355,7 +1355,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"no_vt_direct", &Tuning::no_vt_direct, 0, 1},         // 1: always V row-major + v_transpose_kernel
         {"gemm_ng", &Tuning::gemm_ng, 0, 64},                  // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
         {"attn_h_variant", &Tuning::attn_h_variant, 0, 2},
-        {"vt_stage", &Tuning::vt_stage, 0, 2},                 // V^T of the 256x256 QKV kernel through LDS: 0 / 1 on, 2 off
+        {"vt_stage", &Tuning::vt_stage, 0, 3},                 // V^T of the 256x256 QKV kernel through LDS: 0 / 1 on, 2 off
         {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
