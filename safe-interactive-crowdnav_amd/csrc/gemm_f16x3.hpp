@@ -65,8 +65,7 @@ struct GemmHArgs {
     RowMap rmap;
     int* range_flag;          // set to 1 when an emitted fp16 operand would leave the fp16 range
     int x2;                   // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
-    const unsigned char* W8;  // JMID_PREC_F16MX: W_lo as block-scaled fp8 in MFMA-fragment order (w8_image_kernel), or null
-    int w8_scale;             // its E8M0 scale byte: W_lo = fp8 value x 2^(w8_scale - 127)
+    const unsigned char* W8;  // JMID_PREC_F16MX: bf8(W_lo) in MFMA-fragment order (w8_image_kernel), or null
 };
 
 constexpr int GEMMH_BK = 32;
@@ -808,7 +807,7 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
                         if (part == 0) v *= qs;
                         half_t hh, ll;
                         split_f32_unscaled(v, hh, ll);
-                        if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax);
+                        if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax) && mw0 + row < g.M;   // rows past M hold whatever the padding held
                         pv[e] = plane == 0 ? hh : ll;
                     }
                     const int c = (8 * j + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
@@ -833,13 +832,17 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
 // ---------------------------------------------------------------------------------------------------------------
 // JMID_PREC_F16MX: the F16X2 product  A_hi . (W_hi + W_lo)  with the correction term on the block-scaled fp8 matrix path:
 //     acc += A_hi . W_hi                 four v_mfma_f32_32x32x16_f16 per k64 and output tile, as before
-//     acc += bf8(A_hi) . fp8(W_lo)       ONE v_mfma_scale_f32_32x32x64_f8f6f4 per k64 and output tile (the time of two fp16 steps)
+//     acc += bf8(A_hi) . bf8(W_lo)       ONE v_mfma_f32_32x32x64_f8f6f4 per k64 and output tile (the time of two fp16 steps)
 // 1.5 instead of 2 MFMA passes per product.  The term is 2^-11 of the product, so 2-3 significand bits are plenty:
 //   * bf8 (e5m2) has the exponent field of fp16: bf8(A_hi) is the top byte of every fp16 value, rounded to nearest by adding
 //     0x80 below it - built from the A_hi fragments the wave already holds (one v_add + half a v_perm per dword), no extra
 //     operand plane and no extra LDS traffic;
-//   * fp8 (e4m3) of W_lo with ONE power-of-two scale per matrix is made at weight-load time (w8_image_kernel), already in the
-//     order the instruction wants it, half the bytes of the fp16 W_lo image it replaces in L2 -> LDS.
+//   * bf8(W_lo) is made at weight-load time (w8_image_kernel), already in the order the instruction wants it, half the bytes of
+//     the fp16 W_lo image it replaces in L2 -> LDS.  W_lo of the 2^8-scaled weights lies in bf8's range (subnormals to 2^-16).
+//   * NO block scales: with literal zero scale operands the compiler emits the plain v_mfma_f32_32x32x64_f8f6f4.  The scaled
+//     form is a PAIR (v_mfma_ld_scale_b32 + MFMA), and a wave of another kernel on the same SIMD (out_ddim_kernel next to the
+//     166-VGPR 64-row GEMM + LayerNorm kernel) made such pairs compute with a wrong scale now and then: tile-wide 1-ulp
+//     differences from run to run (tools/concurrency_probe9.hip).
 // The instruction sums over its 64 k in any order as long as A and W agree: byte p of lane (row, h) is k = 16 (p / 8) + 8 h + p % 8
 // of the k64 block for both, i.e. exactly the fp16 fragments' assignment.
 // W8 layout: [K / 64][N / 32][2 pieces][64 lanes][16 bytes]: the 32-column blocks of a workgroup tile are contiguous per k64
@@ -847,37 +850,8 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned char e4m3_rn(float x) {      // OCP e4m3fn, round to nearest even, saturating at 448
-    const unsigned s = x < 0.f ? 0x80u : 0u;
-    const float a = fminf(fabsf(x), 448.f);
-    if (!(a > 0.f)) return (unsigned char)s;
-    int e;
-    (void)frexpf(a, &e);
-    int fl = e - 1;                       // floor(log2 a)
-    if (fl < -6) fl = -6;
-    const float q = rintf(ldexpf(a, 3 - fl));          // in units of 2^(fl - 3): [8, 16] for normals, [0, 8) for subnormals
-    int E = fl + 7, m;
-    if (fl == -6 && q < 8.f) { E = 0; m = (int)q; }
-    else if (q >= 16.f) { E += 1; m = 0; }
-    else m = (int)q - 8;
-    if (E > 15 || (E == 15 && m == 7)) { E = 15; m = 6; }
-    return (unsigned char)(s | (unsigned)(E << 3) | (unsigned)m);
-}
-
-// largest |W_lo| of a weight matrix (as fp32 bits: non-negative floats order like unsigned integers)
-__global__ void w_lo_absmax_kernel(const float* W, size_t n, float scale, unsigned* out_bits) {
-    float mx = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float v = W[i] * scale;
-        asm("" : "+v"(v));
-        const half_t h = (half_t)v;
-        mx = fmaxf(mx, fabsf(v - (float)h));
-    }
-    atomicMax(out_bits, __float_as_uint(mx));
-}
-
-// fp32 [N, K] -> fp8 image of W_lo = W * scale - fp16(W * scale), divided by 2^(scale_byte - 127)
-__global__ void w8_image_kernel(const float* W, unsigned char* out, int N, int K, float scale, int scale_byte) {
+// fp32 [N, K] -> bf8 (e5m2) image of W_lo = W * scale - fp16(W * scale): the top byte of fp16(W_lo) after rounding to nearest
+__global__ void w8_image_kernel(const float* W, unsigned char* out, int N, int K, float scale) {
     const size_t n = (size_t)N * K;
     const int nb32 = N / 32;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -885,11 +859,11 @@ __global__ void w8_image_kernel(const float* W, unsigned char* out, int N, int K
         float v = W[i] * scale;
         asm("" : "+v"(v));
         const half_t h = (half_t)v;
-        const float lo = v - (float)h;
+        const half_t lo = (half_t)(v - (float)h);
         const int kb = k >> 6, kk = k & 63, ksg = kk >> 4, hh = (kk >> 3) & 1, e = kk & 7;
         const int p = ksg * 8 + e, lane = (r & 31) + 32 * hh;
         const size_t o = ((((size_t)kb * nb32 + (r >> 5)) * 2 + (p >> 4)) * 64 + lane) * 16 + (p & 15);
-        out[o] = e4m3_rn(ldexpf(lo, 127 - scale_byte));
+        out[o] = (unsigned char)((__builtin_bit_cast(unsigned short, lo) + 0x80u) >> 8);
     }
 }
 
@@ -898,24 +872,40 @@ __device__ __forceinline__ int bf8_of_f16x4(int d0, int d1) {
     return (int)__builtin_amdgcn_perm((unsigned)(d1 + 0x00800080), (unsigned)(d0 + 0x00800080), 0x07050301u);
 }
 
-// LDS: THREE stages of [A_hi: 2 panel images][W_hi: 2 images] (32 KB; without the lo images there is room for a second tile of
-// look-ahead: one 1 KB DMA instruction lands ~1 us after its issue, longer than a k32 tile of MFMAs lasts), then two buffers
-// for the fp8 image of a k64 block, which travels in two halves: every k32 tile is exactly five DMA instructions per wave, so
-// the wait at the top of a tile is a constant vmcnt(5).
-// (A 128 x 256 tile with two workgroups per CU - one's epilogue under the other's K loop, 1.5x the operand bytes - measured
-// the same time as the 2-stage 256 x 256 version of this kernel and was dropped.)
-constexpr int MX_STAGE = 4 * DMA_PLANE;                                    // halfs
-constexpr size_t MX_W8_OFF = size_t(3) * MX_STAGE * sizeof(half_t);        // bytes: 96 KB
-constexpr size_t MX_LDS_BYTES = MX_W8_OFF + 2 * 16384;                     // 128 KB (= vt_staged_store's 8 x 16 KB)
+// ONE kernel for every tile shape of the mode (the shapes of the F16X2 kernels above, chosen by the same rules), so that an
+// episode's result does not depend on which shape its batch got: every accumulator sees, per k64 block, the four fp16 steps in
+// k order and then the fp8 instruction - bit-identical across shapes.
+//   WR x WC waves, wave tile (32 WM) x (32 WN):  64 x 64 (2x2 waves of 32 x 32, small M),  128 x 128 (2x2 of 64 x 64),
+//   256 x 128 (4x2 of 64 x 64; the ConcatSquash epilogue fits next to 64 accumulators),  256 x 256 (4x2 of 64 x 128).
+// LDS: NS stages of [A_hi tile][W_hi tile] of one k32 step (without the lo images there is room for a second / third tile of
+// look-ahead), then two buffers for the fp8 image of a k64 block, which travels with the ODD k32 tile of its block (the one after
+// which it is used).  The DMA instructions younger than tile kt's at the top of tile kt are a compile-time constant per tile parity.
+template <int WR, int WC, int WM, int WN, int NS>
+struct MxCfg {
+    static constexpr int NT = 64 * WR * WC, BM = 32 * WM * WR, BN = 32 * WN * WC;
+    static constexpr int A_HALFS = BM * 32, W_HALFS = BN * 32, STAGE = A_HALFS + W_HALFS;     // halfs per k32 stage
+    static constexpr int W8_BYTES = BN * 64;                                                  // fp8 image of a k64 block
+    static constexpr int PIECE = NT * 8;                                                      // halfs per DMA instruction
+    static constexpr int NA = A_HALFS / PIECE, NW = W_HALFS / PIECE, N8 = W8_BYTES / (NT * 16);
+    static constexpr size_t W8_OFF = size_t(NS) * STAGE * sizeof(half_t);
+    static constexpr size_t RING_BYTES = W8_OFF + 2 * W8_BYTES;
+    static constexpr size_t VT_BYTES = (WM == 2 && WN == 4) ? size_t(WR * WC) * 16384 : 0;     // vt / qk staged stores
+    static constexpr size_t LDS_BYTES = RING_BYTES > VT_BYTES ? RING_BYTES : VT_BYTES;
+    static_assert(NA >= 1 && NW >= 1 && N8 >= 1 && A_HALFS % PIECE == 0 && W_HALFS % PIECE == 0, "tile / workgroup mismatch");
+};
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int OUT>
-__global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
-    constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
+template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS>
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) void gemm_mx_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
+    using C = MxCfg<WR, WC, WM, WN, NS>;
+    constexpr int BM = C::BM, BN = C::BN, L = NS - 1;          // L tiles of look-ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wr = wid >> 1, wc = wid & 1;
+    const int wr = wid / WC, wc = wid % WC;
+    // XCD-contiguous tile ranges, N fastest: the N-tiles of an M-tile run together and share its A panels in L2
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
@@ -923,24 +913,39 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = g.K / GEMMH_BK;                     // even: K is a multiple of 64
     const int nrb = (g.M + 127) / 128;
-    const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
-    const half_t* src[4];
-    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
-    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
-    src[2] = g.Whi + (size_t)(2 * tn) * nk * 4096 + tid * 8;
-    src[3] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
-    const unsigned char* src8 = g.W8 + (size_t)tn * 8 * 2048 + tid * 16;
+    // DMA sources: piece p of the A (W) tile is C::PIECE halfs of the blocked panel image(s) of this tile's rows
+    const half_t* srcA[C::NA];
+    const half_t* srcW[C::NW];
+#pragma unroll
+    for (int p = 0; p < C::NA; ++p) {
+        const int h0 = (m0 & 127) * 32 + p * C::PIECE;                   // halfs from the start of the tile's first panel image
+        int rb = m0 / 128 + h0 / 4096;
+        rb = rb < nrb ? rb : nrb - 1;
+        srcA[p] = g.Ahi + (size_t)rb * nk * 4096 + h0 % 4096 + tid * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < C::NW; ++p) {
+        const int h0 = (n0 & 127) * 32 + p * C::PIECE;
+        srcW[p] = g.Whi + (size_t)(n0 / 128 + h0 / 4096) * nk * 4096 + h0 % 4096 + tid * 8;
+    }
+    const unsigned char* src8 = g.W8 + (size_t)(n0 / 32) * 2048 + tid * 16;
     const size_t w8_kstride = (size_t)(g.N / 32) * 2048;
-    unsigned char* lds8 = lds_raw + MX_W8_OFF;
+    unsigned char* lds8 = lds_raw + C::W8_OFF;
     auto dma16 = [](const void* s, void* d) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
     };
-    auto issue = [&](int kt, int stg) {                // five wave-instructions
-        half_t* st = lds + stg * MX_STAGE + wid * 512;
+    auto issue = [&](int kt, int stg) {                // NA + NW wave-instructions, + N8 for an odd tile
+        half_t* st = lds + stg * C::STAGE + wid * 512;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(src[i] + (size_t)kt * 4096, st + i * 4096);
-        // half (kt & 1) of the fp8 image of k64 block kt / 2, into buffer (kt / 2) & 1
-        dma16(src8 + (size_t)(kt >> 1) * w8_kstride + (kt & 1) * 8192, lds8 + ((kt >> 1) & 1) * 16384 + (kt & 1) * 8192 + wid * 1024);
+        for (int p = 0; p < C::NA; ++p) dma16(srcA[p] + (size_t)kt * 4096, st + p * C::PIECE);
+#pragma unroll
+        for (int p = 0; p < C::NW; ++p) dma16(srcW[p] + (size_t)kt * 4096, st + C::A_HALFS + p * C::PIECE);
+        if (kt & 1) {                                  // the fp8 image of k64 block kt / 2, into buffer (kt / 2) & 1 (last read L + 1 tiles ago)
+            const unsigned char* s8 = src8 + (size_t)(kt >> 1) * w8_kstride;
+            unsigned char* d8 = lds8 + ((kt >> 1) & 1) * C::W8_BYTES + wid * 1024;
+#pragma unroll
+            for (int q = 0; q < C::N8; ++q) dma16(s8 + q * C::NT * 16, d8 + q * C::NT * 16);
+        }
     };
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -952,19 +957,18 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
     int offA[WM][2], offW[WN][2];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
-        const int row = wr * 64 + i * 32 + l31, r = row & 127;
+        const int row = wr * WM * 32 + i * 32 + l31, r = row & 127;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             offA[i][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-        const int row = wc * 128 + j * 32 + l31, r = row & 127;
+        const int row = wc * WN * 32 + j * 32 + l31, r = row & 127;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            offW[j][ks] = (2 + (row >> 7)) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+            offW[j][ks] = C::A_HALFS + (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
     }
-    const int sb = g.w8_scale * 0x01010101;
     i32x8 a8[WM];
     // one k32 tile: the fp16 product, and the bf8 image of its A fragments into half HALF of the fp8 operand.
     // SWAP: the W fragments go first, the accumulators hold the transposed tile (qk_staged_store)
@@ -992,31 +996,36 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
             }
         }
     };
-    auto top = [&](int kt, int stg_next) {             // tile kt has landed for everybody; stage of tile kt - 1 is free again
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile kt has landed for everybody; the stage of tile kt - 1 is free again.  Younger than tile kt's DMA group at this point:
+    // the groups of tiles kt + 1 .. kt + L - 1, of which the odd ones carry an fp8 image
+    auto top = [&](int kt, int stg_next, auto par_c) {
+        constexpr int P = decltype(par_c)::value;
+        constexpr int n_odd = P == 0 ? L / 2 : (L - 1) / 2;
+        if (kt + L - 1 < nk) wait_vmcnt<(L - 1) * (C::NA + C::NW) + n_odd * C::N8>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) issue(kt + 2, stg_next);
+        if (kt + L < nk) issue(kt + L, stg_next);
     };
     auto kloop = [&](auto swap_c) {
         constexpr bool SWAP = decltype(swap_c)::value;
-        issue(0, 0);
-        issue(1, 1);
+#pragma unroll
+        for (int t = 0; t < L; ++t)
+            if (t < nk) issue(t, t);
         int stg = 0;                                       // stage of tile kt
         for (int kt = 0; kt < nk; kt += 2) {
-            const int s1 = stg == 2 ? 0 : stg + 1, s2 = s1 == 2 ? 0 : s1 + 1;
-            top(kt, s2);
-            tile(lds + stg * MX_STAGE, std::integral_constant<int, 0>{}, swap_c);
+            const int s1 = stg + 1 == NS ? 0 : stg + 1, s2 = s1 + 1 == NS ? 0 : s1 + 1;
+            top(kt, stg == 0 ? NS - 1 : stg - 1, std::integral_constant<int, 0>{});      // (stg + L) % NS
+            tile(lds + stg * C::STAGE, std::integral_constant<int, 0>{}, swap_c);
             __builtin_amdgcn_sched_barrier(0);
-            top(kt + 1, stg);
-            tile(lds + s1 * MX_STAGE, std::integral_constant<int, 1>{}, swap_c);
+            top(kt + 1, stg, std::integral_constant<int, 1>{});                          // (s1 + L) % NS
+            tile(lds + s1 * C::STAGE, std::integral_constant<int, 1>{}, swap_c);
             {
-                const unsigned char* wb = lds8 + ((kt >> 1) & 1) * 16384;
+                const unsigned char* wb = lds8 + ((kt >> 1) & 1) * C::W8_BYTES;
                 i32x8 w8[WN];
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    const unsigned char* p = wb + (size_t)((wc * 4 + j) * 2) * 1024 + lane * 16;
+                    const unsigned char* p = wb + (size_t)((wc * WN + j) * 2) * 1024 + lane * 16;
                     const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
                     const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
                     w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
@@ -1024,15 +1033,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j)      // format selectors: 1 = bf8 (e5m2) for the activation, 0 = fp8 (e4m3) for W_lo; scales: 2^0 and the matrix's
-                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[j], a8[i], acc[i][j], 0, 1, 0, sb, 0, 0x7f7f7f7f)
-                                         : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
+                    for (int j = 0; j < WN; ++j)      // both operands bf8 (format selector 1); literal zero scale operands select the UNSCALED instruction
+                        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[j], a8[i], acc[i][j], 1, 1, 0, 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 1, 0, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             stg = s2;
         }
     };
-    if (OUT == OUT_QKV) {
+    if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         // block-uniform: a Q or K tile (columns below 2 d) is computed transposed and leaves through LDS in full rows
         if ((stage_vt & 2) && n0 < 2 * g.d && g.d % 128 == 0) {
             kloop(std::true_type{});
@@ -1042,7 +1051,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
         }
     }
     kloop(std::false_type{});
-    if (OUT == OUT_QKV) {
+    if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && (stage_vt & 1)) {
             __syncthreads();
             if (vt_staged_store<true>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
@@ -1051,18 +1060,45 @@ __global__ __launch_bounds__(512, 2) void gemm_mx_dma256x256_kernel(GemmHArgs g,
     gemm_h_epilogue<WM, WN, EPI, OUT, true>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
-template <int EPI, int OUT>
-inline hipError_t launch_gemm_mx_dma256x256(const GemmHArgs& g, hipStream_t st) {
-    const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
+template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS>
+inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
+    using C = MxCfg<WR, WC, WM, WN, NS>;
+    const int ntm = (g.M + C::BM - 1) / C::BM, ntn = g.N / C::BN;
     static bool attr_seen[64] = {};
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_dma256x256_kernel<EPI, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)MX_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     }
     const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only
-    hipLaunchKernelGGL((gemm_mx_dma256x256_kernel<EPI, OUT>), dim3(ntm * ntn), dim3(512), MX_LDS_BYTES, st, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
                        vs == 2 ? 0 : (vs == 3 ? 1 : 3));
     return hipGetLastError();
+}
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_64(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 1, 1, 4>(g, st); }
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_128(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 2, 2, 4>(g, st); }
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x128(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 2, 3>(g, st); }
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x256(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 4, 3>(g, st); }
+
+// the F16X2 shape rules (launch_gemm_h_mode below) for the fp8-correction kernels
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_mx(const GemmHArgs& g, hipStream_t st) {
+    const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const int v = tune().gemm_h_variant;
+    if (v == 3) return launch_gemm_mx_128<EPI, OUT>(g, st);
+    if (v == 4) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
+    if (v == 5) return launch_gemm_mx_64<EPI, OUT>(g, st);
+    if constexpr (EPI != EPI_CSL)
+        if (v == 6 && g.N % 256 == 0) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
+    if (big < 256) return launch_gemm_mx_64<EPI, OUT>(g, st);
+    const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+    auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };
+    if constexpr (EPI != EPI_CSL)
+        if (g.N % 256 == 0) {
+            const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
+            if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
+        }
+    if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
+    return launch_gemm_mx_128<EPI, OUT>(g, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1150,6 +1186,9 @@ inline hipError_t launch_gemm_h_dma64(const GemmHArgs& g, hipStream_t st) {
 
 template <int EPI, int OUT, bool X2>
 inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
+    if constexpr (X2)      // JMID_PREC_F16MX: every shape has its fp8-correction kernel (N a multiple of 128, K of 64: all of the net's GEMMs)
+        if (g.W8 && g.K % 64 == 0 && g.N % 128 == 0 && tune().gemm_h_variant != 1 && tune().gemm_h_variant != 2)
+            return launch_gemm_mx<EPI, OUT>(g, st);
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     // 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged, 3 = 128x128 LDS-DMA, 4 = 256x128 LDS-DMA,
     // 5 = 64x64 LDS-DMA, 6 = 256x256 LDS-DMA (N % 256 == 0)
@@ -1168,11 +1207,7 @@ inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     // too many registers next to the 128 accumulators
     if (EPI != EPI_CSL && g.N % 256 == 0) {
         const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
-        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) {
-            if constexpr (X2 && EPI != EPI_CSL)
-                if (g.W8 && g.K % 64 == 0) return launch_gemm_mx_dma256x256<EPI, OUT>(g, st);
-            return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
-        }
+        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
     }
     if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT, X2>(g, st);
     return launch_gemm_h_dma<EPI, OUT, X2>(g, st);

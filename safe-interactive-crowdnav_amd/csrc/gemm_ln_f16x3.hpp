@@ -38,8 +38,7 @@ struct GemmLnArgs {
     float eps;
     int* range_flag;
     int x2;                       // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
-    const unsigned char* W8;      // JMID_PREC_F16MX: fp8 image of W_lo (gemm_f16x3.hpp::w8_image_kernel), or null
-    int w8_scale;
+    const unsigned char* W8;      // JMID_PREC_F16MX: bf8 image of W_lo (gemm_f16x3.hpp::w8_image_kernel), or null
 };
 
 // fp32 row-major [512, K] -> k16-panel hi/lo planes
@@ -53,6 +52,97 @@ __global__ void split_planes_k16_kernel(const float* in, half_t* hi, half_t* lo,
         hi[o] = h;
         lo[o] = l;
     }
+}
+
+// epilogue of the 64-row kernels (same arithmetic, in the same order, as add_ln_kernel<2, true>)
+__device__ __forceinline__ void gln64_epilogue(const GemmLnArgs& g, f32x16 (&accm)[2][2], unsigned char* lds_raw, int m0, int wid,
+                                               int wc, int lane, int l31, int hi) {
+    constexpr int WM = 2, WN = 2;
+    // ---- epilogue.  The residual rows (8 per wave) are requested first: their HBM latency hides under the tile
+    // write.  Rows past M exist in the padded panels, so the loads need no guard (the stores do).
+    constexpr int d = GLN_BN;
+    f16x4 rph[8][2], rpl[8][2];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t ob = blk_index(m0 + wid * 8 + rr, (i * 64 + lane) * 4, d);
+            rph[rr][i] = *reinterpret_cast<const f16x4*>(g.Xh + ob);
+            rpl[rr][i] = *reinterpret_cast<const f16x4*>(g.Xl + ob);
+        }
+    f32x4 gm[2], bt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gm[i] = *reinterpret_cast<const f32x4*>(g.gamma + (i * 64 + lane) * 4);
+        bt[i] = *reinterpret_cast<const f32x4*>(g.beta + (i * 64 + lane) * 4);
+    }
+    // Y tile (fp32, + bias) into LDS
+    __builtin_amdgcn_s_barrier();          // everybody is done with the rings (all DMAs have landed: vmcnt(0) above)
+    float* tile = reinterpret_cast<float*>(lds_raw);
+    {
+        float bv[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bv[j] = g.bias[wc * 64 + j * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tile[(i * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
+                        fmaf(accm[i][j][r], kWInv, bv[j]);
+    }
+    __syncthreads();
+    // residual + LayerNorm, one wave per row, 8 rows per wave (the arithmetic of add_ln_kernel<2, true>)
+    bool overflow = false;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+        const int trow = wid * 8 + rr, row = m0 + trow;
+        f32x4 v[2];
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (float)rph[rr][i][e] + (float)rpl[rr][i][e];
+            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
+            v[i] = a + y;
+            sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum(sacc) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)d + g.eps);
+        if (row < g.M) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                f16x4 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                    half_t hh, ll;
+                    split_f32(o, hh, ll);
+                    overflow |= !(fabsf(o) <= kHalfMax);
+                    vh[e] = hh;
+                    vl[e] = ll;
+                }
+                const size_t ob = blk_index(row, c, d);
+                *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
+                *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
+            }
+        }
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
 }
 
 template <bool X2>
@@ -150,91 +240,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_f16x3_kernel(GemmLnArgs g, int
         step(s + 1, 1);
     }
 
-    // ---- epilogue.  The residual rows (8 per wave) are requested first: their HBM latency hides under the tile
-    // write.  Rows past M exist in the padded panels, so the loads need no guard (the stores do).
-    constexpr int d = GLN_BN;
-    f16x4 rph[8][2], rpl[8][2];
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t ob = blk_index(m0 + wid * 8 + rr, (i * 64 + lane) * 4, d);
-            rph[rr][i] = *reinterpret_cast<const f16x4*>(g.Xh + ob);
-            rpl[rr][i] = *reinterpret_cast<const f16x4*>(g.Xl + ob);
-        }
-    f32x4 gm[2], bt[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        gm[i] = *reinterpret_cast<const f32x4*>(g.gamma + (i * 64 + lane) * 4);
-        bt[i] = *reinterpret_cast<const f32x4*>(g.beta + (i * 64 + lane) * 4);
-    }
-    // Y tile (fp32, + bias) into LDS
-    __builtin_amdgcn_s_barrier();          // everybody is done with the rings (all DMAs have landed: vmcnt(0) above)
-    float* tile = reinterpret_cast<float*>(lds_raw);
-    {
-        float bv[WN];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) bv[j] = g.bias[wc * 64 + j * 32 + l31];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) asm volatile("" : "+v"(bv[j]));
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    tile[(i * 32 + frag_row(r, hi)) * GLN_TILE_LD + wc * 64 + j * 32 + l31] =
-                        fmaf(accm[i][j][r], kWInv, bv[j]);
-    }
-    __syncthreads();
-    // residual + LayerNorm, one wave per row, 8 rows per wave (the arithmetic of add_ln_kernel<2, true>)
-    bool overflow = false;
-#pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-        const int trow = wid * 8 + rr, row = m0 + trow;
-        f32x4 v[2];
-        float sacc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = (i * 64 + lane) * 4;
-            f32x4 a;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = (float)rph[rr][i][e] + (float)rpl[rr][i][e];
-            const f32x4 y = *reinterpret_cast<const f32x4*>(tile + trow * GLN_TILE_LD + c);
-            v[i] = a + y;
-            sacc += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
-        const float mean = wave_sum(sacc) / (float)d;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = v[i][e] - mean;
-                q += t * t;
-            }
-        const float rstd = rsqrtf(wave_sum(q) / (float)d + g.eps);
-        if (row < g.M) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = (i * 64 + lane) * 4;
-                f16x4 vh, vl;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
-                    half_t hh, ll;
-                    split_f32(o, hh, ll);
-                    overflow |= !(fabsf(o) <= kHalfMax);
-                    vh[e] = hh;
-                    vl[e] = ll;
-                }
-                const size_t ob = blk_index(row, c, d);
-                *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
-                *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
-            }
-        }
-    }
-    if (overflow) atomicOr(g.range_flag, 1);
+    gln64_epilogue(g, accm, lds_raw, m0, wid, wc, lane, l31, hi);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -443,8 +449,9 @@ constexpr size_t GLNX_RING_BYTES = size_t(GLNX_A_OFF + 3 * GLNX_A_STAGE) * sizeo
 constexpr size_t GLNX_LDS_BYTES = GLNX_RING_BYTES > size_t(64) * GLN_TILE_LD * sizeof(float) ? GLNX_RING_BYTES
                                                                                               : size_t(64) * GLN_TILE_LD * sizeof(float);
 
-__global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int ntm) {
-    constexpr int WM = 4, WN = 2;
+template <int WM>      // 4: 128-row tiles, 2: 64-row tiles (chosen by grid fill like the F16X2 kernels)
+__global__ __launch_bounds__(512, 2) void gemm_ln_mx_kernel(GemmLnArgs g, int ntm) {
+    constexpr int WN = 2, BM = 32 * WM;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -453,16 +460,20 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int m0 = tm * GLN2_BM;
+    const int m0 = tm * BM;
     const int nk = g.K / 32, nsteps = 2 * nk, nkb = g.K / 64;
 
     auto dma16 = [](const void* s, void* d) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
     };
-    const half_t* a_hi = g.Ahi + (size_t)tm * nk * 4096 + tid * 8;
+    // a k32 tile of A_hi: a whole 8 KB panel image (128 rows, one instruction per wave) or a 4 KB half (64 rows: waves 0-3 only)
+    const bool a_wave = WM == 4 || wid < 4;
+    const half_t* a_hi = WM == 4 ? g.Ahi + (size_t)tm * nk * 4096 + tid * 8
+                                 : g.Ahi + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + (tid & 255) * 8;
     auto issueA = [&](int ka) {     // one wave-instruction; past the end: the last tile again into its own stage
+        if (!a_wave) return;
         const int kk = ka < nk ? ka : nk - 1;
-        dma16(a_hi + (size_t)kk * 4096, lds + GLNX_A_OFF + (kk % 3) * GLNX_A_STAGE + wid * 512);
+        dma16(a_hi + (size_t)kk * 4096, lds + GLNX_A_OFF + (kk % 3) * GLNX_A_STAGE + (WM == 4 ? wid : wid & 3) * 512);
     };
     auto issueW = [&](int s, int stage) {
         half_t* st = lds + stage * GLNX_W_STAGE + wc * 64 * 16;
@@ -492,7 +503,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) offW[j] = (wc * 64 + j * 32 + l31) * 16 + hi * 8;
-    const int sb = g.w8_scale * 0x01010101;
     i32x8 a8[WM];
 
     issueW8(0);
@@ -504,8 +514,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int
     auto step = [&](const int s, auto q_c) {
         constexpr int Q = decltype(q_c)::value, ks = Q & 1;
         if (s + 1 >= nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (Q <= 1 && s >= 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (a_wave) {
+            if (Q <= 1 && s >= 4) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {                    // 64-row tiles, waves 4-7: no A instruction of their own in flight
+            if (Q <= 1 && s >= 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         if (ks == 0) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (s + 2 < nsteps) issueW(s + 2, wst == 0 ? 2 : wst - 1);
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 1, 0, 0, 0, 0);   // unscaled, both bf8
             __builtin_amdgcn_sched_barrier(0);
             if ((s >> 2) + 1 < nkb) issueW8((s >> 2) + 1);
         }
@@ -553,7 +568,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_mx_kernel(GemmLnArgs g, int
         step(s + 2, std::integral_constant<int, 2>{});
         step(s + 3, std::integral_constant<int, 3>{});
     }
-    gln128_epilogue(g, acc, lds_raw, m0, wid, wc, lane, l31, hi);
+    if constexpr (WM == 4) gln128_epilogue(g, acc, lds_raw, m0, wid, wc, lane, l31, hi);
+    else gln64_epilogue(g, acc, lds_raw, m0, wid, wc, lane, l31, hi);
 }
 
 template <bool X2>
@@ -582,20 +598,25 @@ inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
 
 inline hipError_t launch_gemm_ln_mx(const GemmLnArgs& g, hipStream_t st) {
     static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (first_use_on_device(attr_seen)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_mx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)GLNX_LDS_BYTES);
-    const int ntm = (g.M + GLN2_BM - 1) / GLN2_BM;
-    hipLaunchKernelGGL(gemm_ln128_mx_kernel, dim3(ntm), dim3(512), GLNX_LDS_BYTES, st, g, ntm);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_mx_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)GLNX_LDS_BYTES);
+    }
+    // the row tile by grid fill, as launch_gemm_ln_mode
+    auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };
+    const long n128 = (g.M + GLN2_BM - 1) / GLN2_BM, n64 = (g.M + GLN_BM - 1) / GLN_BM;
+    if (tune().ln_rows == 128 || (tune().ln_rows == 0 && 1.04 * fill(n128) >= fill(n64))) {
+        hipLaunchKernelGGL(gemm_ln_mx_kernel<4>, dim3((int)n128), dim3(512), GLNX_LDS_BYTES, st, g, (int)n128);
+    } else {
+        hipLaunchKernelGGL(gemm_ln_mx_kernel<2>, dim3((int)n64), dim3(512), GLNX_LDS_BYTES, st, g, (int)n64);
+    }
     return hipGetLastError();
 }
 
 inline hipError_t launch_gemm_ln(const GemmLnArgs& g, hipStream_t st) {
-    if (g.x2 && g.W8 && g.K % 64 == 0) {
-        auto fill = [](long n) { return (double)n / (double)(((n + 255) / 256) * 256); };
-        const long n128 = (g.M + GLN2_BM - 1) / GLN2_BM, n64 = (g.M + GLN_BM - 1) / GLN_BM;
-        if (tune().ln_rows == 128 || (tune().ln_rows == 0 && 1.04 * fill(n128) >= fill(n64))) return launch_gemm_ln_mx(g, st);
-    }
+    if (g.x2 && g.W8 && g.K % 64 == 0) return launch_gemm_ln_mx(g, st);
     return g.x2 ? launch_gemm_ln_mode<true>(g, st) : launch_gemm_ln_mode<false>(g, st);
 }
 

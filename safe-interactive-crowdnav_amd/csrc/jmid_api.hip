@@ -93,7 +93,7 @@ struct jmid_ctx {
     std::map<std::string, std::vector<size_t>> expected;  // name -> shape
     std::map<std::string, DevBuf> w;
     std::map<std::string, HalfPair> wsplit;  // hi/lo fp16 planes of the GEMM weights (F16X3 path)
-    struct W8Image { unsigned char* p = nullptr; int scale = 0; };
+    struct W8Image { unsigned char* p = nullptr; };
     std::map<std::string, W8Image> w8;       // JMID_PREC_F16MX: fp8 images of W_lo (w8_image_kernel), keyed like wsplit
     int mx = 0;          // the running call is JMID_PREC_F16MX (x2 is set as well: everything not on the fp8 path runs as F16X2)
     std::map<std::string, HalfPair> w16;     // k16-panel copies of out_proj / linear2 for the fused GEMM + LayerNorm
@@ -312,32 +312,16 @@ int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
 // JMID_PREC_F16MX: hand the GEMM the fp8 image of this weight's lo plane (the kernels that have no fp8 path ignore it)
 void set_w8(jmid_ctx* h, GemmHArgs& g, const std::string& name) {
     g.W8 = nullptr;
-    g.w8_scale = 0;
     if (!h->mx) return;
     auto it = h->w8.find(name);
     if (it == h->w8.end()) return;
     g.W8 = it->second.p;
-    g.w8_scale = it->second.scale;
 }
 
-// fp8 image of W_lo for a device-resident fp32 weight [N, K] (N % 32 == 0, K % 64 == 0)
+// bf8 image of W_lo for a device-resident fp32 weight [N, K] (N % 32 == 0, K % 64 == 0)
 int make_w8(jmid_ctx* h, const float* dW, int N, int K, jmid_ctx::W8Image* out) {
-    unsigned* dmax = nullptr;
-    HIPCHK(h, hipMalloc((void**)&dmax, sizeof(unsigned)));
-    HIPCHK(h, hipMemsetAsync(dmax, 0, sizeof(unsigned), h->stream));
-    hipLaunchKernelGGL(w_lo_absmax_kernel, dim3(256), dim3(256), 0, h->stream, dW, (size_t)N * K, kWScale, dmax);
-    unsigned bits = 0;
-    HIPCHK(h, hipMemcpyAsync(&bits, dmax, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    HIPCHK(h, hipFree(dmax));
-    float mx;
-    memcpy(&mx, &bits, sizeof(float));
-    int e = -127;                                   // W_lo = fp8 x 2^e with the largest |W_lo| just inside the e4m3 range (448)
-    if (mx > 0.f) e = (int)ceilf(log2f(mx / 448.0f));
-    if (e < -127) e = -127;
-    out->scale = e + 127;
     HIPCHK(h, hipMalloc((void**)&out->p, (size_t)N * K));
-    hipLaunchKernelGGL(w8_image_kernel, dim3(256), dim3(256), 0, h->stream, dW, out->p, N, K, kWScale, out->scale);
+    hipLaunchKernelGGL(w8_image_kernel, dim3(256), dim3(256), 0, h->stream, dW, out->p, N, K, kWScale);
     HIPCHK(h, hipGetLastError());
     return 0;
 }
@@ -544,7 +528,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                               W(h, p + ".norm1.bias"), sb.Xh, sb.Xl, M, d, 1e-5f, h->range_flag, h->x2};
                 if (h->mx) {
                     auto it8 = h->w8.find(p + ".self_attn.out_proj.weight");
-                    if (it8 != h->w8.end()) { gl.W8 = it8->second.p; gl.w8_scale = it8->second.scale; }
+                    if (it8 != h->w8.end()) gl.W8 = it8->second.p;
                 }
                 ProfScope ps(h, KC_GEMM_OUT);
                 HIPCHK(h, launch_gemm_ln(gl, h->stream));
@@ -569,7 +553,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                               W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag, h->x2};
                 if (h->mx) {
                     auto it8 = h->w8.find(p + ".linear2.weight");
-                    if (it8 != h->w8.end()) { gl.W8 = it8->second.p; gl.w8_scale = it8->second.scale; }
+                    if (it8 != h->w8.end()) gl.W8 = it8->second.p;
                 }
                 ProfScope ps(h, KC_GEMM_FF2);
                 HIPCHK(h, launch_gemm_ln(gl, h->stream));
@@ -1503,7 +1487,7 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
         g.M = M; g.N = N; g.K = K;
         if (h->mx && N % 32 == 0 && K % 64 == 0) {
             if (int rc8 = make_w8(h, dW, N, K, &w8img)) return rc8;
-            g.W8 = w8img.p; g.w8_scale = w8img.scale;
+            g.W8 = w8img.p;
         }
         rc = relu ? run_gemm_h<EPI_BIAS_RELU, OUT_F32>(h, KC_GEMM_QKV, g) : run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g);
     }

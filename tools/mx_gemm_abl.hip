@@ -7,6 +7,10 @@
 #include <cstdlib>
 #include <vector>
 using namespace jmid;
+// the probe keeps the layout of the first version of the kernel: three 32 KB stages, then two 16 KB fp8-image buffers (halves per tile)
+constexpr int MX_STAGE = 4 * DMA_PLANE;
+constexpr size_t MX_W8_OFF = size_t(3) * MX_STAGE * sizeof(half_t);
+constexpr size_t MX_LDS_BYTES = MX_W8_OFF + 2 * 16384;
 
 template <int ABL>
 __global__ __launch_bounds__(512, 2) void probe_kernel(GemmHArgs g, int ntm, int ntn) {
@@ -62,7 +66,6 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(GemmHArgs g, int ntm, int
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) offW[j][ks] = (2 + (row >> 7)) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
     }
-    const int sb = g.w8_scale * 0x01010101;
     i32x8 a8[WM];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(GemmHArgs g, int ntm, int
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb);
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 1, 0, 0, 0, 0);
             } else {
 #pragma unroll
                 for (int j = 0; j < WN; ++j) asm volatile("" ::"v"(w8[j]));
@@ -179,7 +182,7 @@ int main() {
         GemmHArgs g{};
         g.Ahi = (half_t*)dev_rand(blk_plane_elems(M, K) * 2, 0x3f3f); g.Alo = g.Ahi;
         g.Whi = (half_t*)dev_rand(blk_plane_elems(N, K) * 2, 0x3f3f); g.Wlo = g.Whi;
-        g.W8 = (unsigned char*)dev_rand((size_t)N * K, 0x3f3f); g.w8_scale = 115;
+        g.W8 = (unsigned char*)dev_rand((size_t)N * K, 0x3f3f);
         std::vector<float> hb(N, 0.1f); float* bias; hipMalloc(&bias, N * 4); hipMemcpy(bias, hb.data(), N * 4, hipMemcpyHostToDevice);
         g.bias = bias; g.M = M; g.N = N; g.K = K; g.x2 = 1;
         half_t *chi, *clo; hipMalloc(&chi, blk_plane_elems(M, N) * 2); hipMalloc(&clo, blk_plane_elems(M, N) * 2);

@@ -56,7 +56,6 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(GemmLnArgs g, int ntm) {
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) offW[j] = (wc * 64 + j * 32 + l31) * 16 + hi * 8;
-    const int sb = g.w8_scale * 0x01010101;
     i32x8 a8[WM];
 
     issueW8(0);
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void probe_kernel(GemmLnArgs g, int ntm) {
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    { if (!(ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 0, 0, 0x7f7f7f7f, 0, sb); else asm volatile("" ::"v"(a8[i]), "v"(w8[j])); }
+                    { if (!(ABL & 2)) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 1, 0, 0, 0, 0); else asm volatile("" ::"v"(a8[i]), "v"(w8[j])); }
             __builtin_amdgcn_sched_barrier(0);
             if ((s >> 2) + 1 < nkb) issueW8((s >> 2) + 1);
         }
@@ -145,7 +144,7 @@ int main() {
         GemmLnArgs g{};
         g.Ahi = (half_t*)dev_rand(blk_plane_elems(M, K) * 2, 0x3f3f); g.Alo = g.Ahi;
         g.W16hi = (half_t*)dev_rand((size_t)512 * K * 2, 0x3f3f); g.W16lo = g.W16hi;
-        g.W8 = (unsigned char*)dev_rand((size_t)512 * K, 0x3f3f); g.w8_scale = 115;
+        g.W8 = (unsigned char*)dev_rand((size_t)512 * K, 0x3f3f);
         std::vector<float> hb(512, 0.1f); float* v; hipMalloc(&v, 512 * 4); hipMemcpy(v, hb.data(), 512 * 4, hipMemcpyHostToDevice);
         g.bias = v; g.gamma = v; g.beta = v;
         g.Xh = (half_t*)dev_rand(blk_plane_elems(M, 512) * 2, 0x3f3f); g.Xl = (half_t*)dev_rand(blk_plane_elems(M, 512) * 2, 0x0f3f);

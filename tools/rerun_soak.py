@@ -21,6 +21,7 @@ for kv in sys.argv[6:]:                      # extra tuning knobs: key=value
     k, v = kv.split("=")
     eng.set_tuning(k, int(v))
 eng.set_chunk_episodes(chunk)
+eng.set_tuning("lanes", 1)
 ref, bad = eng.denoise(x_T, ctx, None, precision=prec, want_pos=False)[0].clone(), 0    # lanes = 1 reference
 eng.set_tuning("lanes", lanes)
 for i in range(calls):
