@@ -15,9 +15,10 @@ Default workload = BASELINE.json configs[2] ("256 parallel episodes x N=5 x K=20
 throughput target and the roofline are quoted on; the single-scene case (configs[1], E=1) is measured in the same run
 and reported under "single_scene".
 
-Precision modes.  `value` is the mode named by --precision (default f16x2: fp16 activation x split-fp16 weight, the
-mode the drop-in predictor class `HumanTrajectoryForecasterSim` runs by default; >= the bf16 BASELINE.json names).
-Every mode listed in --modes (default "f16x2,f16x3"; f16x3 = fp32-class three-term products) gets THE SAME measurement - W warm-up steps, one untimed profiling step, K timed steps between
+Precision modes.  `value` is the mode named by --precision (default f16mx: fp16 activation x split-fp16 weight with the
+weight-lo correction term as one bf8 x bf8 MFMA per k64, the mode the drop-in predictor class `HumanTrajectoryForecasterSim`
+runs by default; >= the bf16 BASELINE.json names).  Every mode listed in --modes (default "f16mx,f16x2,f16x3": f16x2 = the
+same products with the correction term in fp16, f16x3 = fp32-class three-term products) gets THE SAME measurement - W warm-up steps, one untimed profiling step, K timed steps between
 barriers, parity against the oracle on the same episodes - and is reported under `modes[<name>]` with the same keys;
 the top-level keys are a copy of modes[--precision].  Prints ONE JSON line on rank 0.
 """
@@ -56,14 +57,14 @@ DTYPE_TEXT = {
     "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate",
     "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; softmax logits, "
              "residual stream, LayerNorm and DDIM state at f32-class precision",
-    "f16mx": "f16x2 with the weight-lo correction term of every large GEMM as ONE block-scaled fp8 MFMA per k64 "
-             "(bf8 image of the fp16 activation x e4m3 image of W_lo): 1.5 MFMA passes per GEMM product, fp32 accumulate; "
-             "attention, residual stream, LayerNorm and DDIM state as in f16x2",
+    "f16mx": "fp16 activation x split-fp16 (hi + lo) weight: A_hi x W_hi as fp16 MFMAs plus the correction term as ONE bf8 x bf8 MFMA "
+             "per k64 (bf8 = top byte of the fp16 activation / of fp16(W_lo)): 1.5 MFMA passes per GEMM product, fp32 accumulate; "
+             "attention (softmax logits with all three fp16 terms), residual stream, LayerNorm and DDIM state at f32-class precision",
 }
 PROF_CLASSES = ["gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_ff", "gemm_tail", "attention"]
 # kernel class -> substring of the kernel names of that class in the per-call PMC summary (tools/pmc_call.sh)
-PMC_KERNEL_OF_CLASS = {"attention": "attn_f16x3_dma_kernel", "gemm_qkv": "gemm_f16x3_dma256x256_kernel<0, 2",
-                       "gemm_ff1": "gemm_f16x3_dma256x256_kernel<1, 1", "gemm_ff": "ff_ln_f16x3_kernel",
+PMC_KERNEL_OF_CLASS = {"attention": "attn_f16x3_dma_kernel", "gemm_qkv": ("gemm_f16x3_dma256x256_kernel<0, 2", "gemm_mx_kernel<0, 2"),
+                       "gemm_ff1": ("gemm_f16x3_dma256x256_kernel<1, 1", "gemm_mx_kernel<1, 1"), "gemm_ff": "ff_ln_f16x3_kernel",
                        "gemm_attn_out": "gemm_ln", "gemm_ff2": "gemm_ln"}
 
 
@@ -119,8 +120,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--episodes-per-gpu", type=int, default=0)
-    ap.add_argument("--precision", default="f16x2", choices=["f32", "f16x3", "f16x2", "f16mx"], help="the mode `value` is quoted on")
-    ap.add_argument("--modes", default="f16x2,f16x3",
+    ap.add_argument("--precision", default="f16mx", choices=["f32", "f16x3", "f16x2", "f16mx"], help="the mode `value` is quoted on")
+    ap.add_argument("--modes", default="f16mx,f16x2,f16x3",
                     help="comma list of modes measured identically in this run (the --precision mode is always included)")
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
@@ -289,7 +290,8 @@ def main():
             pmc, src = pmc_summary(precision)
             if pmc and joint and (N, K, H, steps50) == (5, 20, 12, 50):
                 kname = PMC_KERNEL_OF_CLASS.get(dom)
-                rows = [v for k, v in pmc.get("kernels", {}).items() if kname and kname in k and v.get("launches", 0) >= 50]
+                knames = (kname,) if isinstance(kname, str) else (kname or ())
+                rows = [v for k, v in pmc.get("kernels", {}).items() if any(n in k for n in knames) and v.get("launches", 0) >= 50]
                 if rows:
                     r = max(rows, key=lambda v: v["hbm_bytes_per_launch"])
                     chunks_per_step = dom_t["launches"] / (steps50 * args.steps * dims.tf_layer)
@@ -349,9 +351,8 @@ def main():
     out["modes_note"] = ("every mode: same batch, same warm-up, same number of timed steps between the same barriers, same "
                          "parity sample; `value` and the top-level keys are modes[config.precision]")
     if len(modes) > 1:
-        a, b = modes[0], modes[1]
         out["mean_ADE_between_modes_m"] = {f"{a}_vs_{b}": float(np.linalg.norm(
-            (last_pos[a] - last_pos[b]).cpu().numpy(), axis=-1).mean())}
+            (last_pos[a] - last_pos[b]).cpu().numpy(), axis=-1).mean()) for i, a in enumerate(modes) for b in modes[i + 1:]}
 
     # ---- single scene (BASELINE configs[1]) latency in the same run, every mode
     if world == 1:

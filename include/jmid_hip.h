@@ -54,6 +54,12 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     the softmax logits Q.K keep all three terms (their error is exponentiated) and the residual
  *                     stream, LayerNorm and DDIM state keep hi + lo.  Mean ADE vs the reference 7e-6 m on the cfg3
  *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~25 % more trajectories per second on batches; the lo planes this mode never reads are not written
+ *   JMID_PREC_F16MX   F16X2 with the weight-lo correction term of every GEMM on the fp8 matrix path: A_hi x W_hi as fp16 MFMAs
+ *                     plus ONE v_mfma_f32_32x32x64_f8f6f4 per 64-deep block on bf8(A_hi) x bf8(W_lo) (bf8 = e5m2 = the top byte
+ *                     of the fp16 value, rounded to nearest; unscaled) - 1.5 instead of 2 MFMA passes per product.  The term is
+ *                     2^-11 of the product, so its 2-bit significand costs nothing measurable: same GEMM error (2^-12.7) and
+ *                     same ADE as F16X2 on every fixture, ~10 % more trajectories per second.  Attention as in F16X2.
+ *                     Bit-identical across batch sizes / chunk plans like the other modes.  The default of the Python class.
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3, JMID_PREC_F16MX = 4 };
 
@@ -63,7 +69,7 @@ enum {
     JMID_ENOWEIGHT = -2,  /* a required weight has not been loaded */
     JMID_EHIP = -3,       /* HIP runtime error */
     JMID_ENOMEM = -4,
-    JMID_ERANGE = -5      /* F16X3/F16X2: an operand left the fp16 range; rerun with JMID_PREC_F32 */
+    JMID_ERANGE = -5      /* F16X3/F16X2/F16MX: an operand left the fp16 range; rerun with JMID_PREC_F32 */
 };
 
 /* Library / build identification (also the cheap "does it load" probe). */

@@ -572,17 +572,19 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         // to the three launches below it replaces) at the shipped width.  Opt-in: it saves two launches per step but runs
         // four waves per CU, and measured slower than the three well-occupied kernels at every batch size (one scene
         // 13.65 vs 13.23 ms per call, a 51-episode chunk +1.3 %; tools/single_scene_sweep.py tail_fuse=2,1)
-        tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse == 1;
+        tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse == 1 && !h->mx;   // the fused kernel has no fp8-correction K loop
         if (!tail_fused) {
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
         const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
         g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w3.hi; g.Wlo = w3.lo;
+        set_w8(h, g, "concat3._layer.weight");
         g.bias = W(h, "concat3._layer.bias"); g.Chi = sb.Y3h; g.Clo = sb.Y3l; g.ldc = h->dmid; g.N = h->dmid; g.K = d;
         g.goff = h->hl.g3; g.boff = h->hl.b3;
         if (int rc = (run_gemm_h<EPI_CSL, OUT_SPLIT>(h, KC_GEMM_TAIL, g))) return rc;
         const HalfPair& w4 = h->wsplit["concat4._layer.weight"];
         g.Ahi = sb.Y3h; g.Alo = sb.Y3l; g.Whi = w4.hi; g.Wlo = w4.lo;
+        set_w8(h, g, "concat4._layer.weight");
         g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
         g.goff = h->hl.g4; g.boff = h->hl.b4;
         if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
@@ -894,7 +896,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* jmid_version(void) { return "jmid_hip 0.5.0 (gfx950; f32-mfma + f16x3 / f16x2 split-mfma)"; }
+const char* jmid_version(void) { return "jmid_hip 0.6.0 (gfx950; f32-mfma + f16x3 / f16x2 split-mfma + f16mx fp8-correction)"; }
 
 int jmid_device_count(void) {
     int n = 0;

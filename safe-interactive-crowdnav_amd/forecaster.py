@@ -12,14 +12,15 @@ and nothing else.  Here the history buffers and the scene/batch construction are
 (``scene.py``), and everything from the context encoder to the integrated sample trajectories runs in the HIP
 library through the C ABI (``engine.py`` -> ``include/jmid_hip.h``).  There is no CPU fallback for that part.
 
-Arithmetic (``precision``): the contractions run in the library's F16X2 mode by default - fp16 activation operand
-times split-fp16 (hi + lo) weight, two MFMAs per product, fp32 accumulation; softmax logits, residual stream, LayerNorm
+Arithmetic (``precision``): the contractions run in the library's F16MX mode by default - fp16 activation operand times
+split-fp16 weight, as ``A_hi . W_hi`` on the fp16 matrix cores plus the correction term ``A_hi . W_lo`` as ONE bf8 x bf8
+MFMA per 64-deep block (1.5 MFMA passes per GEMM product), fp32 accumulation; softmax logits, residual stream, LayerNorm
 and DDIM state at fp32-class precision.  It is the mode ``bench.py`` quotes, >= the bf16 BASELINE.json names for this
-workload, and it holds every reference golden fixture inside the 1e-4 m mean-ADE gate (worst 5.3e-5 m on the 2-step
-fixtures, 4e-6 m on the 50-step cfg3 sample).  ``precision="f16x3"`` selects the fp32-class
-three-term products (mean ADE ~1e-6 m, the fp32-vs-fp64 noise floor; ~20 % fewer trajectories per second on batches),
-``"f32"`` the exact-fp32 MFMA path.  If an activation ever leaves the fp16 range the call is repeated transparently in
-the exact-fp32 mode.
+workload, and it holds every reference golden fixture inside the 1e-4 m mean-ADE gate with the same errors as
+``precision="f16x2"`` (the same products with the correction term in fp16: two passes; worst 5.3e-5 m on the 2-step
+fixtures, 4e-6 m on the 50-step cfg3 sample).  ``"f16x3"`` selects the fp32-class three-term
+products (mean ADE ~1e-6 m, the fp32-vs-fp64 noise floor; ~25 % fewer trajectories per second on batches), ``"f32"`` the
+exact-fp32 MFMA path.  If an activation ever leaves the fp16 range the call is repeated transparently in the exact-fp32 mode.
 
 RNG contract (``rng_compat``): ``x_T`` is always the first draw of torch's CPU default generator
 (``MID/models/diffusion.py:499``).  The reference also draws one (unused, DDIM) ``randn_like(x_T)`` per reverse step
@@ -119,7 +120,7 @@ class _ModelInfo:
 
 class HumanTrajectoryForecasterSim(ForecasterSimSuper):
     def __init__(self, env_config=None, mid_config_file=None, *, weights: Optional[JMIDWeights] = None,
-                 device_id: int = 0, precision: str = "f16x2", rng_compat: str = "auto"):
+                 device_id: int = 0, precision: str = "f16mx", rng_compat: str = "auto"):
         self.init_super(env_config)
         self.precision = precision
         if rng_compat not in ("auto", "cpu", "cuda"):
@@ -208,7 +209,7 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
 
 
 def predict_batch(engine: JmidEngine, human_xy: np.ndarray, robot_xy: np.ndarray, seeds, *, num_samples: int,
-                  num_ret_samples: int, horizon: int, time_step: float, precision: str = "f16x2"
+                  num_ret_samples: int, horizon: int, time_step: float, precision: str = "f16mx"
                   ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """``predict_ret_best()`` for E independent episodes in as few device calls as their cluster sizes allow: the feed
     of the multi-episode evaluation sweeps.

@@ -24,7 +24,7 @@ from safe_interactive_crowdnav_amd.scene import synthetic_episodes
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 ADE_GATE = 1e-4
-SPLIT_MODES = ["f16x3", "f16x2"]
+SPLIT_MODES = ["f16x3", "f16x2", "f16mx"]
 
 
 def ade(a, b):

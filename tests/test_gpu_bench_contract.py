@@ -39,20 +39,20 @@ def test_bench_json_contract():
     from safe_interactive_crowdnav_amd.forecaster import HumanTrajectoryForecasterSim
     import inspect
     default = inspect.signature(HumanTrajectoryForecasterSim.__init__).parameters["precision"].default
-    assert j["config"]["precision"] == default == "f16x2" and j["parity"]["precision"] == default
+    assert j["config"]["precision"] == default == "f16mx" and j["parity"]["precision"] == default
     assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
-    # ... and both split modes are measured the same way and reported under the same keys
-    assert set(j["modes"]) == {"f16x3", "f16x2"}
+    # ... and all split modes are measured the same way and reported under the same keys
+    assert set(j["modes"]) == {"f16x3", "f16x2", "f16mx"}
     for m, v in j["modes"].items():
         for k in MODE_KEYS + ("parity",):
             assert k in v, (m, k)
         assert v["steps"] == 1 and v["warmup"] == 1 and v["value"] > 0
         assert v["parity"]["pass"] is True and v["parity"]["episodes"] == 3
         assert v["parity"]["episode_ids"] == [0, 2, 5]          # spread over the batch: every chunk of 2 is sampled
-    assert j["value"] == j["modes"]["f16x2"]["value"] and j["ms_per_step"] == j["modes"]["f16x2"]["ms_per_step"]
+    assert j["value"] == j["modes"]["f16mx"]["value"] and j["ms_per_step"] == j["modes"]["f16mx"]["ms_per_step"]
     assert j["modes"]["f16x3"]["parity"]["mean_ADE_vs_oracle_m"] <= 1e-5       # fp32-class mode
-    assert j["mean_ADE_between_modes_m"]["f16x2_vs_f16x3"] <= 1e-4
-    assert set(j["single_scene"]["modes"]) == {"f16x3", "f16x2"}
+    assert j["mean_ADE_between_modes_m"]["f16x2_vs_f16x3"] <= 1e-4 and j["mean_ADE_between_modes_m"]["f16mx_vs_f16x2"] <= 1e-4
+    assert set(j["single_scene"]["modes"]) == {"f16x3", "f16x2", "f16mx"}
     # PMC-derived fields name the committed profile they were read from
     for k in ("traffic_source", "mfma_busy"):
         if k in r:

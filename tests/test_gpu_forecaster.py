@@ -125,7 +125,7 @@ def test_forecaster_falls_back_to_fp32_when_fp16_range_is_exceeded(tmp_path):
     t["transformer_encoder.layers.0.linear2.weight"] = t["transformer_encoder.layers.0.linear2.weight"] / 4e4
     wbig = JMIDWeights(w.dims, t)
     outs = []
-    for prec in ("f16x3", "f16x2", "f32"):
+    for prec in ("f16x3", "f16x2", "f16mx", "f32"):
         env, ypath = write_configs(str(tmp_path / prec), joint=True, ctx_dim=32, N=int(z["N"]), K=int(z["K"]),
                                    k_ret=int(z["k_ret"]), H=int(z["H"]), step=2)
         f = HumanTrajectoryForecasterSim(env, ypath, weights=wbig, precision=prec)
