@@ -51,6 +51,9 @@ struct AttnHArgs {
     float* Opart;      // [nsplit][nseq*S][d] fp32
     float* MLpart;     // [nsplit][nseq*S][nhead][2]
     int x2;            // JMID_PREC_F16X2: V enters P.V as its hi plane only (P and the logits keep all terms)
+    // JMID_PREC_F16MX (head_dim 128): bf8 images of K_hi and K_lo, [nseq*S, d] bytes each (written by the QKV GEMM instead
+    // of the fp16 K_lo plane): the two correction terms of the logits run as bf8 x bf8 MFMAs.  Null: the fp16 terms.
+    const unsigned char *K8h, *K8l;
 };
 
 template <int HD>
@@ -250,7 +253,14 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
         tprev = now_;                                                 \
         __builtin_amdgcn_sched_barrier(0);                            \
     }
-template <bool TRACE, bool X2 = false>
+// MX (JMID_PREC_F16MX): S^T = K_hi . Q_hi in fp16 as before, and the two correction terms as ONE bf8 x bf8
+// v_mfma_f32_32x32x64_f8f6f4 each per 64-deep half of the head: bf8(K_hi) . bf8(Q_lo) + bf8(K_lo) . bf8(Q_hi) - 16 instead of
+// 24 fp16-MFMA times per key tile.  The terms are 2^-12 of the logit; with 2-bit significands they are good to ~2^-15 of it,
+// which moves the attention output by 2^-18.7 (flat softmax) ... 2^-14 (logit spread 4 nats, a key at p = 0.95) relative -
+// below the 2^-12.7 of the mode's GEMMs.  bf8(K) comes from the QKV GEMM epilogue (two 4 KB images per key tile in the
+// place of the 8 KB fp16 K_lo image: same DMA bytes, same fragment-read bytes, no extra VALU work per tile); bf8(Q) is made
+// once per wave from the Q planes.  k order of the fp8 instruction: byte p of lane (row, h) is head dim 64 blk + 32 h + p.
+template <bool TRACE, bool X2 = false, bool MX = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
@@ -278,18 +288,40 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     // K / V^T tile and meets the barriers, but computes nothing
     const bool wave_idle = (qt * 4 + wid) * 32 >= S;
 
-    f16x8 qh[NKS], ql[NKS];
+    f16x8 qh[NKS], ql[MX ? 1 : NKS];
+    i32x8 q8h[2], q8l[2];            // MX: bf8 images of this lane's Q_hi / Q_lo row, 32 head dims per 64-deep block
     {
         const size_t o = (tok0 + qc) * d + h * HD + 8 * hi;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             qh[ks] = *reinterpret_cast<const f16x8*>(a.Qhi + o + 16 * ks);
-            ql[ks] = *reinterpret_cast<const f16x8*>(a.Qlo + o + 16 * ks);
+            if (!MX) ql[ks] = *reinterpret_cast<const f16x8*>(a.Qlo + o + 16 * ks);
+        }
+        if (MX) {
+            const size_t o8 = (tok0 + qc) * d + h * HD + 32 * hi;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const i32x4 vh = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qhi + o8 + 64 * blk + 8 * c));
+                    const i32x4 vl = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qlo + o8 + 64 * blk + 8 * c));
+                    q8h[blk][2 * c] = bf8_of_f16x4(vh[0], vh[1]);
+                    q8h[blk][2 * c + 1] = bf8_of_f16x4(vh[2], vh[3]);
+                    q8l[blk][2 * c] = bf8_of_f16x4(vl[0], vl[1]);
+                    q8l[blk][2 * c + 1] = bf8_of_f16x4(vl[2], vl[3]);
+                }
         }
     }
     // the Q loads are ordinary VMEM loads: retire them before the DMA ring starts so that vmcnt counts only DMAs
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qh[ks]), "+v"(ql[ks]));
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qh[ks]));
+    if (!MX) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(ql[ks]));
+    } else {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) asm volatile("" : "+v"(q8h[blk]), "+v"(q8l[blk]));
+    }
 
     f32x16 ot[NT];
 #pragma unroll
@@ -310,7 +342,16 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     auto issue_one = [&](int kt, int i) {
         half_t* st = lds + (kt & 1) * ATT_STAGE + wid * 512;
         if (i >= 6 && X2) return;   // F16X2: the V^T lo plane is neither written by the QKV epilogue nor read here
-        if (i < 4) {
+        if (MX && (i == 2 || i == 3)) {
+            // a whole bf8 K image: 32 keys x 128 bytes; thread = (key row tid / 8, stored 16-byte chunk tid % 8), which
+            // holds source chunk (tid % 8) ^ ((row >> 1) & 7): conflict-free ds_read_b128 of a lane-half's two chunks
+            const int row = tid >> 3;
+            int key = kt * KT + row;
+            key = key < S ? key : S - 1;
+            const unsigned char* src = (i == 2 ? a.K8h : a.K8l) + (tok0 + key) * d + h * HD + (((tid & 7) ^ ((row >> 1) & 7)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
+        } else if (i < 4) {
             int key = kt * KT + 16 * (i & 1) + k_row;
             key = key < S ? key : S - 1;
             const half_t* src = ((i >> 1) ? kl_g : kh_g) + (size_t)key * d + k_c * 8;
@@ -367,7 +408,35 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         f32x16 sm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
-        if (!(abl & 8)) {
+        if (MX) {
+            // fp16 part: K_hi . Q_hi, fragments read one step ahead; the next tile's DMA instructions go out one per step
+            f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + kbase + (((0 + hi) ^ kx) << 3));
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                f16x8 kh_n = kh_c;
+                if (ks + 1 < NKS) kh_n = *reinterpret_cast<const f16x8*>(Kh + kbase + (((2 * (ks + 1) + hi) ^ kx) << 3));
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
+                if (more && !(abl & 16)) issue_one(kt + 1, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                kh_c = kh_n;
+            }
+            // correction terms: bf8(K_hi) . bf8(Q_lo) + bf8(K_lo) . bf8(Q_hi), one instruction per 64-deep block and term
+            const unsigned char* k8 = reinterpret_cast<const unsigned char*>(Kl);      // K_hi image, then (4 KB on) the K_lo image
+            const int r8 = l31 * 128, sw = (l31 >> 1) & 7;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int c0 = blk * 4 + hi * 2;
+                const i32x4 h0 = *reinterpret_cast<const i32x4*>(k8 + r8 + ((c0 ^ sw) << 4));
+                const i32x4 h1 = *reinterpret_cast<const i32x4*>(k8 + r8 + (((c0 + 1) ^ sw) << 4));
+                const i32x4 l0 = *reinterpret_cast<const i32x4*>(k8 + 4096 + r8 + ((c0 ^ sw) << 4));
+                const i32x4 l1 = *reinterpret_cast<const i32x4*>(k8 + 4096 + r8 + (((c0 + 1) ^ sw) << 4));
+                const i32x8 kh8 = i32x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const i32x8 kl8 = i32x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                sm = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kh8, q8l[blk], sm, 1, 1, 0, 0, 0, 0);   // unscaled, both bf8
+                sm = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kl8, q8h[blk], sm, 1, 1, 0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (!(abl & 8)) {
             // software-pipelined fragment reads: the K fragments of step ks+1 are requested before the MFMAs of step
             // ks issue, so the LDS latency hides under 96 cycles of MFMA instead of stalling the pipe every step
             f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + kbase + (((0 + hi) ^ kx) << 3));
@@ -381,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                     kl_n = *reinterpret_cast<const f16x8*>(Kl + ok);
                 }
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
-                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[ks], sm, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[MX ? 0 : ks], sm, 0, 0, 0);
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_c, qh[ks], sm, 0, 0, 0);
                 if (more && !(abl & 16)) issue_one(kt + 1, ks);
                 __builtin_amdgcn_sched_barrier(0);
@@ -592,7 +661,14 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
         }
         const int nqt = (a.S + 127) / 128;
         const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
-        if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
+        if (a.x2 && a.K8h) {
+            static bool mx_seen[64] = {};
+            if (first_use_on_device(mx_seen))
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
+                               (unsigned long long*)nullptr);
+        } else if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
             hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
                                (unsigned long long*)nullptr);
         else

@@ -41,6 +41,10 @@ __device__ __forceinline__ void split_f32(float v, half_t& hi, half_t& lo) {
     lo = (half_t)(v - (float)hi);
 }
 __device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& lo) { split_f32(v, hi, lo); }
+// bf8 (e5m2) image of one fp16 value: its top byte after rounding to nearest
+__device__ __forceinline__ unsigned char bf8_of_f16(half_t v) {
+    return (unsigned char)((__builtin_bit_cast(unsigned short, v) + 0x80u) >> 8);
+}
 
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
@@ -66,6 +70,8 @@ struct GemmHArgs {
     int* range_flag;          // set to 1 when an emitted fp16 operand would leave the fp16 range
     int x2;                   // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
     const unsigned char* W8;  // JMID_PREC_F16MX: bf8(W_lo) in MFMA-fragment order (w8_image_kernel), or null
+    unsigned char *K8h, *K8l; // OUT_QKV, JMID_PREC_F16MX with head_dim 128: bf8 images of K_hi / K_lo, [M, d] bytes each, written
+                              // INSTEAD of the fp16 K_lo plane (attn_f16x3_dma_kernel<.., MX>); null: K_lo as fp16
 };
 
 constexpr int GEMMH_BK = 32;
@@ -100,7 +106,7 @@ __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[W
 // stores issue back to back.  The per-column scalars (bias, time part of the hyper nets) are loaded once and pinned
 // with an empty asm: otherwise hipcc re-waits `vmcnt(0)` before every use inside the store loop, and since stores
 // count on vmcnt too (CDNA4) every store would wait for the previous one to complete.
-template <int WM, int WN, int EPI, int OUT, bool X2, bool FULL>
+template <int WM, int WN, int EPI, int OUT, bool X2, bool FULL, bool K8 = false>
 __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 (&accm)[WM][WN],
                                                      int m0, int n0, int wr, int wc, int l31, int hi) {
     bool overflow = false;
@@ -191,7 +197,12 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                             g.Clo[(size_t)m * g.d + nn] = l;
                         } else if (part == 1) {
                             g.Khi[(size_t)m * g.d + nn] = h;
-                            g.Klo[(size_t)m * g.d + nn] = l;
+                            if (K8 && g.K8h) {      // K8: compile-time, only the F16MX kernels (the byte stores cost the others registers)
+                                g.K8h[(size_t)m * g.d + nn] = bf8_of_f16(h);
+                                g.K8l[(size_t)m * g.d + nn] = bf8_of_f16(l);
+                            } else {
+                                g.Klo[(size_t)m * g.d + nn] = l;
+                            }
                         } else {   // V row-major planes; v_transpose_kernel makes them key-contiguous
                             g.Vthi[(size_t)m * g.d + nn] = h;
                             if (!X2) g.Vtlo[(size_t)m * g.d + nn] = l;
@@ -204,14 +215,14 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
     if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
 }
 
-template <int WM, int WN, int EPI, int OUT, bool X2 = false>
+template <int WM, int WN, int EPI, int OUT, bool X2 = false, bool K8 = false>
 __device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&accm)[WM][WN],
                                                 int m0, int n0, int wr, int wc, int l31, int hi, int bm = 64 * WM,
                                                 int bn = 64 * WN) {
     if (m0 + bm <= g.M && n0 + bn <= g.N)
-        gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, true>(g, accm, m0, n0, wr, wc, l31, hi);
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, true, K8>(g, accm, m0, n0, wr, wc, l31, hi);
     else
-        gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, false>(g, accm, m0, n0, wr, wc, l31, hi);
+        gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, false, K8>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
 template <int WM, int WN, int EPI, int OUT, bool X2 = false>
@@ -776,23 +787,75 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
 // 16 KB of LDS with 8-byte writes (16-byte units XOR-swizzled by the row: conflict-free both ways) and out again as 16 bytes
 // per lane = 256 contiguous bytes per token row: 16 + 16 store instructions per wave instead of 256 two-byte ones.
 // Same arithmetic as gemm_h_epilogue (bias, Q pre-scaled by qscale, unscaled hi/lo split).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc)[2][4], int mw0, int nw0, half_t* wlds, int l31,
                                                 int hi, int lane) {
     const int part = nw0 / g.d, nn0 = nw0 - part * g.d;
     half_t* dst_base[2] = {part == 0 ? g.Chi : g.Khi, part == 0 ? g.Clo : g.Klo};
     const float qs = part == 0 ? g.qscale : 1.0f;
-    f32x4 bv[4][4];
+    // the values first, in place (bias, Q scale): 16 bias registers at a time instead of 64 next to the 128 accumulators
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+        f32x4 bv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[j][q] = *reinterpret_cast<const f32x4*>(g.bias + nw0 + j * 32 + 8 * q + 4 * hi);
+        for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(g.bias + nw0 + j * 32 + 8 * q + 4 * hi);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[j][q]));
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[q][e]);
+                    if (part == 0) v *= qs;
+                    acc[i][j][4 * q + e] = v;
+                }
+    }
     bool overflow = false;
+    const bool k8 = part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
+        if (plane == 1 && k8) {
+            // byte planes through the same LDS: [64 rows][128 bytes] per image, 16-byte units XOR-swizzled by the row; one
+            // image at a time (both at once cost 70 spilled registers next to the 128 accumulators)
+            unsigned char* w8 = reinterpret_cast<unsigned char*>(wlds);
+#pragma unroll
+            for (int img = 0; img < 2; ++img) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 32 + l31, sw = (row >> 1) & 7;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            unsigned pk = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[i][j][4 * q + e];
+                                half_t hh, ll;
+                                split_f32_unscaled(v, hh, ll);
+                                pk |= (unsigned)bf8_of_f16(img == 0 ? hh : ll) << (8 * e);
+                            }
+                            const int col = j * 32 + 8 * q + 4 * hi;
+                            *reinterpret_cast<unsigned*>(w8 + row * 128 + (((col >> 4) ^ sw) << 4) + (col & 15)) = pk;
+                            __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from computing far ahead of the LDS writes (spills)
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                unsigned char* dst8 = (img == 0 ? g.K8h : g.K8l) + (size_t)mw0 * g.d + nn0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = t * 8 + (lane >> 3), u = lane & 7;
+                    const u32x4_t v16 = *reinterpret_cast<const u32x4_t*>(w8 + row * 128 + ((u ^ ((row >> 1) & 7)) << 4));
+                    if (mw0 + row < g.M) *reinterpret_cast<u32x4_t*>(dst8 + (size_t)row * g.d + u * 16) = v16;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = i * 32 + l31;
@@ -803,8 +866,7 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
                     f16x4 pv;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[j][q][e]);
-                        if (part == 0) v *= qs;
+                        const float v = acc[i][j][4 * q + e];
                         half_t hh, ll;
                         split_f32_unscaled(v, hh, ll);
                         if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax) && mw0 + row < g.M;   // rows past M hold whatever the padding held
@@ -812,6 +874,7 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
                     }
                     const int c = (8 * j + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
                     *reinterpret_cast<f16x4*>(wlds + row * 128 + c * 4) = pv;
+                    __builtin_amdgcn_sched_barrier(0);           // (as in the byte phase)
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1043,7 +1106,8 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
     };
     if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         // block-uniform: a Q or K tile (columns below 2 d) is computed transposed and leaves through LDS in full rows
-        if ((stage_vt & 2) && n0 < 2 * g.d && g.d % 128 == 0) {
+        // (with bf8 K images always: the generic epilogue of this shape is compiled without the byte stores)
+        if (((stage_vt & 2) || (g.K8h && n0 >= g.d)) && n0 < 2 * g.d && g.d % 128 == 0) {
             kloop(std::true_type{});
             __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
             qk_staged_store(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
@@ -1057,7 +1121,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
             if (vt_staged_store<true>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
         }
     }
-    gemm_h_epilogue<WM, WN, EPI, OUT, true>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
+    gemm_h_epilogue<WM, WN, EPI, OUT, true, OUT == OUT_QKV && !(WM == 2 && WN == 4)>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
 template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS>

@@ -500,6 +500,12 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl;
                 g.Vthi = vt_direct ? sb.Vth : sb.Vh; g.Vtlo = vt_direct ? sb.Vtl : sb.Vl; g.vt_direct = vt_direct;
                 g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad; g.qscale = att_scale * 1.4426950408889634f;
+                // JMID_PREC_F16MX with attn_mx = 1 (opt-in: the attention kernel gets 7 % faster, the QKV epilogue loses more than
+                // that), head_dim 128 (the LDS-DMA attention kernel): bf8 images of K_hi / K_lo in the K_lo plane's memory
+                const bool k8 = h->mx && hd == 128 && tune().attn_h_variant != 1 && tune().attn_mx == 1;
+                unsigned char* k8h = k8 ? reinterpret_cast<unsigned char*>(sb.Kl) : nullptr;
+                unsigned char* k8l = k8 ? k8h + (size_t)M * d : nullptr;
+                g.K8h = k8h; g.K8l = k8l;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_QKV>(h, KC_GEMM_QKV, g))) return rc;
                 if (!vt_direct) {
                     ProfScope ps(h, KC_VTRANS);
@@ -510,8 +516,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 ProfScope ps(h, KC_ATTN);
                 const int ns = sb.attn_nsplit;   // per call, not per chunk (run_network)
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
-                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2};
+                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2, k8h, k8l};
                 HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
+                g.K8h = nullptr; g.K8l = nullptr;
             } else {
                 g.C = sb.QKV; g.ldc = 3 * d;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g))) return rc;
@@ -1345,6 +1352,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
+        {"attn_mx", &Tuning::attn_mx, 0, 1},
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
