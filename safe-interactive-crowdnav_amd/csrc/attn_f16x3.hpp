@@ -260,7 +260,11 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 // below the 2^-12.7 of the mode's GEMMs.  bf8(K) comes from the QKV GEMM epilogue (two 4 KB images per key tile in the
 // place of the 8 KB fp16 K_lo image: same DMA bytes, same fragment-read bytes, no extra VALU work per tile); bf8(Q) is made
 // once per wave from the Q planes.  k order of the fp8 instruction: byte p of lane (row, h) is head dim 64 blk + 32 h + p.
-template <bool TRACE, bool X2 = false, bool MX = false>
+// PIPE: software-pipelined key-tile loop.  The K ring runs one tile ahead of the V^T ring: iteration t issues the QK^T MFMAs of
+// tile t + 1 FIRST and does the softmax of tile t (VALU / transcendental work that depends only on the previous iteration's
+// scores) in their shadow, then the P.V MFMAs of tile t - a wave keeps its own MFMA pipe busy through its softmax instead
+// of relying on the other wave of the SIMD to fill the gap.  Same arithmetic per element, same order: bit-identical.
+template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
@@ -383,6 +387,132 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int ntiles_all = (S + KT - 1) / KT;
     const int kt_begin = (int)((long)split * ntiles_all / a.nsplit);
     const int ntiles = (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
+    if constexpr (PIPE) {
+        // one of the 8 DMA wave-instructions of an iteration: i < 4 -> K planes of tile tk, else V^T planes of tile tv
+        // (branch-free: past the end the last tile is copied again - valid bytes into a stage nobody reads any more - so that the
+        // MFMAs and the softmax of an iteration stay in ONE basic block, which is what the scheduler can interleave)
+        auto issue_kv = [&](int tk, int tv, int i) {
+            const int t = i < 4 ? tk : tv;
+            issue_one(t < ntiles ? t : ntiles - 1, i);
+        };
+        auto qk_step = [&](const half_t* Kh, const half_t* Kl, int ks, f32x16& sm) {
+            const int ok = kbase + (((2 * ks + hi) ^ kx) << 3);
+            const f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + ok);
+            const f16x8 kl_c = *reinterpret_cast<const f16x8*>(Kl + ok);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[MX ? 0 : ks], sm, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_c, qh[ks], sm, 0, 0, 0);
+        };
+        f32x16 sm_cur;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm_cur[r] = 0.f;
+        // prologue: K(b), K(b + 1), V(b); scores of the first tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_one(kt_begin, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (!wave_idle) {
+            const half_t* Kh = lds + (kt_begin & 1) * ATT_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                qk_step(Kh, Kh + ATT_KPLANE, ks, sm_cur);
+                issue_kv(kt_begin + 1, kt_begin, ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_kv(kt_begin + 1, kt_begin, i);
+        }
+        for (int kt = kt_begin; kt < ntiles; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(kt + 1) and V(kt) have landed (this wave's share) ...
+            __builtin_amdgcn_s_barrier();                      // ... and everybody else's; everybody is done with iteration kt - 1
+            __builtin_amdgcn_sched_barrier(0);
+            const bool nxt = kt + 1 < ntiles;
+            if (wave_idle) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) issue_kv(kt + 2, kt + 1, i);
+                continue;
+            }
+            const half_t* Kn = lds + ((kt + 1) & 1) * ATT_STAGE;                       // K planes of tile kt + 1
+            const half_t* Vh = lds + (kt & 1) * ATT_STAGE + 2 * ATT_KPLANE;            // V^T planes of tile kt
+            const half_t* Vl = Vh + ATT_VPLANE;
+            f32x16 sm_next;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm_next[r] = 0.f;
+            // ---- the next tile's scores (MFMA) and this tile's softmax (VALU), interleaved by hand: after the three MFMAs of a
+            // QK^T step (96 MFMA cycles in flight) comes one slice of the softmax of the previous scores.  (After the last tile
+            // the scores are computed on stale K bytes and dropped.)
+            f32x16 sm = sm_cur;
+            float tmax, m_new, alpha, psum = 0.f;
+            bool rescale;
+            f16x8 ph[2], pl[2];
+            float pv[16];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                qk_step(Kn, Kn + ATT_KPLANE, ks, sm_next);
+                issue_kv(kt + 2, kt + 1, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) {                           // only the last tile can hold keys past S
+                    const int lim = kt == ntiles_all - 1 ? S - kt * KT : KT;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sm[r] = frag_row(r, hi) >= lim ? -INFINITY : sm[r];
+                    tmax = sm[0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sm[r]);
+                } else if (ks == 1) {
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                    m_new = fmaxf(m_run, tmax);
+                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                    rescale = !__all(m_new == m_run);
+                } else if (ks <= 5) {
+#pragma unroll
+                    for (int r = 4 * (ks - 2); r < 4 * (ks - 1); ++r) {
+                        sm[r] = __builtin_amdgcn_exp2f(sm[r] - m_new);
+                        pv[r] = sm[r];
+                    }
+                    if (ks == 3) split8(pv, ph[0], pl[0]);
+                    if (ks == 5) split8(pv + 8, ph[1], pl[1]);
+                } else if (ks == 6) {
+                    // the row sum in the order of the plain loop: r = 0 .. 15, then the other lane half
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) psum += sm[r];
+                    psum += __shfl_xor(psum, 32, 64);
+                    l_run = fmaf(l_run, alpha, psum);
+                    m_run = m_new;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (rescale) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
+            }
+            // ---- P.V of this tile (fragment reads one step ahead, as in the plain loop)
+            auto vload = [&](int step, f16x8& vh, f16x8& vl) {
+                const int n = step >> 1, mf = step & 1;
+                vh = *reinterpret_cast<const f16x8*>(Vh + n * 1024 + vbase[mf]);
+                if (!X2) vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
+            };
+            f16x8 vh_c, vl_c;
+            vload(0, vh_c, vl_c);
+#pragma unroll
+            for (int step = 0; step < 2 * NT; ++step) {
+                f16x8 vh_n = vh_c, vl_n = vl_c;
+                if (step + 1 < 2 * NT) vload(step + 1, vh_n, vl_n);
+                const int n = step >> 1, mf = step & 1;
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, ph[mf], ot[n], 0, 0, 0);
+                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
+                if (!X2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                vh_c = vh_n;
+                vl_c = vl_n;
+            }
+            sm_cur = sm_next;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copies past the end
+    } else {
     issue(kt_begin);
     ATT_STAMP(0)   // prologue: Q loads, first DMA issue
     for (int kt = kt_begin; kt < ntiles; ++kt) {
@@ -522,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
         ATT_STAMP(6)
     }
+    }   // !PIPE
     if (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -668,6 +799,20 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
             hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
                                (unsigned long long*)nullptr);
+        } else if (tune().attn_h_variant == 2) {
+            static bool pipe_seen[64] = {};
+            if (first_use_on_device(pipe_seen)) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, false, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+            }
+            if (a.x2)
+                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, 0,
+                                   (unsigned long long*)nullptr);
+            else
+                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, 0,
+                                   (unsigned long long*)nullptr);
         } else if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
             hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
                                (unsigned long long*)nullptr);
