@@ -555,7 +555,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_mx_kernel(GemmLnArgs g, int nt
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
+#ifdef JMID_PROBE_SCALED_MFMA   // tools/concurrency_probe9.hip only: the same product through the scaled instruction PAIR, both scales 2^0
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 1, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i], w8[j], acc[i][j], 1, 1, 0, 0, 0, 0);   // unscaled, both bf8
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if ((s >> 2) + 1 < nkb) issueW8((s >> 2) + 1);
         }

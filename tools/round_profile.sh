@@ -1,11 +1,18 @@
 #!/bin/bash
-# All measurements profiles/ holds for a round, in one GPU-box call (about 6 minutes).  Output: gpurun_out/$R/
+# All measurements profiles/ holds for a round, in one GPU-box call (about 15 minutes).  Output: gpurun_out/$R/
 #   R=r02 tools/round_profile.sh ; then python tools/update_profiles.py r02
 export TMPDIR=/tmp
 R=${R:-r02}
 O=gpurun_out/$R
 mkdir -p $O
-# default bench (BASELINE configs[2]), both split modes measured identically, parity sample over all chunks
+# PMC first: HBM bytes and MFMA busy per production kernel over one whole call, per mode; the summaries go into profiles/ of
+# this copy right away, so that the bench lines below quote THEM (file name + git blob hash of exactly these bytes)
+for m in f16mx f16x2 f16x3; do
+  JMID_PREC=$m tools/pmc_call.sh > $O/pmc_$m.log 2>&1
+  cp gpurun_out/pmc/pmc_call_$m.json $O/
+  cp gpurun_out/pmc/pmc_call_$m.json profiles/${R}_pmc_call_$m.json
+done
+# default bench (BASELINE configs[2]), all split modes measured identically, parity sample over all chunks
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
 timeout 300 python bench.py --precision f32 --modes f32 --cpu-episodes 0 --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
 timeout 300 python bench.py --workload cfg2 --cpu-episodes 0 --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
@@ -20,22 +27,22 @@ import sys,json
 d=json.loads(sys.stdin.read()); print('episodes/call', $e, {m: (v['value'], v['ms_per_step']) for m, v in d['modes'].items()})"
 done > $O/episode_sweep.log
 # rocprofv3 kernel stats of one step on a 51-episode chunk, per mode
-for m in f16x2 f16x3; do
+for m in f16mx f16x2 f16x3; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
   find $O/prof_$m -name "*kernel_stats.csv" -exec cp {} $O/${m}_kernel_stats.csv \;
   rm -rf $O/prof_$m
 done
 # single-scene kernel stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --workload cfg2 --modes f16x2 --steps 20 --warmup 3 --cpu-episodes 0 --no-profile > $O/prof_bench_cfg2.log 2>&1
-find $O/prof_ss -name "*kernel_stats.csv" -exec cp {} $O/cfg2_f16x2_kernel_stats.csv \;
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --workload cfg2 --modes f16mx --steps 20 --warmup 3 --cpu-episodes 0 --no-profile > $O/prof_bench_cfg2.log 2>&1
+find $O/prof_ss -name "*kernel_stats.csv" -exec cp {} $O/cfg2_f16mx_kernel_stats.csv \;
 rm -rf $O/prof_ss
-# PMC: HBM bytes and MFMA busy per production kernel over one whole call
-JMID_PREC=f16x2 tools/pmc_call.sh > $O/pmc_x2.log 2>&1
-JMID_PREC=f16x3 tools/pmc_call.sh > $O/pmc_x3.log 2>&1
-cp gpurun_out/pmc/pmc_call_f16x2.json gpurun_out/pmc/pmc_call_f16x3.json $O/
 # reproducibility soak of the default path + the documented multi-lane disturbance
 # reproducibility soak: one chunk in flight, and 2 / 3 / 4 chunks in flight against the one-chunk reference (bitwise)
-python tools/rerun_soak.py f16x2 20 256 1 > $O/soak.log 2>&1
+python tools/rerun_soak.py f16mx 20 256 1 > $O/soak.log 2>&1
+python tools/rerun_soak.py f16mx 20 256 2 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16mx 10 256 3 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16mx 12 64 2 32 >> $O/soak.log 2>&1
+python tools/rerun_soak.py f16x2 20 256 1 >> $O/soak.log 2>&1
 python tools/rerun_soak.py f16x3 20 256 1 >> $O/soak.log 2>&1
 python tools/rerun_soak.py f16x2 20 256 2 >> $O/soak.log 2>&1
 python tools/rerun_soak.py f16x3 20 256 2 >> $O/soak.log 2>&1
@@ -43,10 +50,14 @@ python tools/rerun_soak.py f16x2 10 256 3 >> $O/soak.log 2>&1
 python tools/rerun_soak.py f16x3 10 256 4 >> $O/soak.log 2>&1
 # the instruction-level reproduction of what used to disturb them (needs build/concurrency_probe8, tools/concurrency_probe8.hip)
 if [ -x build/concurrency_probe8 ]; then for c in 3 1 0; do timeout 300 ./build/concurrency_probe8 300 $c; done > $O/packed_fp32_probe.log 2>&1; fi
+# the second co-residency finding: the scaled fp8 MFMA pair next to out_ddim_kernel (needs build/concurrency_probe9 and, for the
+# "before" half, build/concurrency_probe9_scaled: the same probe built with -DPROBE_SCALED_MFMA)
+if [ -x build/concurrency_probe9 ]; then (timeout 300 ./build/concurrency_probe9 40 | grep -v "hi plane\|tiles with"; if [ -x build/concurrency_probe9_scaled ]; then echo "--- the same with the SCALED instruction pair (v_mfma_ld_scale_b32 + v_mfma_scale_f32_32x32x64_f8f6f4)"; timeout 300 ./build/concurrency_probe9_scaled 40 | grep -v "hi plane\|tiles with"; fi) > $O/scaled_mfma_probe.log 2>&1; fi
 # lanes 1 / 2 / 3 on the default batch
-python tools/single_scene_sweep.py lanes=1,2,3 f16x2 256 2>/dev/null | grep ms > $O/lanes.log
+python tools/single_scene_sweep.py lanes=1,2,3 f16mx 256 2>/dev/null | grep ms > $O/lanes.log
+python tools/single_scene_sweep.py lanes=1,2,3 f16x2 256 2>/dev/null | grep ms >> $O/lanes.log
 python tools/single_scene_sweep.py lanes=1,2,3 f16x3 256 2>/dev/null | grep ms >> $O/lanes.log
 for f in $O/bench_*.json; do echo "== $f"; python -c "
 import json,sys
 d=json.load(open('$f')); print(d['value'], d['ms_per_step'], d.get('single_scene',{}).get('ms_per_call'), {m:(v['value'], v.get('parity',{}).get('mean_ADE_vs_oracle_m')) for m,v in d['modes'].items()})"; done
-cat $O/episode_sweep.log; grep -v amdgpu $O/soak.log | tail -8
+cat $O/episode_sweep.log; grep -v amdgpu $O/soak.log | tail -12

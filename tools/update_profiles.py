@@ -4,13 +4,16 @@ import json, os, shutil, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = f"gpurun_out/{R}", "profiles"
 names = ["bench_cfg3.json", "bench_cfg3_f32.json", "bench_cfg2.json", "bench_cfg4.json", "bench_cfg5_1gpu.json", "bench_cfg3_imid.json",
-         "bench_cfg3_orca.json", "episode_sweep.log", "soak.log", "packed_fp32_probe.log", "lanes.log", "pmc_call_f16x2.json", "pmc_call_f16x3.json"]
+         "bench_cfg3_orca.json", "episode_sweep.log", "soak.log", "packed_fp32_probe.log", "scaled_mfma_probe.log", "lanes.log", "pmc_call_f16mx.json", "pmc_call_f16x2.json",
+         "pmc_call_f16x3.json"]
 for n in names:
     if os.path.exists(f"{src}/{n}"):
         shutil.copy(f"{src}/{n}", f"{dst}/{R}_{n}")
 if os.path.exists(f"{src}/bench_cfg3.err"):
     shutil.copy(f"{src}/bench_cfg3.err", f"{dst}/{R}_bench_cfg3.stderr.log")
-hdr = {"f16x2": "python bench.py --precision f16x2 --modes f16x2 --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
+hdr = {"f16mx": "python bench.py --precision f16mx --modes f16mx --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
+       "cfg2_f16mx": "python bench.py --workload cfg2 --modes f16mx --steps 20 --warmup 3 --cpu-episodes 0 --no-profile",
+       "f16x2": "python bench.py --precision f16x2 --modes f16x2 --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
        "f16x3": "python bench.py --precision f16x3 --modes f16x3 --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51",
        "cfg2_f16x2": "python bench.py --workload cfg2 --modes f16x2 --steps 20 --warmup 3 --cpu-episodes 0 --no-profile"}
 for tag, cmd in hdr.items():
@@ -19,7 +22,7 @@ for tag, cmd in hdr.items():
         open(f"{dst}/{R}_{tag}_kernel_stats.csv", "w").write(
             f"# rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}   (durations in ns; the run holds one warm-up-free "
             "profiling step, one timed step and the single-scene calls of that mode)\n" + open(f).read())
-for m in ("f16x2", "f16x3"):
+for m in ("f16mx", "f16x2", "f16x3"):
     p = f"{dst}/{R}_pmc_call_{m}.json"
     if os.path.exists(p):
         j = json.load(open(p))
