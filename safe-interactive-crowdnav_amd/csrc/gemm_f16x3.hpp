@@ -788,6 +788,7 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
 // per lane = 256 contiguous bytes per token row: 16 + 16 store instructions per wave instead of 256 two-byte ones.
 // Same arithmetic as gemm_h_epilogue (bias, Q pre-scaled by qscale, unscaled hi/lo split).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <bool K8IMG = false>     // K8IMG: the kernel variant that can write bf8 K images (attn_mx = 1); compiled out of the default one
 __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc)[2][4], int mw0, int nw0, half_t* wlds, int l31,
                                                 int hi, int lane) {
     const int part = nw0 / g.d, nn0 = nw0 - part * g.d;
@@ -813,7 +814,7 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
                 }
     }
     bool overflow = false;
-    const bool k8 = part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
+    const bool k8 = K8IMG && part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
         if (plane == 1 && k8) {
@@ -959,7 +960,7 @@ struct MxCfg {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS>
+template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS, bool K8IMG = false>
 __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) void gemm_mx_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
     using C = MxCfg<WR, WC, WM, WN, NS>;
     constexpr int BM = C::BM, BN = C::BN, L = NS - 1;          // L tiles of look-ahead
@@ -1107,10 +1108,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
     if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         // block-uniform: a Q or K tile (columns below 2 d) is computed transposed and leaves through LDS in full rows
         // (with bf8 K images always: the generic epilogue of this shape is compiled without the byte stores)
-        if (((stage_vt & 2) || (g.K8h && n0 >= g.d)) && n0 < 2 * g.d && g.d % 128 == 0) {
+        if (((stage_vt & 2) || (K8IMG && g.K8h && n0 >= g.d)) && n0 < 2 * g.d && g.d % 128 == 0) {
             kloop(std::true_type{});
             __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
-            qk_staged_store(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
+            qk_staged_store<K8IMG>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
             return;
         }
     }
@@ -1124,17 +1125,19 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
     gemm_h_epilogue<WM, WN, EPI, OUT, true, OUT == OUT_QKV && !(WM == 2 && WN == 4)>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
 }
 
-template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS>
+template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS, bool K8IMG = false>
 inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
     using C = MxCfg<WR, WC, WM, WN, NS>;
+    if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4 && !K8IMG)      // bf8 K images wanted (attn_mx = 1): the variant that can write them
+        if (g.K8h) return launch_gemm_mx_cfg<EPI, OUT, WR, WC, WM, WN, NS, true>(g, st);
     const int ntm = (g.M + C::BM - 1) / C::BM, ntn = g.N / C::BN;
     static bool attr_seen[64] = {};
     if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     }
     const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only
-    hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
                        vs == 2 ? 0 : (vs == 3 ? 1 : 3));
     return hipGetLastError();
 }

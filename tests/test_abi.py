@@ -85,4 +85,9 @@ def test_device_code_holds_no_packed_fp32_instructions(tmp_path):
         n_kernels += dis.count("<_ZN4jmid")
         for op in ("v_pk_add_f32", "v_pk_mul_f32", "v_pk_fma_f32"):
             assert op not in dis, f"{op} found in the device code: build with -Xclang -target-feature -Xclang -packed-fp32-ops"
+        # ... and no SCALED fp8 MFMA: it is an instruction pair (v_mfma_ld_scale_b32 + MFMA) that computed with a wrong scale next to
+        # waves of another kernel on the same SIMD (tools/concurrency_probe9.hip); the F16MX kernels use the unscaled instruction
+        assert "v_mfma_f32_32x32x64_f8f6f4" in dis
+        for op in ("v_mfma_scale", "v_mfma_ld_scale"):
+            assert op not in dis, f"{op} found in the device code"
     assert n_kernels > 50
