@@ -177,7 +177,10 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "gemm_h_variant"  F16X3 GEMM kernel: 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged,
  *                     3 = 128x128 LDS-DMA ring, 4 = 256x128 LDS-DMA ring, 5 = 64x64 LDS-DMA ring,
  *                     6 = 256x256 LDS-DMA ring (N % 256 == 0)
- *   "attn_h_variant"  F16X3 attention kernel: 0 auto, 1 = register-staged, 2 = LDS-DMA ring (head_dim 128 only)
+ *   "attn_h_variant"  split-fp16 attention kernel: 0 auto (LDS-DMA ring for head_dim 128), 1 = register-staged, 2 = LDS-DMA ring with
+ *                     the software-pipelined key-tile loop (bit-identical, measured 1.7 % slower)
+ *   "attn_mx"         JMID_PREC_F16MX: 1 = the logits' correction terms as bf8 MFMAs too (bf8 K images from the QKV epilogue;
+ *                     attention -7 %, QKV GEMM +25 %: slower overall; results differ at rounding level)
  *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 8192 tokens), 1 always, 2 never
  *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
  *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 2: +2-4 % on batches
@@ -191,7 +194,8 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *   "tail_fuse"       1 = concat3 -> concat4 -> output layer -> sampler update -> next embedding in one kernel (d_model
  *                     512; bit-identical, two launches fewer per step, measured slower: off by default), 0 / 2 = the three
  *                     separate launches; "tail_rows" its row tile (0 auto, 32, 64)
- *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T with direct 8-byte stores instead of full rows through LDS
+ *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
+ *                     LDS; 3 = only Q / K direct
  *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with
  *                     the same (E, A, K, T, precision) on (same kernels in the same order: bit-identical; one graph launch
  *                     instead of ~28 x n_steps kernel launches; measured 0-3 % SLOWER than the eager launches, so off by
