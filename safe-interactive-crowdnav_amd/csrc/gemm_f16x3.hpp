@@ -645,143 +645,6 @@ __device__ __forceinline__ bool vt_staged_store(const GemmHArgs& g, f32x16 (&acc
     return true;
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// 256x256 LDS-DMA variant (N a multiple of 256: in_proj 1536, linear1 1024): 8 waves (4 along M x 2 along N), wave tile
-// 64 x 128 - possible since the product needs ONE accumulator set (128 VGPRs).  A third fewer operand bytes per FLOP
-// through L2 -> LDS and a quarter fewer fragment reads per MFMA than the 256x128 tile.  64 KB stages, 2-stage ring
-// (the next tile's 8 DMA instructions are issued right after the barrier):
-// one K-tile of look-ahead is 48 MFMAs per wave, the same cover time as two tiles of the 256x128 kernel.
-constexpr int DMA3_STAGE = 8 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi(2), Wlo(2)
-constexpr size_t DMA3_LDS_BYTES = size_t(2) * DMA3_STAGE * sizeof(half_t);
-
-template <int EPI, int OUT, bool X2 = false>
-__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int burst, int stage_vt) {
-    constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wr = wid >> 1, wc = wid & 1;                 // wr 0..3 (64 rows each), wc 0..1 (128 columns each)
-    // XCD-contiguous tile ranges, N fastest: the N-tiles of an M-tile run together and share its A panels in L2
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int tm = swz / ntn, tn = swz - tm * ntn;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = g.K / GEMMH_BK;
-    const int nrb = (g.M + 127) / 128;
-    const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
-    const half_t* src[8];
-    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
-    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
-    src[2] = g.Alo + (size_t)rb0 * nk * 4096 + tid * 8;
-    src[3] = g.Alo + (size_t)rb1 * nk * 4096 + tid * 8;
-    src[4] = g.Whi + (size_t)(2 * tn) * nk * 4096 + tid * 8;
-    src[5] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
-    src[6] = g.Wlo + (size_t)(2 * tn) * nk * 4096 + tid * 8;
-    src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
-    auto issue_one = [&](int kt, int i) {
-        half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
-        if ((i == 2 || i == 3) && X2) return;   // F16X2: the A lo images stay out of LDS
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
-                                         (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
-    };
-    f32x16 acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    int offA[WM][2], offW[WN][2];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        const int row = wr * 64 + i * 32 + l31, r = row & 127;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            offA[i][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int row = wc * 128 + j * 32 + l31, r = row & 127;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-            offW[j][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) issue_one(0, i);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        const bool more = kt + 1 < nk && !burst;
-        if (burst && kt + 1 < nk) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) issue_one(kt + 1, i);
-        }
-        const half_t* st = lds + (kt & 1) * DMA3_STAGE;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[WM], al[WM], wh[WN], wl[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
-                if (!X2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
-            }
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
-                wl[j] = *reinterpret_cast<const f16x8*>(st + 6 * DMA_PLANE + offW[j][ks]);
-            }
-            // burst == 0 (diagnostics, gemm_abl bit 3): the 8 DMA instructions of the next K-tile go out behind the MFMA
-            // groups instead of right after the barrier - measured 1 % slower here, unlike in the attention kernel
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
-            if (more) {
-                issue_one(kt + 1, 4 * ks + 0);
-                issue_one(kt + 1, 4 * ks + 1);
-            }
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
-            if (more) {
-                issue_one(kt + 1, 4 * ks + 2);
-                issue_one(kt + 1, 4 * ks + 3);
-            }
-            if (!X2)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    if (OUT == OUT_QKV) {
-        // a V tile (block-uniform: n0 is a multiple of 256 and d_model of 128): V^T goes out through LDS in full rows
-        if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && stage_vt) {
-            __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
-            if (vt_staged_store<X2>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
-        }
-    }
-    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
-}
-
-template <int EPI, int OUT, bool X2 = false>
-inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
-    const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
-    }
-    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (gemm_abl_bits() & 8) ? 0 : 1,
-                       tune().vt_stage != 2 ? 1 : 0);
-    return hipGetLastError();
-}
-
 // Q / K planes of a wave's 64-token x 128-column tile through LDS, for accumulators of the TRANSPOSED product (W fragments as the
 // first MFMA operand): registers 4q..4q+3 of a lane are then 4 consecutive COLUMNS of one token, so a plane goes into the wave's
 // 16 KB of LDS with 8-byte writes (16-byte units XOR-swizzled by the row: conflict-free both ways) and out again as 16 bytes
@@ -891,6 +754,192 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
         __builtin_amdgcn_wave_barrier();
     }
     if (overflow) atomicOr(g.range_flag, 1);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 256x256 LDS-DMA variant (N a multiple of 256: in_proj 1536, linear1 1024): 8 waves (4 along M x 2 along N), wave tile
+// 64 x 128 - possible since the product needs ONE accumulator set (128 VGPRs).  A third fewer operand bytes per FLOP
+// through L2 -> LDS and a quarter fewer fragment reads per MFMA than the 256x128 tile.  64 KB stages, 2-stage ring
+// (the next tile's 8 DMA instructions are issued right after the barrier):
+// one K-tile of look-ahead is 48 MFMAs per wave, the same cover time as two tiles of the 256x128 kernel.
+constexpr int DMA3_STAGE = 8 * DMA_PLANE;                 // Ahi(2 images), Alo(2), Whi(2), Wlo(2)
+constexpr size_t DMA3_LDS_BYTES = size_t(2) * DMA3_STAGE * sizeof(half_t);
+
+template <int EPI, int OUT, bool X2 = false>
+__global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs g, int ntm, int ntn, int burst, int stage_vt) {
+    constexpr int WM = 2, WN = 4, BM = 256, BN = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half_t* lds = reinterpret_cast<half_t*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 1, wc = wid & 1;                 // wr 0..3 (64 rows each), wc 0..1 (128 columns each)
+    // XCD-contiguous tile ranges, N fastest: the N-tiles of an M-tile run together and share its A panels in L2
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int tm = swz / ntn, tn = swz - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = g.K / GEMMH_BK;
+    const int nrb = (g.M + 127) / 128;
+    const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
+    const half_t* src[8];
+    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[2] = g.Alo + (size_t)rb0 * nk * 4096 + tid * 8;
+    src[3] = g.Alo + (size_t)rb1 * nk * 4096 + tid * 8;
+    src[4] = g.Whi + (size_t)(2 * tn) * nk * 4096 + tid * 8;
+    src[5] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
+    src[6] = g.Wlo + (size_t)(2 * tn) * nk * 4096 + tid * 8;
+    src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
+    auto issue_one = [&](int kt, int i) {
+        half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
+        if ((i == 2 || i == 3) && X2) return;   // F16X2: the A lo images stay out of LDS
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
+                                         (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
+    };
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int offA[WM][2], offW[WN][2];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int row = wr * 64 + i * 32 + l31, r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offA[i][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int row = wc * 128 + j * 32 + l31, r = row & 127;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            offW[j][ks] = (row >> 7) * DMA_PLANE + r * 32 + (((ks * 2 + hi) ^ ((r >> 2) & 3)) * 8);
+    }
+    // block-uniform: a Q or K tile of the QKV GEMM (columns below 2 d) is computed TRANSPOSED - W fragments as the first MFMA
+    // operand, so that a lane holds four consecutive columns of a token - and leaves through LDS in full rows (qk_staged_store;
+    // same values: a product does not care which operand it came in as)
+    if (OUT == OUT_QKV && (stage_vt & 2) && n0 < 2 * g.d && g.d % 128 == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_one(0, i);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) issue_one(kt + 1, i);
+            }
+            const half_t* st = lds + (kt & 1) * DMA3_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
+                    if (!X2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
+                    wl[j] = *reinterpret_cast<const f16x8*>(st + 6 * DMA_PLANE + offW[j][ks]);
+                }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+                if (!X2)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
+        qk_staged_store(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_one(0, i);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool more = kt + 1 < nk && !burst;
+        if (burst && kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) issue_one(kt + 1, i);
+        }
+        const half_t* st = lds + (kt & 1) * DMA3_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[WM], al[WM], wh[WN], wl[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(st + offA[i][ks]);
+                if (!X2) al[i] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offA[i][ks]);
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(st + 4 * DMA_PLANE + offW[j][ks]);
+                wl[j] = *reinterpret_cast<const f16x8*>(st + 6 * DMA_PLANE + offW[j][ks]);
+            }
+            // burst == 0 (diagnostics, gemm_abl bit 3): the 8 DMA instructions of the next K-tile go out behind the MFMA
+            // groups instead of right after the barrier - measured 1 % slower here, unlike in the attention kernel
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+            if (more) {
+                issue_one(kt + 1, 4 * ks + 0);
+                issue_one(kt + 1, 4 * ks + 1);
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+            if (more) {
+                issue_one(kt + 1, 4 * ks + 2);
+                issue_one(kt + 1, 4 * ks + 3);
+            }
+            if (!X2)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (OUT == OUT_QKV) {
+        // a V tile (block-uniform: n0 is a multiple of 256 and d_model of 128): V^T goes out through LDS in full rows
+        if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && (stage_vt & 1)) {
+            __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
+            if (vt_staged_store<X2>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane)) return;
+        }
+    }
+    gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
+}
+
+template <int EPI, int OUT, bool X2 = false>
+inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
+    const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
+    static bool attr_seen[64] = {};
+    if (first_use_on_device(attr_seen)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
+    }
+    const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only
+    hipLaunchKernelGGL((gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>), dim3(ntm * ntn), dim3(512), DMA3_LDS_BYTES, st, g, ntm, ntn, (gemm_abl_bits() & 8) ? 0 : 1,
+                       vs == 2 ? 0 : (vs == 3 ? 1 : 3));
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
