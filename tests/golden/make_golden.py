@@ -257,10 +257,10 @@ def gen_sample_case(tag, ctx_dim, B, n_sample, T, step, joint, sampling, bestof,
 
 
 def gen_wrapper_case(tag, kind, joint, ctx_dim, N, K, k_ret, H, step, wseed, dseed, n_frames=7,
-                     time_jitter=0.0, drop_frame=None):
-    f, weights = make_forecaster(joint, ctx_dim, N, K, k_ret, H, step, wseed)
+                     time_jitter=0.0, drop_frame=None, time_step=0.25):
+    f, weights = make_forecaster(joint, ctx_dim, N, K, k_ret, H, step, wseed, time_step=time_step)
     rng = np.random.default_rng(dseed)
-    frames = scenario(kind, N, n_frames, rng)
+    frames = scenario(kind, N, n_frames, rng, time_step=time_step)
     if time_jitter:
         # stamps slightly EARLY (off the time_step grid): subsample_df bins from the last stamp backwards
         # and keeps the last row per bin (mid_sim_wrapper.py:283-298)
@@ -324,7 +324,7 @@ def gen_wrapper_case(tag, kind, joint, ctx_dim, N, K, k_ret, H, step, wseed, dse
             ev = nbr_edge[key][a]
             edge_mask[a, e] = float(torch.clamp(torch.sum(ev, dim=0, keepdim=True), max=1.0))
     save(f"wrapper_{tag}.npz", kind=kind, joint=int(joint), ctx_dim=ctx_dim, N=N, K=K, k_ret=k_ret, H=H,
-         step=step, wseed=wseed, dseed=dseed, wsum=weights.checksum(), time_step=0.25, past=6,
+         step=step, wseed=wseed, dseed=dseed, wsum=weights.checksum(), time_step=time_step, past=6,
          robot_xy=np.array([fr[0] for fr in frames]), human_xy=np.array([fr[1] for fr in frames]),
          stamps=np.array([fr[2] for fr in frames]),
          node_ids=np.array(rec["nodes"]), x_t=np32(x_t), x_st=np32(x_st_t), nbr_sum=nbr_sum,
@@ -380,6 +380,10 @@ def main():
     gen_wrapper_case("imid_singleton", "singleton", False, 256, 3, 8, 8, 12, 2, 37, 313)
     gen_wrapper_case("jmid_jitter", "together", True, 256, 4, 8, 8, 12, 2, 35, 308, n_frames=9, time_jitter=0.04)
     gen_wrapper_case("jmid_gap", "together", True, 256, 4, 8, 8, 12, 2, 35, 309, n_frames=9, drop_frame=6)
+    # a 100 Hz environment: positions = cumsum(velocity) * 0.01 s, so the K = 100 samples of the two pedestrians lie within the KDE
+    # bandwidths (0.01-0.1 m) of each other and the joint-KDE ranking is NOT a tie (log-weights -3.1 ... -2.3): the top-k choice
+    # and its order are pinned through predict_ret_best()
+    gen_wrapper_case("jmid_topk_tight", "together", True, 256, 2, 100, 15, 8, 2, 38, 314, time_step=0.01)
     gen_ddpm_case("jmid_w32_a2k3t4_s10", 32, 2, 3, 4, 10, True, 41, 501)
     gen_ddpm_case("imid_w32_a3k4t6_s100", 32, 3, 4, 6, 100, False, 42, 502)     # stride 1: last step t = 1 uses z = 0
     gen_ddpm_case("jmid_w256_a5k20t12_s10", 256, 5, 20, 12, 10, True, 43, 503)
