@@ -24,16 +24,28 @@ struct EmbedArgs {
     half_t* Xl;
 };
 
-// channels j..j+3 of token m (row t of the positional table): ConcatSquash(2 -> d) + PE, stored as fp32 and / or planes
-__device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, int t, float x0, float x1, const float* hrow) {
+// channels j..j+3 of token m (row t of the positional table): ConcatSquash(2 -> d) + PE, stored as fp32 and / or planes.
+// In two pieces: what depends only on the (episode, agent) row and the step (weights, gate, bias: EmbedCols), and the rest.
+struct EmbedCols {
+    f32x4 w0, w1, b1, gate, bias;
+};
+__device__ __forceinline__ void embed_cols(const EmbedArgs& a, int j, const float* hrow, EmbedCols& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int cc = j + e;
+        c.w0[e] = a.W1[2 * cc];
+        c.w1[e] = a.W1[2 * cc + 1];
+        c.b1[e] = a.b1[cc];
+        c.gate[e] = sigmoidf_(hrow[a.goff + cc] + a.thyp[a.goff + cc]);
+        c.bias[e] = hrow[a.boff + cc] + a.thyp[a.boff + cc];
+    }
+}
+__device__ __forceinline__ void embed_store_cols(const EmbedArgs& a, int m, int j, int t, float x0, float x1, const EmbedCols& c) {
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int c = j + e;
-        const float lin = a.W1[2 * c] * x0 + a.W1[2 * c + 1] * x1 + a.b1[c];
-        const float gate = sigmoidf_(hrow[a.goff + c] + a.thyp[a.goff + c]);
-        const float bias = hrow[a.boff + c] + a.thyp[a.boff + c];
-        o[e] = lin * gate + bias + a.pe[(size_t)t * a.d + c];
+        const float lin = c.w0[e] * x0 + c.w1[e] * x1 + c.b1[e];
+        o[e] = lin * c.gate[e] + c.bias[e] + a.pe[(size_t)t * a.d + j + e];
     }
     if (a.X) *reinterpret_cast<f32x4*>(a.X + (size_t)m * a.d + j) = o;
     if (a.Xh) {
@@ -49,6 +61,11 @@ __device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, in
         *reinterpret_cast<f16x4*>(a.Xh + ob) = vh;
         *reinterpret_cast<f16x4*>(a.Xl + ob) = vl;
     }
+}
+__device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, int t, float x0, float x1, const float* hrow) {
+    EmbedCols c;
+    embed_cols(a, j, hrow, c);
+    embed_store_cols(a, m, j, t, x0, x1, c);
 }
 
 // one thread per (token, 4 channels)
@@ -219,6 +236,38 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt)
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= a.M) return;
     out_ddim_row<EMBED_NEXT>(a, nxt, m, lane, a.Y4 + (size_t)m * a.dl);
+}
+
+// One wave per TRAJECTORY (the T consecutive tokens of one sample of one agent) for d <= 512: the ConcatSquash gate and bias of
+// the next embedding depend on the (episode, agent) row and the step only, so they - 512 sigmoids and 2 KB of hyper-net rows
+// per token in the kernel above - are computed once per trajectory, and a wave's stores walk through adjacent rows of the
+// blocked planes.  Same expressions per element (embed_cols / embed_store_cols): the same bits.  70 -> 4x us per 61 200-token
+// launch (the kernel above was 2.3 % of an F16MX step).
+template <bool EMBED_NEXT>
+__global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs nxt) {
+    const int lane = threadIdx.x & 63;
+    const int traj = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int T = a.rmap.T, m0 = traj * T;
+    if (m0 >= a.M) return;
+    EmbedCols c[2];
+    const int j0 = lane * 4, j1 = lane * 4 + 256;
+    if (EMBED_NEXT) {
+        const float* hrow = nxt.hyp + (size_t)nxt.rmap.ea(m0) * nxt.hyp_ld;
+        if (j0 < nxt.d) embed_cols(nxt, j0, hrow, c[0]);
+        if (j1 < nxt.d) embed_cols(nxt, j1, hrow, c[1]);
+    }
+    for (int t = 0; t < T; ++t) {
+        const int m = m0 + t;
+        float s0, s1;
+        out_dot(a, a.Y4 + (size_t)m * a.dl, lane, s0, s1);
+        float xn0 = 0.f, xn1 = 0.f;
+        if (lane == 0) out_update(a, m, s0, s1, xn0, xn1);
+        if (EMBED_NEXT) {
+            const float x0 = __shfl(xn0, 0, 64), x1 = __shfl(xn1, 0, 64);
+            if (j0 < nxt.d) embed_store_cols(nxt, m, j0, t, x0, x1, c[0]);
+            if (j1 < nxt.d) embed_store_cols(nxt, m, j1, t, x0, x1, c[1]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ integrator
