@@ -39,6 +39,8 @@ struct GemmLnArgs {
     int* range_flag;
     int x2;                       // JMID_PREC_F16X2: two-term product A_hi x (W_hi + W_lo)
     const unsigned char* W8;      // JMID_PREC_F16MX: bf8 image of W_lo (gemm_f16x3.hpp::w8_image_kernel), or null
+    int no_lo_out;                // the lo plane of the result is not written: nobody reads it (the last LayerNorm of the net in
+                                  // F16X2 / F16MX: the tail GEMM takes X_hi only, the next step starts from a fresh embedding)
 };
 
 // fp32 row-major [512, K] -> k16-panel hi/lo planes
@@ -138,7 +140,7 @@ __device__ __forceinline__ void gln64_epilogue(const GemmLnArgs& g, f32x16 (&acc
                 }
                 const size_t ob = blk_index(row, c, d);
                 *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
-                *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
+                if (!g.no_lo_out) *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
             }
         }
     }
@@ -334,7 +336,7 @@ __device__ __forceinline__ void gln128_epilogue(const GemmLnArgs& g, f32x16 (&ac
                     }
                     const size_t ob = blk_index(row, c, d);
                     *reinterpret_cast<f16x4*>(g.Xh + ob) = vh;
-                    *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
+                    if (!g.no_lo_out) *reinterpret_cast<f16x4*>(g.Xl + ob) = vl;
                 }
             }
         }

@@ -558,6 +558,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 const HalfPair& w16 = h->w16[p + ".linear2.weight"];
                 GemmLnArgs gl{sb.H1h, sb.H1l, w16.hi, w16.lo, W(h, p + ".linear2.bias"), W(h, p + ".norm2.weight"),
                               W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag, h->x2};
+                gl.no_lo_out = h->x2 && l + 1 == h->tf_layer;     // the residual stream ends here: concat3 reads X_hi only
                 if (h->mx) {
                     auto it8 = h->w8.find(p + ".linear2.weight");
                     if (it8 != h->w8.end()) gl.W8 = it8->second.p;
@@ -663,7 +664,17 @@ int auto_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
 // quarter of a chunk, e.g. 256 = 5 x 51 + 1) would run all 50 steps at single-scene latency, so it is spread over the
 // full chunks instead (52 + 4 x 51) - only with the automatic size: a forced size is taken literally.
 std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
-    const int c = h->chunk_eps > 0 ? std::min(E, h->chunk_eps) : auto_chunk(h, E, tokens_per_episode);
+    int c = h->chunk_eps > 0 ? std::min(E, h->chunk_eps) : auto_chunk(h, E, tokens_per_episode);
+    if (h->chunk_eps <= 0 && h->lanes >= 2 && E >= 2 && tune().graph != 1) {     // (a captured loop is a one-chunk call)
+        // Two chunks in flight want two chunks.  A batch that fits one chunk is split in two halves: its kernels do not fill the
+        // chip, and two half-size launches side by side finish 5-13 % sooner than one (4 / 8 / 16 / 32 / 48 episodes: 23.3 ->
+        // 22.2, 36.0 -> 31.8, 60.9 -> 58.0, 111.3 -> 97.2, 140.5 -> 132.5 ms per call; tools/small_batch_lanes.py).  In
+        // JMID_PREC_F16MX larger batches run in half-size chunks too (2 x 26 episodes in flight instead of 51 + 51: -1.2 ... -2.6 %
+        // on 104 / 256 / 512 episodes; F16X2 -0.4 %, F16X3 +0.9 %: left alone; tools/chunk26_check.py).  The split-KV factor of a
+        // call does not depend on its chunk plan (run_network), so neither do the results.
+        if (E <= c) c = (E + 1) / 2;
+        else if (h->mx) c = (c + 1) / 2;
+    }
     std::vector<int> sizes(E / c, c);
     const int tail = E % c;
     if (tail) {

@@ -1,0 +1,23 @@
+import os, sys, time
+import torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from safe_interactive_crowdnav_amd.engine import JmidEngine
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+A, K, T = 5, 20, 12
+eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 23), joint=True, step=50)
+for prec, E in (("f16mx", 104), ("f16mx", 512), ("f16x3", 256), ("f16x2", 256), ("f16mx", 256)):
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.randn([E, A, 256], generator=g).cuda()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    row = []
+    for rep in range(2):
+        for chunk in (0, 26):
+            eng.set_chunk_episodes(chunk)
+            v = eng.denoise(x_T, ctx, None, precision=prec, want_pos=False)[0]
+            eng.synchronize(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                v = eng.denoise(x_T, ctx, None, precision=prec, want_pos=False)[0]
+            eng.synchronize(); torch.cuda.synchronize()
+            row.append(f"chunk {chunk}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms")
+    print(f"[{prec}] E={E}: " + " | ".join(row), flush=True)
