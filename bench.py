@@ -274,7 +274,8 @@ def main():
                     "measured": ("HIP events on the library's stream around every launch of this kernel class in the "
                                  "timed region" if args.lanes == 1 else
                                  "HIP events on the library's stream, one full pass over the batch with ONE chunk "
-                                 "in flight (the kernel has the GPU to itself), untimed, in this run"),
+                                 "in flight (the kernel has the GPU to itself; the one-lane chunk plan: 51-52 episodes per "
+                                 "launch), untimed, in this run"),
                     "path_achieved": round(path_tflops, 2), "path_frac": round(path_tflops / peak, 4),
                     "timed_region": {"lanes": args.lanes, "launches": dom_t["launches"], "avg_launch_ms": round(dom_t["avg_ms"], 4),
                                      "note": "the same kernel class bracketed by HIP events inside the timed region; with lanes > 1 "
@@ -294,7 +295,8 @@ def main():
                 rows = [v for k, v in pmc.get("kernels", {}).items() if any(n in k for n in knames) and v.get("launches", 0) >= 50]
                 if rows:
                     r = max(rows, key=lambda v: v["hbm_bytes_per_launch"])
-                    chunks_per_step = dom_t["launches"] / (steps50 * args.steps * dims.tf_layer)
+                    # per launch of the SAME launches `achieved` is quoted on (the exclusive pass runs the one-lane chunk plan)
+                    chunks_per_step = dom_x["launches"] / (steps50 * (args.steps if args.lanes == 1 else 1) * dims.tf_layer)
                     tokens_per_launch = E * A * K * H / chunks_per_step
                     roof["traffic"] = r["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
                     roof["traffic_source"] = dict(src, kernel=r.get("name"), measured_at_tokens=pmc["tokens"],
@@ -345,7 +347,8 @@ def main():
     for k in ("roofline", "kernels", "hbm", "sweep_metrics"):
         if k in head:
             out[k] = head[k]
-    out["kernels_note"] = "per-class HIP-event times of ONE untimed pass over the same batch with one chunk in flight"
+    out["kernels_note"] = ("per-class HIP-event times of ONE untimed pass over the same batch with one chunk in flight "
+                           "(one-lane chunk plan: 51-52 episodes per launch; the timed region may run smaller chunks, two at a time)")
     out["sweep_metrics_note"] = "random-init weights: displacement vs the constant-velocity future is not meaningful"
     out["modes"] = results
     out["modes_note"] = ("every mode: same batch, same warm-up, same number of timed steps between the same barriers, same "
