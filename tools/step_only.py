@@ -11,6 +11,7 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 51
 N, K, H = 5, 20, 12
 dev = torch.device("cuda", 0)
 eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 0), joint=True, device_id=0, step=50)
+eng.set_tuning("lanes", 1)      # one chunk, one launch per kernel and step: the per-launch counters are those of a 51-episode launch
 syn = synthetic_episodes(E, N, seed=0, horizon=H)
 x_st = torch.from_numpy(syn["x_st"].reshape(E * N, 6, 6)).to(dev)
 nbr = torch.from_numpy(syn["nbr_sum"].reshape(E * N, 2, 6, 6)).to(dev)
