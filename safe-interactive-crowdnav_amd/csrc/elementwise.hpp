@@ -238,16 +238,17 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt)
     out_ddim_row<EMBED_NEXT>(a, nxt, m, lane, a.Y4 + (size_t)m * a.dl);
 }
 
-// One wave per TRAJECTORY (the T consecutive tokens of one sample of one agent) for d <= 512: the ConcatSquash gate and bias of
+// One wave per TRAJECTORY (the T consecutive tokens of one sample of one agent), or per piece of one, for d <= 512: the ConcatSquash gate and bias of
 // the next embedding depend on the (episode, agent) row and the step only, so they - 512 sigmoids and 2 KB of hyper-net rows
 // per token in the kernel above - are computed once per trajectory, and a wave's stores walk through adjacent rows of the
 // blocked planes.  Same expressions per element (embed_cols / embed_store_cols): the same bits.  70 -> 4x us per 61 200-token
 // launch (the kernel above was 2.3 % of an F16MX step).
 template <bool EMBED_NEXT>
-__global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs nxt) {
+__global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs nxt, int tpw) {
+    // tpw tokens per wave (a divisor of T: a whole trajectory, or a piece of one when there are few trajectories)
     const int lane = threadIdx.x & 63;
-    const int traj = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int T = a.rmap.T, m0 = traj * T;
+    const int piece = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int m0 = piece * tpw, t0 = m0 % a.rmap.T;
     if (m0 >= a.M) return;
     EmbedCols c[2];
     const int j0 = lane * 4, j1 = lane * 4 + 256;
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs
         if (j0 < nxt.d) embed_cols(nxt, j0, hrow, c[0]);
         if (j1 < nxt.d) embed_cols(nxt, j1, hrow, c[1]);
     }
-    for (int t = 0; t < T; ++t) {
-        const int m = m0 + t;
+    for (int t = t0; t < t0 + tpw; ++t) {
+        const int m = m0 + t - t0;
         float s0, s1;
         out_dot(a, a.Y4 + (size_t)m * a.dl, lane, s0, s1);
         float xn0 = 0.f, xn1 = 0.f;

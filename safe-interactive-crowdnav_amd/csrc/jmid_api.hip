@@ -621,16 +621,20 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             const int rows = tune().tail_rows ? tune().tail_rows : (M < 64 * 256 ? 32 : 64);
             HIPCHK(h, launch_tail(ta, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, rows,
                                   h->x2 != 0, h->stream));
-        } else if (d <= 512 && M % T == 0 && tune().out_traj != 2 && (tune().out_traj == 1 || M / T >= 4096)) {
-            // one wave per trajectory (T tokens) once there are enough of them to fill the chip: one scene (100 trajectories)
-            // takes 14.0 instead of 12.7 ms per call this way, a 51-episode chunk 150.3 instead of 151.2
-            const int ntraj = M / T;
+        } else if (d <= 512 && M % T == 0 && tune().out_traj != 2 && (tune().out_traj == 1 || M >= 4096 * 4)) {
+            // one wave per trajectory (T tokens) - or per piece of one, the largest divisor of T that still leaves >= 4096 waves -
+            // once there are enough tokens to fill the chip that way: one scene (100 trajectories) takes 14.0 instead of
+            // 12.7 ms per call with whole trajectories, a 51-episode chunk 150.3 instead of 151.2
+            int tpw = T;
+            while (tpw > 1 && (M / tpw < 4096 || T % tpw != 0)) --tpw;
+            if (tune().out_traj == 1) tpw = T;
+            const int nw = M / tpw;
             if (next_step >= 0 && !e_out)
-                hipLaunchKernelGGL(out_ddim_traj_kernel<true>, dim3((ntraj + 3) / 4), dim3(256), bystander_lds(out_ddim_traj_kernel<true>),
-                                   h->stream, oa, embed_args(h->thyp + (size_t)next_step * h->hl.total));
+                hipLaunchKernelGGL(out_ddim_traj_kernel<true>, dim3((nw + 3) / 4), dim3(256), bystander_lds(out_ddim_traj_kernel<true>),
+                                   h->stream, oa, embed_args(h->thyp + (size_t)next_step * h->hl.total), tpw);
             else
-                hipLaunchKernelGGL(out_ddim_traj_kernel<false>, dim3((ntraj + 3) / 4), dim3(256), bystander_lds(out_ddim_traj_kernel<false>),
-                                   h->stream, oa, EmbedArgs{});
+                hipLaunchKernelGGL(out_ddim_traj_kernel<false>, dim3((nw + 3) / 4), dim3(256), bystander_lds(out_ddim_traj_kernel<false>),
+                                   h->stream, oa, EmbedArgs{}, tpw);
         } else if (next_step >= 0 && !e_out)
             hipLaunchKernelGGL(out_ddim_kernel<true>, dim3((M + 3) / 4), dim3(256), bystander_lds(out_ddim_kernel<true>),
                                h->stream, oa, embed_args(h->thyp + (size_t)next_step * h->hl.total));
