@@ -179,6 +179,8 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     6 = 256x256 LDS-DMA ring (N % 256 == 0)
  *   "attn_h_variant"  split-fp16 attention kernel: 0 auto (LDS-DMA ring for head_dim 128), 1 = register-staged, 2 = LDS-DMA ring with
  *                     the software-pipelined key-tile loop (bit-identical, measured 1.7 % slower)
+ *   "csl_swap"        JMID_PREC_F16MX ConcatSquash (tail) GEMMs: 0 = transposed product + row-wise epilogue, 2 = column-wise epilogue
+ *                     (bit-identical, 2 % slower per call)
  *   "out_traj"        output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories per chunk,
  *                     1 = always, 2 = one wave per token (bit-identical)
  *   "attn_mx"         JMID_PREC_F16MX: 1 = the logits' correction terms as bf8 MFMAs too (bf8 K images from the QKV epilogue;

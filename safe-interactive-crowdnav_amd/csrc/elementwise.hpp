@@ -257,16 +257,76 @@ __global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs
         if (j0 < nxt.d) embed_cols(nxt, j0, hrow, c[0]);
         if (j1 < nxt.d) embed_cols(nxt, j1, hrow, c[1]);
     }
-    for (int t = t0; t < t0 + tpw; ++t) {
-        const int m = m0 + t - t0;
-        float s0, s1;
-        out_dot(a, a.Y4 + (size_t)m * a.dl, lane, s0, s1);
-        float xn0 = 0.f, xn1 = 0.f;
-        if (lane == 0) out_update(a, m, s0, s1, xn0, xn1);
-        if (EMBED_NEXT) {
-            const float x0 = __shfl(xn0, 0, 64), x1 = __shfl(xn1, 0, 64);
-            if (j0 < nxt.d) embed_store_cols(nxt, m, j0, t, x0, x1, c[0]);
-            if (j1 < nxt.d) embed_store_cols(nxt, m, j1, t, x0, x1, c[1]);
+    // Nothing in the per-token chain waits for memory: the Y4 rows of up to 12 tokens (two values per lane and token for
+    // dl <= 128) and their x are requested at once, and the output layer's gate / bias (per (episode, agent) row and step, like
+    // the embedding's) are computed once per wave.  Every lane carries the token's update (the reductions are wave-uniform);
+    // lane 0 stores it.  out_update's expressions, term by term.
+    const bool regs = a.dl <= 128;
+    const int c0 = lane, c1 = lane + 64;
+    const float wo00 = c0 < a.dl ? a.Wo[c0] : 0.f, wo10 = c0 < a.dl ? a.Wo[a.dl + c0] : 0.f;
+    const float wo01 = c1 < a.dl ? a.Wo[c1] : 0.f, wo11 = c1 < a.dl ? a.Wo[a.dl + c1] : 0.f;
+    const float* hrow_o = a.hyp + (size_t)a.rmap.ea(m0) * a.hyp_ld;
+    const float g0 = sigmoidf_(hrow_o[a.goff] + a.thyp[a.goff]), g1 = sigmoidf_(hrow_o[a.goff + 1] + a.thyp[a.goff + 1]);
+    const float hb0 = hrow_o[a.boff], hb1 = hrow_o[a.boff + 1], tb0 = a.thyp[a.boff], tb1 = a.thyp[a.boff + 1];
+    const float bo0 = a.bo[0], bo1 = a.bo[1];
+    for (int tb = 0; tb < tpw; tb += 12) {
+        const int nb = tpw - tb < 12 ? tpw - tb : 12;
+        float yv[12][2];
+        if (regs) {
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const float* y = a.Y4 + (size_t)(m0 + tb + (u < nb ? u : 0)) * a.dl;
+                yv[u][0] = c0 < a.dl ? y[c0] : 0.f;
+                yv[u][1] = c1 < a.dl ? y[c1] : 0.f;
+            }
+        }
+        // lane u holds x (and the DDPM draw) of token u of the block
+        const int mu = m0 + tb + (lane < nb ? lane : 0);
+        const float xl0 = a.e_out ? 0.f : a.x[2 * (size_t)mu], xl1 = a.e_out ? 0.f : a.x[2 * (size_t)mu + 1];
+        const float zl0 = (a.ddpm && a.z) ? a.z[2 * (size_t)mu] : 0.f, zl1 = (a.ddpm && a.z) ? a.z[2 * (size_t)mu + 1] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            if (u >= nb) break;
+            const int m = m0 + tb + u, t = t0 + tb + u;
+            float s0, s1;
+            if (regs) {               // out_dot's sums in out_dot's order: c = lane, then lane + 64
+                s0 = 0.f;
+                s1 = 0.f;
+                if (c0 < a.dl) { s0 += yv[u][0] * wo00; s1 += yv[u][0] * wo10; }
+                if (c1 < a.dl) { s0 += yv[u][1] * wo01; s1 += yv[u][1] * wo11; }
+                s0 = wave_sum(s0);
+                s1 = wave_sum(s1);
+            } else {
+                out_dot(a, a.Y4 + (size_t)m * a.dl, lane, s0, s1);
+            }
+            const float e0 = (s0 + bo0) * g0 + hb0 + tb0;
+            const float e1 = (s1 + bo1) * g1 + hb1 + tb1;
+            float xn0 = 0.f, xn1 = 0.f;
+            if (a.e_out) {
+                if (lane == 0) {
+                    a.e_out[2 * (size_t)m] = e0;
+                    a.e_out[2 * (size_t)m + 1] = e1;
+                }
+            } else {
+                const float x0 = __shfl(xl0, u, 64), x1 = __shfl(xl1, u, 64);
+                if (a.ddpm) {
+                    const float z0 = __shfl(zl0, u, 64), z1 = __shfl(zl1, u, 64);
+                    xn0 = a.c0 * (x0 - a.c1 * e0) + a.sigma * z0;
+                    xn1 = a.c0 * (x1 - a.c1 * e1) + a.sigma * z1;
+                } else {
+                    const float p0 = (x0 - e0 * a.c_e) / a.c_x, p1 = (x1 - e1 * a.c_e) / a.c_x;
+                    xn0 = a.n_x * p0 + a.n_e * e0;
+                    xn1 = a.n_x * p1 + a.n_e * e1;
+                }
+                if (lane == 0) {
+                    a.x[2 * (size_t)m] = xn0;
+                    a.x[2 * (size_t)m + 1] = xn1;
+                }
+            }
+            if (EMBED_NEXT) {
+                if (j0 < nxt.d) embed_store_cols(nxt, m, j0, t, xn0, xn1, c[0]);
+                if (j1 < nxt.d) embed_store_cols(nxt, m, j1, t, xn0, xn1, c[1]);
+            }
         }
     }
 }

@@ -942,6 +942,57 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ConcatSquash epilogue for accumulators of the TRANSPOSED product (W fragments as the first MFMA operand): a lane holds ONE
+// token row per 32-row block and 4 consecutive columns per register group, so the (episode, agent) row of the hyper buffer -
+// three integer divisions - is found once per row instead of once per element, gate / bias / time vectors come as 16-byte
+// loads, and the result leaves as 16-byte (fp32) or 8-byte (fp16 planes) stores.  Per element the arithmetic of
+// gemm_h_epilogue_impl<.., EPI_CSL, ..>: the same bits.
+template <int WM, int WN, int OUT, bool X2>
+__device__ __forceinline__ void csl_swapped_epilogue(const GemmHArgs& g, f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31, int hi) {
+    bool overflow = false;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = mw0 + i * 32 + l31;
+        if (m >= g.M) continue;
+        const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = nw0 + j * 32 + 8 * q + 4 * hi;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + c0);
+                const f32x4 tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0);
+                const f32x4 tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
+                const f32x4 hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0);
+                const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[e]);
+                    v = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
+                    o[e] = v;
+                }
+                if (OUT == OUT_F32) {
+                    *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + c0) = o;
+                } else {
+                    f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        half_t hh, ll;
+                        split_f32(o[e], hh, ll);
+                        overflow |= !(fabsf(o[e]) <= kHalfMax);
+                        vh[e] = hh;
+                        vl[e] = ll;
+                    }
+                    const size_t ob = blk_index(m, c0, g.N);
+                    *reinterpret_cast<f16x4*>(g.Chi + ob) = vh;
+                    if (!X2) *reinterpret_cast<f16x4*>(g.Clo + ob) = vl;
+                }
+            }
+    }
+    if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // JMID_PREC_F16MX: the F16X2 product  A_hi . (W_hi + W_lo)  with the correction term on the block-scaled fp8 matrix path:
 //     acc += A_hi . W_hi                 four v_mfma_f32_32x32x16_f16 per k64 and output tile, as before
@@ -1164,6 +1215,13 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
             return;
         }
     }
+    if constexpr (EPI == EPI_CSL && (OUT == OUT_F32 || OUT == OUT_SPLIT)) {
+        if (stage_vt & 4) {       // the tail GEMMs: transposed product, row-wise ConcatSquash epilogue
+            kloop(std::true_type{});
+            csl_swapped_epilogue<WM, WN, OUT, true>(g, acc, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
+            return;
+        }
+    }
     kloop(std::false_type{});
     if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && (stage_vt & 1)) {
@@ -1185,9 +1243,9 @@ inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     }
-    const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only
+    const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only; bit 2: row-wise ConcatSquash epilogue
     hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
-                       vs == 2 ? 0 : (vs == 3 ? 1 : 3));
+                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4));
     return hipGetLastError();
 }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_64(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 1, 1, 4>(g, st); }
