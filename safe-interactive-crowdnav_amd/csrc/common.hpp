@@ -84,7 +84,7 @@ struct Tuning {
     int attn_nsplit = 0;     // split-KV factor of the head_dim-128 attention launches: 0 auto, 1..16 forced
     int tail_fuse = 0;       // tail of the net in one kernel (tail_f16x3.hpp, d_model 512): 1 on, 0 / 2 off (default: slower, see jmid_api.hip)
     int tail_rows = 0;       // its row tile: 0 auto, 32, 64
-    int csl_swap = 0;        // F16MX ConcatSquash GEMMs: 0 = transposed product + row-wise epilogue, 2 = the column-wise epilogue
+    int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
     int out_traj = 0;        // output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories, 1 = always, 2 = one wave per token
     int attn_mx = 0;         // JMID_PREC_F16MX: 1 = the logits' correction terms as bf8 MFMAs too (head_dim 128; measured slower overall), 0 = as fp16 MFMAs
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS

@@ -942,34 +942,38 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
-// ConcatSquash epilogue for accumulators of the TRANSPOSED product (W fragments as the first MFMA operand): a lane holds ONE
+// Row-wise epilogue (ConcatSquash; also plain bias + ReLU) for accumulators of the TRANSPOSED product (W fragments as the first MFMA operand): a lane holds ONE
 // token row per 32-row block and 4 consecutive columns per register group, so the (episode, agent) row of the hyper buffer -
 // three integer divisions - is found once per row instead of once per element, gate / bias / time vectors come as 16-byte
 // loads, and the result leaves as 16-byte (fp32) or 8-byte (fp16 planes) stores.  Per element the arithmetic of
 // gemm_h_epilogue_impl<.., EPI_CSL, ..>: the same bits.
-template <int WM, int WN, int OUT, bool X2>
+template <int WM, int WN, int EPI, int OUT, bool X2>
 __device__ __forceinline__ void csl_swapped_epilogue(const GemmHArgs& g, f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31, int hi) {
     bool overflow = false;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int m = mw0 + i * 32 + l31;
         if (m >= g.M) continue;
-        const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
+        const float* hrow = EPI == EPI_CSL ? g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld : nullptr;
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int c0 = nw0 + j * 32 + 8 * q + 4 * hi;
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + c0);
-                const f32x4 tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0);
-                const f32x4 tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
-                const f32x4 hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0);
-                const f32x4 hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
+                f32x4 tg, tb, hg, hb;
+                if (EPI == EPI_CSL) {
+                    tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0);
+                    tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
+                    hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0);
+                    hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
+                }
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[e]);
-                    v = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
+                    if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+                    if (EPI == EPI_CSL) v = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
                     o[e] = v;
                 }
                 if (OUT == OUT_F32) {
@@ -1215,10 +1219,12 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
             return;
         }
     }
-    if constexpr (EPI == EPI_CSL && (OUT == OUT_F32 || OUT == OUT_SPLIT)) {
-        if (stage_vt & 4) {       // the tail GEMMs: transposed product, row-wise ConcatSquash epilogue
+    if constexpr ((EPI == EPI_CSL && (OUT == OUT_F32 || OUT == OUT_SPLIT)) || (EPI == EPI_BIAS_RELU && OUT == OUT_SPLIT)) {
+        // the tail GEMMs (ConcatSquash): transposed product, row-wise epilogue.  (linear1 the same way - csl_swap = 3 - is 1 %
+        // slower per call: its column-wise 2-byte stores are cheaper than row-wise 8-byte ones, and it has no per-row work to save)
+        if (stage_vt & (EPI == EPI_CSL ? 4 : 8)) {
             kloop(std::true_type{});
-            csl_swapped_epilogue<WM, WN, OUT, true>(g, acc, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
+            csl_swapped_epilogue<WM, WN, EPI, OUT, true>(g, acc, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
             return;
         }
     }
@@ -1245,7 +1251,7 @@ inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
     }
     const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only; bit 2: row-wise ConcatSquash epilogue
     hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
-                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4));
+                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0));
     return hipGetLastError();
 }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_64(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 1, 1, 4>(g, st); }
