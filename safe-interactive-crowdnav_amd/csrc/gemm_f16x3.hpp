@@ -84,22 +84,30 @@ constexpr size_t gemm_h_lds_bytes() {
 
 // three passes over the wave's tiles so that consecutive MFMAs into the same accumulator are WM*WN instructions
 // apart (a back-to-back dependent pair stalls for the MFMA latency)
-template <int WM, int WN, bool X2>
+// SWAP: the W fragments go first - the accumulators hold the TRANSPOSED tile (a lane then owns one token row per 32-row block and
+// four consecutive columns per register group: rowwise epilogues below).  Same products, same order.
+template <int WM, int WN, bool X2, bool SWAP = false>
 __device__ __forceinline__ void mfma3(const f16x8 (&ah)[WM], const f16x8 (&al)[WM], const f16x8 (&wh)[WN],
                                       const f16x8 (&wl)[WN], f32x16 (&acc)[WM][WN]) {
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
     if (X2) return;   // JMID_PREC_F16X2: the activation's lo plane stays out of the product
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < WN; ++j)
+            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
 }
 
 // Epilogue.  FULL = the whole block tile is inside [M, N] (block-uniform): no per-element predication, so the
@@ -225,6 +233,67 @@ __device__ __forceinline__ void gemm_h_epilogue(const GemmHArgs& g, f32x16 (&acc
         gemm_h_epilogue_impl<WM, WN, EPI, OUT, X2, false, K8>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
+// Row-wise epilogue (ConcatSquash; also plain bias + ReLU) for accumulators of the TRANSPOSED product (W fragments as the first MFMA operand): a lane holds ONE
+// token row per 32-row block and 4 consecutive columns per register group, so the (episode, agent) row of the hyper buffer -
+// three integer divisions - is found once per row instead of once per element, gate / bias / time vectors come as 16-byte
+// loads, and the result leaves as 16-byte (fp32) or 8-byte (fp16 planes) stores.  Per element the arithmetic of
+// gemm_h_epilogue_impl<.., EPI_CSL, ..>: the same bits.
+template <int WM, int WN, int EPI, int OUT, bool X2>
+__device__ __forceinline__ void csl_swapped_epilogue(const GemmHArgs& g, f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31, int hi) {
+    bool overflow = false;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = mw0 + i * 32 + l31;
+        if (m >= g.M) continue;
+        const float* hrow = EPI == EPI_CSL ? g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld : nullptr;
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = nw0 + j * 32 + 8 * q + 4 * hi;
+                if (c0 >= g.N) continue;          // N is a multiple of 4 (d_mid, d_low of the net; 128 in the F16MX kernels)
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + c0);
+                f32x4 tg, tb, hg, hb;
+                if (EPI == EPI_CSL) {
+                    tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0);
+                    tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
+                    hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0);
+                    hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
+                }
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[e]);
+                    if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+                    if (EPI == EPI_CSL) v = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
+                    o[e] = v;
+                }
+                if (OUT == OUT_F32) {
+                    *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + c0) = o;
+                } else {
+                    f16x4 vh, vl;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        half_t hh, ll;
+                        split_f32(o[e], hh, ll);
+                        overflow |= !(fabsf(o[e]) <= kHalfMax);
+                        vh[e] = hh;
+                        vl[e] = ll;
+                    }
+                    const size_t ob = blk_index(m, c0, g.N);
+                    *reinterpret_cast<f16x4*>(g.Chi + ob) = vh;
+                    if (!X2) *reinterpret_cast<f16x4*>(g.Clo + ob) = vl;
+                }
+            }
+    }
+    if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
+}
+
+// the ConcatSquash GEMMs (EPI_CSL into fp32 or planes) of every kernel below run transposed with the row-wise epilogue
+template <int EPI, int OUT>
+constexpr bool csl_rowwise() { return EPI == EPI_CSL && (OUT == OUT_F32 || OUT == OUT_SPLIT); }
+
+
 template <int WM, int WN, int EPI, int OUT, bool X2 = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -318,12 +387,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmHArgs g) {
                 wh[j] = *reinterpret_cast<const f16x8*>(Wh + j * 32 * LD + ks * 16);
                 wl[j] = *reinterpret_cast<const f16x8*>(Wl + j * 32 * LD + ks * 16);
             }
-            mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
+            mfma3<WM, WN, X2, csl_rowwise<EPI, OUT>()>(ah, al, wh, wl, accm);
         }
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
+    if constexpr (csl_rowwise<EPI, OUT>()) {
+        csl_swapped_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
+        return;
+    }
     gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi);
 }
 
@@ -443,8 +516,12 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
                 wh[j] = *reinterpret_cast<const f16x8*>(st + 2 * DMA_PLANE + offW[j][ks]);
                 wl[j] = *reinterpret_cast<const f16x8*>(st + 3 * DMA_PLANE + offW[j][ks]);
             }
-            mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
+            mfma3<WM, WN, X2, csl_rowwise<EPI, OUT>()>(ah, al, wh, wl, accm);
         }
+    }
+    if constexpr (csl_rowwise<EPI, OUT>()) {
+        csl_swapped_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
+        return;
     }
     gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi);
 }
@@ -564,10 +641,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 #pragma unroll
                 for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(wh[i]), "v"(wl[i]));
             } else {
-                mfma3<WM, WN, X2>(ah, al, wh, wl, accm);
+                mfma3<WM, WN, X2, csl_rowwise<EPI, OUT>()>(ah, al, wh, wl, accm);
             }
         }
         stage = stage == 2 ? 0 : stage + 1;
+    }
+    if constexpr (csl_rowwise<EPI, OUT>()) {
+        csl_swapped_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
+        return;
     }
     gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
 }
@@ -942,61 +1023,6 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     return hipGetLastError();
 }
 
-// Row-wise epilogue (ConcatSquash; also plain bias + ReLU) for accumulators of the TRANSPOSED product (W fragments as the first MFMA operand): a lane holds ONE
-// token row per 32-row block and 4 consecutive columns per register group, so the (episode, agent) row of the hyper buffer -
-// three integer divisions - is found once per row instead of once per element, gate / bias / time vectors come as 16-byte
-// loads, and the result leaves as 16-byte (fp32) or 8-byte (fp16 planes) stores.  Per element the arithmetic of
-// gemm_h_epilogue_impl<.., EPI_CSL, ..>: the same bits.
-template <int WM, int WN, int EPI, int OUT, bool X2>
-__device__ __forceinline__ void csl_swapped_epilogue(const GemmHArgs& g, f32x16 (&acc)[WM][WN], int mw0, int nw0, int l31, int hi) {
-    bool overflow = false;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        const int m = mw0 + i * 32 + l31;
-        if (m >= g.M) continue;
-        const float* hrow = EPI == EPI_CSL ? g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld : nullptr;
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c0 = nw0 + j * 32 + 8 * q + 4 * hi;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + c0);
-                f32x4 tg, tb, hg, hb;
-                if (EPI == EPI_CSL) {
-                    tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0);
-                    tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
-                    hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0);
-                    hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
-                }
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[e]);
-                    if (EPI == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-                    if (EPI == EPI_CSL) v = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
-                    o[e] = v;
-                }
-                if (OUT == OUT_F32) {
-                    *reinterpret_cast<f32x4*>(g.C + (size_t)m * g.ldc + c0) = o;
-                } else {
-                    f16x4 vh, vl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        half_t hh, ll;
-                        split_f32(o[e], hh, ll);
-                        overflow |= !(fabsf(o[e]) <= kHalfMax);
-                        vh[e] = hh;
-                        vl[e] = ll;
-                    }
-                    const size_t ob = blk_index(m, c0, g.N);
-                    *reinterpret_cast<f16x4*>(g.Chi + ob) = vh;
-                    if (!X2) *reinterpret_cast<f16x4*>(g.Clo + ob) = vl;
-                }
-            }
-    }
-    if (OUT != OUT_F32 && overflow) atomicOr(g.range_flag, 1);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // JMID_PREC_F16MX: the F16X2 product  A_hi . (W_hi + W_lo)  with the correction term on the block-scaled fp8 matrix path:
 //     acc += A_hi . W_hi                 four v_mfma_f32_32x32x16_f16 per k64 and output tile, as before
@@ -1346,8 +1372,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
             al[0] = *reinterpret_cast<const f16x8*>(st + DMA64_PLANE + offA[ks]);
             wh[0] = *reinterpret_cast<const f16x8*>(st + 2 * DMA64_PLANE + offW[ks]);
             wl[0] = *reinterpret_cast<const f16x8*>(st + 3 * DMA64_PLANE + offW[ks]);
-            mfma3<1, 1, X2>(ah, al, wh, wl, accm);
+            mfma3<1, 1, X2, csl_rowwise<EPI, OUT>()>(ah, al, wh, wl, accm);
         }
+    }
+    if constexpr (csl_rowwise<EPI, OUT>()) {
+        csl_swapped_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0 + wr * WM * 32, n0 + wc * WN * 32, l31, hi);
+        return;
     }
     gemm_h_epilogue<WM, WN, EPI, OUT, X2>(g, accm, m0, n0, wr, wc, l31, hi, BM, BN);
 }
