@@ -58,7 +58,9 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     plus ONE v_mfma_f32_32x32x64_f8f6f4 per 64-deep block on bf8(A_hi) x bf8(W_lo) (bf8 = e5m2 = the top byte
  *                     of the fp16 value, rounded to nearest; unscaled) - 1.5 instead of 2 MFMA passes per product.  The term is
  *                     2^-11 of the product, so its 2-bit significand costs nothing measurable: same GEMM error (2^-12.7) and
- *                     same ADE as F16X2 on every fixture, ~10 % more trajectories per second.  Attention as in F16X2.
+ *                     same ADE as F16X2 on every fixture.  In attention (head_dim 128) the two correction terms of the logits
+ *                     take the same path (bf8 images of K from the QKV GEMM, of Q made in the kernel); P.V as in F16X2.
+ *                     ~15 % more trajectories per second than F16X2.
  *                     Bit-identical across batch sizes / chunk plans like the other modes.  The default of the Python class.
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3, JMID_PREC_F16MX = 4 };
@@ -183,21 +185,8 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     (bit-identical, 2 % slower per call)
  *   "out_traj"        output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories per chunk,
  *                     1 = always, 2 = one wave per token (bit-identical)
- *   "attn_mx"         JMID_PREC_F16MX: 1 = the logits' correction terms as bf8 MFMAs too (bf8 K images from the QKV epilogue;
- *                     attention -7 %, QKV GEMM +25 %: slower overall; results differ at rounding level)
- *   "ln_fuse"         GEMM + residual + LayerNorm in one kernel (d_model 512): 0 auto (>= 8192 tokens), 1 always, 2 never
- *   "no_vt_direct"    1 = V row-major + transpose kernel even when the QKV epilogue could write V^T itself
- *   "lanes"           chunks of the denoise loop in flight at once on separate streams, 1..4 (default 2: +2-4 % on batches
- *                     of several chunks; bit-identical to 1 - see DESIGN.md section 3 for what used to prevent that)
- *   "bystander_lds"   bytes of dynamic LDS (0..163840, default 0) the row-wise kernels request without using them, so
- *                     that they never share a CU with an attention / GEMM workgroup of another lane (>= 65536 made
- *                     lanes > 1 reproducible in every soak run so far)
- *   "fuse_embed"      0 = separate embedding kernel at the start of every step instead of the fused output kernel
- *   "ln_rows"         row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
- *   "attn_pack"       0 = one short sequence (S <= 16, iMID) per wave instead of several per score tile
- *   "tail_fuse"       1 = concat3 -> concat4 -> output layer -> sampler update -> next embedding in one kernel (d_model
- *                     512; bit-identical, two launches fewer per step, measured slower: off by default), 0 / 2 = the three
- *                     separate launches; "tail_rows" its row tile (0 auto, 32, 64)
+ *   "attn_mx"         JMID_PREC_F16MX, head_dim 128: 2 = the logits' correction terms as fp16 MFMAs (F16X2's attention) instead of
+ *                     bf8 ones (default; results differ at rounding level, 2.8 % slower per call)
  *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
  *                     LDS; 3 = only Q / K direct
  *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with

@@ -732,6 +732,12 @@ __device__ __forceinline__ bool vt_staged_store(const GemmHArgs& g, f32x16 (&acc
 // per lane = 256 contiguous bytes per token row: 16 + 16 store instructions per wave instead of 256 two-byte ones.
 // Same arithmetic as gemm_h_epilogue (bias, Q pre-scaled by qscale, unscaled hi/lo split).
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x4_e __attribute__((ext_vector_type(4)));
+typedef int i32x2_e __attribute__((ext_vector_type(2)));
+// bf8 (e5m2) images of the four fp16 values in two dwords: their top bytes after rounding to nearest (= bf8_of_f16x4 below)
+__device__ __forceinline__ int bf8_of_f16x4_e(int d0, int d1) {
+    return (int)__builtin_amdgcn_perm((unsigned)(d1 + 0x00800080), (unsigned)(d0 + 0x00800080), 0x07050301u);
+}
 template <bool K8IMG = false>     // K8IMG: the kernel variant that can write bf8 K images (attn_mx = 1); compiled out of the default one
 __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc)[2][4], int mw0, int nw0, half_t* wlds, int l31,
                                                 int hi, int lane) {
@@ -761,46 +767,6 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
     const bool k8 = K8IMG && part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
-        if (plane == 1 && k8) {
-            // byte planes through the same LDS: [64 rows][128 bytes] per image, 16-byte units XOR-swizzled by the row; one
-            // image at a time (both at once cost 70 spilled registers next to the 128 accumulators)
-            unsigned char* w8 = reinterpret_cast<unsigned char*>(wlds);
-#pragma unroll
-            for (int img = 0; img < 2; ++img) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = i * 32 + l31, sw = (row >> 1) & 7;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            unsigned pk = 0;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float v = acc[i][j][4 * q + e];
-                                half_t hh, ll;
-                                split_f32_unscaled(v, hh, ll);
-                                pk |= (unsigned)bf8_of_f16(img == 0 ? hh : ll) << (8 * e);
-                            }
-                            const int col = j * 32 + 8 * q + 4 * hi;
-                            *reinterpret_cast<unsigned*>(w8 + row * 128 + (((col >> 4) ^ sw) << 4) + (col & 15)) = pk;
-                            __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from computing far ahead of the LDS writes (spills)
-                        }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                unsigned char* dst8 = (img == 0 ? g.K8h : g.K8l) + (size_t)mw0 * g.d + nn0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int row = t * 8 + (lane >> 3), u = lane & 7;
-                    const u32x4_t v16 = *reinterpret_cast<const u32x4_t*>(w8 + row * 128 + ((u ^ ((row >> 1) & 7)) << 4));
-                    if (mw0 + row < g.M) *reinterpret_cast<u32x4_t*>(dst8 + (size_t)row * g.d + u * 16) = v16;
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
-            continue;
-        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = i * 32 + l31;
@@ -825,11 +791,23 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         half_t* dst = dst_base[plane] + (size_t)mw0 * g.d + nn0;
+        // K tile with bf8 images wanted (attn_mx = 1): they are made from the rows on their way out - 8 bytes per lane next to
+        // the 16 of the fp16 plane; the fp16 K_lo plane itself is not written then
+        unsigned char* dst8 = k8 ? (plane == 0 ? g.K8h : g.K8l) + (size_t)mw0 * g.d + nn0 : nullptr;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int row = t * 4 + (lane >> 4), u = lane & 15;
             const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
-            if (mw0 + row < g.M) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
+            if (mw0 + row < g.M) {
+                if (!(k8 && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
+                if (k8) {
+                    const i32x4_e dw = __builtin_bit_cast(i32x4_e, v8);
+                    i32x2_e b8;
+                    b8[0] = bf8_of_f16x4_e(dw[0], dw[1]);
+                    b8[1] = bf8_of_f16x4_e(dw[2], dw[3]);
+                    *reinterpret_cast<i32x2_e*>(dst8 + (size_t)row * g.d + u * 8) = b8;
+                }
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();

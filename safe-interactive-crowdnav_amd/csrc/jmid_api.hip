@@ -500,9 +500,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Chi = sb.Qh; g.Clo = sb.Ql; g.Khi = sb.Kh; g.Klo = sb.Kl;
                 g.Vthi = vt_direct ? sb.Vth : sb.Vh; g.Vtlo = vt_direct ? sb.Vtl : sb.Vl; g.vt_direct = vt_direct;
                 g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad; g.qscale = att_scale * 1.4426950408889634f;
-                // JMID_PREC_F16MX with attn_mx = 1 (opt-in: the attention kernel gets 7 % faster, the QKV epilogue loses more than
-                // that), head_dim 128 (the LDS-DMA attention kernel): bf8 images of K_hi / K_lo in the K_lo plane's memory
-                const bool k8 = h->mx && hd == 128 && tune().attn_h_variant != 1 && tune().attn_mx == 1;
+                // JMID_PREC_F16MX, head_dim 128 (the LDS-DMA attention kernel): bf8 images of K_hi / K_lo in the K_lo plane's memory, for
+                // the logits' correction terms as bf8 MFMAs (attention 7 % faster; "attn_mx" = 2: fp16 terms as in F16X2)
+                const bool k8 = h->mx && hd == 128 && tune().attn_h_variant == 0 && tune().attn_mx != 2;
                 unsigned char* k8h = k8 ? reinterpret_cast<unsigned char*>(sb.Kl) : nullptr;
                 unsigned char* k8l = k8 ? k8h + (size_t)M * d : nullptr;
                 g.K8h = k8h; g.K8l = k8l;
@@ -1377,7 +1377,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
-        {"attn_mx", &Tuning::attn_mx, 0, 1},
+        {"attn_mx", &Tuning::attn_mx, 0, 2},
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
