@@ -1,5 +1,5 @@
 """A/B of one tuning knob on a 51-episode 50-step call: time per call and bitwise equality of the results.
-python tools/ab_knob.py precision knob valueA valueB [episodes] [other=knob ...]"""
+python tools/ab_knob.py precision knob valueA valueB [episodes] [other=knob ...]     (JMID_JOINT=0: the iMID net)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 prec, knob, va, vb = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 E = int(sys.argv[5]) if len(sys.argv) > 5 else 51
 A, K, T = 5, 20, 12
-eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 23), joint=True, step=50)
+eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 23), joint=os.environ.get("JMID_JOINT", "1") == "1", step=50)
 eng.set_tuning("lanes", 1)
 for kv in sys.argv[6:]:
     k, v = kv.split("=")
