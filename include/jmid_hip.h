@@ -59,8 +59,9 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     of the fp16 value, rounded to nearest; unscaled) - 1.5 instead of 2 MFMA passes per product.  The term is
  *                     2^-11 of the product, so its 2-bit significand costs nothing measurable: same GEMM error (2^-12.7) and
  *                     same ADE as F16X2 on every fixture.  In attention (head_dim 128) the two correction terms of the logits
- *                     take the same path (bf8 images of K from the QKV GEMM, of Q made in the kernel); P.V as in F16X2.
- *                     ~15 % more trajectories per second than F16X2.
+ *                     take the same path (bf8 images of K from the QKV GEMM, of Q made in the kernel), and P.V is one MFMA per
+ *                     product: P_hi . V_hi with P rounded to nearest - the one rounding every other activation of the mode gets.
+ *                     ~20 % more trajectories per second than F16X2.
  *                     Bit-identical across batch sizes / chunk plans like the other modes.  The default of the Python class.
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3, JMID_PREC_F16MX = 4 };
@@ -185,8 +186,9 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     (bit-identical, 2 % slower per call)
  *   "out_traj"        output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories per chunk,
  *                     1 = always, 2 = one wave per token (bit-identical)
- *   "attn_mx"         JMID_PREC_F16MX, head_dim 128: 2 = the logits' correction terms as fp16 MFMAs (F16X2's attention) instead of
- *                     bf8 ones (default; results differ at rounding level, 2.8 % slower per call)
+ *   "attn_mx"         JMID_PREC_F16MX, head_dim 128: 0 (default) = the logits' correction terms as bf8 MFMAs and ONE fp16 plane of P
+ *                     (rounded to nearest) in P.V; 1 = bf8 corrections, P_hi + P_lo (4.5 % slower per call, same ADE); 2 = F16X2's
+ *                     attention (fp16 corrections, P_hi + P_lo; 7 % slower).  Results differ at rounding level between the three
  *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
  *                     LDS; 3 = only Q / K direct
  *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with

@@ -26,6 +26,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned int pk_f16(float a, float b) {
     return __builtin_bit_cast(unsigned int, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
+// the same, rounded to nearest even (v_cvt_pk_f16_f32)
+__device__ __forceinline__ unsigned int pk_f16_rne(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_{a, b}, f16x2));
+}
 // p[0..7] -> hi fragment and unscaled lo fragment (8 fp16 each)
 __device__ __forceinline__ void split8(const float* p, f16x8& hi, f16x8& lo) {
     u32x4 h, l;
@@ -260,11 +265,14 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 // below the 2^-12.7 of the mode's GEMMs.  bf8(K) comes from the QKV GEMM epilogue (two 4 KB images per key tile in the
 // place of the 8 KB fp16 K_lo image: same DMA bytes, same fragment-read bytes, no extra VALU work per tile); bf8(Q) is made
 // once per wave from the Q planes.  k order of the fp8 instruction: byte p of lane (row, h) is head dim 64 blk + 32 h + p.
+// P1 (the mode's default): P.V with ONE fp16 plane of P, rounded to nearest - the same single rounding the mode gives every other
+// activation (V itself is one plane): 8 instead of 16 MFMAs per key tile and no lo half of the split.  ADE against exact fp32
+// 1.164e-5 m with or without the P_lo term.
 // PIPE: software-pipelined key-tile loop.  The K ring runs one tile ahead of the V^T ring: iteration t issues the QK^T MFMAs of
 // tile t + 1 FIRST and does the softmax of tile t (VALU / transcendental work that depends only on the previous iteration's
 // scores) in their shadow, then the P.V MFMAs of tile t - a wave keeps its own MFMA pipe busy through its softmax instead
 // of relying on the other wave of the SIMD to fill the gap.  Same arithmetic per element, same order: bit-identical.
-template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false>
+template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
@@ -620,7 +628,15 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
         }
         f16x8 ph[2], pl[2];
-        {
+        if (P1) {       // one fp16 plane of P, rounded to nearest
+#pragma unroll
+            for (int mf = 0; mf < 2; ++mf) {
+                u32x4 hq;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hq[i] = pk_f16_rne(sm[8 * mf + 2 * i], sm[8 * mf + 2 * i + 1]);
+                ph[mf] = __builtin_bit_cast(f16x8, hq);
+            }
+        } else {
             float pv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) pv[r] = sm[r];
@@ -643,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 if (step + 1 < 2 * NT) vload(step + 1, vh_n, vl_n);
                 const int n = step >> 1, mf = step & 1;
                 ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, ph[mf], ot[n], 0, 0, 0);
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
+                if (!P1) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
                 if (!X2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 vh_c = vh_n;
@@ -797,8 +813,16 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
             if (first_use_on_device(mx_seen))
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
-                               (unsigned long long*)nullptr);
+            if (tune().attn_mx != 1) {     // default: one fp16 plane of P
+                static bool p1_seen[64] = {};
+                if (first_use_on_device(p1_seen))
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, true, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt,
+                                   attn_abl_bits(), (unsigned long long*)nullptr);
+            } else
+                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
+                                   (unsigned long long*)nullptr);
         } else if (tune().attn_h_variant == 2) {
             static bool pipe_seen[64] = {};
             if (first_use_on_device(pipe_seen)) {
