@@ -188,7 +188,8 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     1 = always, 2 = one wave per token (bit-identical)
  *   "attn_mx"         JMID_PREC_F16MX, head_dim 128: 0 (default) = the logits' correction terms as bf8 MFMAs and ONE fp16 plane of P
  *                     (rounded to nearest) in P.V; 1 = bf8 corrections, P_hi + P_lo (4.5 % slower per call, same ADE); 2 = F16X2's
- *                     attention (fp16 corrections, P_hi + P_lo; 7 % slower).  Results differ at rounding level between the three
+ *                     attention (fp16 corrections, P_hi + P_lo; 7 % slower).  Results differ at rounding level between the three.
+ *                     3 = as 0, with Q_lo written as an fp16 plane and its bf8 image made in the attention kernel (same bits, 1 % slower)
  *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
  *                     LDS; 3 = only Q / K direct
  *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with

@@ -59,6 +59,7 @@ struct AttnHArgs {
     // JMID_PREC_F16MX (head_dim 128): bf8 images of K_hi and K_lo, [nseq*S, d] bytes each (written by the QKV GEMM instead
     // of the fp16 K_lo plane): the two correction terms of the logits run as bf8 x bf8 MFMAs.  Null: the fp16 terms.
     const unsigned char *K8h, *K8l;
+    const unsigned char* Q8l;    // with them: bf8 image of Q_lo in the Q_lo plane's place (null: made here from the fp16 plane)
 };
 
 template <int HD>
@@ -316,12 +317,26 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const i32x4 vh = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qhi + o8 + 64 * blk + 8 * c));
-                    const i32x4 vl = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qlo + o8 + 64 * blk + 8 * c));
                     q8h[blk][2 * c] = bf8_of_f16x4(vh[0], vh[1]);
                     q8h[blk][2 * c + 1] = bf8_of_f16x4(vh[2], vh[3]);
-                    q8l[blk][2 * c] = bf8_of_f16x4(vl[0], vl[1]);
-                    q8l[blk][2 * c + 1] = bf8_of_f16x4(vl[2], vl[3]);
                 }
+            if (a.Q8l) {      // the QKV GEMM wrote the image (wave-uniform)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const i32x4 l0 = *reinterpret_cast<const i32x4*>(a.Q8l + o8 + 64 * blk);
+                    const i32x4 l1 = *reinterpret_cast<const i32x4*>(a.Q8l + o8 + 64 * blk + 16);
+                    q8l[blk] = i32x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+            } else {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const i32x4 vl = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qlo + o8 + 64 * blk + 8 * c));
+                        q8l[blk][2 * c] = bf8_of_f16x4(vl[0], vl[1]);
+                        q8l[blk][2 * c + 1] = bf8_of_f16x4(vl[2], vl[3]);
+                    }
+            }
         }
     }
     // the Q loads are ordinary VMEM loads: retire them before the DMA ring starts so that vmcnt counts only DMAs

@@ -72,6 +72,7 @@ struct GemmHArgs {
     const unsigned char* W8;  // JMID_PREC_F16MX: bf8(W_lo) in MFMA-fragment order (w8_image_kernel), or null
     unsigned char *K8h, *K8l; // OUT_QKV, JMID_PREC_F16MX with head_dim 128: bf8 images of K_hi / K_lo, [M, d] bytes each, written
                               // INSTEAD of the fp16 K_lo plane (attn_f16x3_dma_kernel<.., MX>); null: K_lo as fp16
+    unsigned char* Q8l;       // with them: bf8 image of Q_lo, [M, d] bytes, INSTEAD of the fp16 Q_lo plane (all that kernel wants of Q_lo)
 };
 
 constexpr int GEMMH_BK = 32;
@@ -202,7 +203,10 @@ __device__ __forceinline__ void gemm_h_epilogue_impl(const GemmHArgs& g, f32x16 
                     } else {
                         if (part == 0) {
                             g.Chi[(size_t)m * g.d + nn] = h;
-                            g.Clo[(size_t)m * g.d + nn] = l;
+                            if (K8 && g.Q8l)
+                                g.Q8l[(size_t)m * g.d + nn] = bf8_of_f16(l);
+                            else
+                                g.Clo[(size_t)m * g.d + nn] = l;
                         } else if (part == 1) {
                             g.Khi[(size_t)m * g.d + nn] = h;
                             if (K8 && g.K8h) {      // K8: compile-time, only the F16MX kernels (the byte stores cost the others registers)
@@ -765,6 +769,7 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
     }
     bool overflow = false;
     const bool k8 = K8IMG && part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
+    const bool q8 = K8IMG && part == 0 && g.Q8l != nullptr;     // Q tile: the bf8 image of Q_lo instead of the fp16 plane
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
 #pragma unroll
@@ -793,14 +798,15 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
         half_t* dst = dst_base[plane] + (size_t)mw0 * g.d + nn0;
         // K tile with bf8 images wanted (attn_mx = 1): they are made from the rows on their way out - 8 bytes per lane next to
         // the 16 of the fp16 plane; the fp16 K_lo plane itself is not written then
-        unsigned char* dst8 = k8 ? (plane == 0 ? g.K8h : g.K8l) + (size_t)mw0 * g.d + nn0 : nullptr;
+        const bool img = k8 || (q8 && plane == 1);
+        unsigned char* dst8 = img ? (k8 ? (plane == 0 ? g.K8h : g.K8l) : g.Q8l) + (size_t)mw0 * g.d + nn0 : nullptr;
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int row = t * 4 + (lane >> 4), u = lane & 15;
             const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
             if (mw0 + row < g.M) {
-                if (!(k8 && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
-                if (k8) {
+                if (!((k8 || q8) && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
+                if (img) {
                     const i32x4_e dw = __builtin_bit_cast(i32x4_e, v8);
                     i32x2_e b8;
                     b8[0] = bf8_of_f16x4_e(dw[0], dw[1]);
@@ -1216,7 +1222,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
     if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         // block-uniform: a Q or K tile (columns below 2 d) is computed transposed and leaves through LDS in full rows
         // (with bf8 K images always: the generic epilogue of this shape is compiled without the byte stores)
-        if (((stage_vt & 2) || (K8IMG && g.K8h && n0 >= g.d)) && n0 < 2 * g.d && g.d % 128 == 0) {
+        if (((stage_vt & 2) || (K8IMG && g.K8h && (n0 >= g.d || g.Q8l))) && n0 < 2 * g.d && g.d % 128 == 0) {
             kloop(std::true_type{});
             __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
             qk_staged_store<K8IMG>(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);

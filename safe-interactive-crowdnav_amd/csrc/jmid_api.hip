@@ -505,7 +505,8 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 const bool k8 = h->mx && hd == 128 && tune().attn_h_variant == 0 && tune().attn_mx != 2;
                 unsigned char* k8h = k8 ? reinterpret_cast<unsigned char*>(sb.Kl) : nullptr;
                 unsigned char* k8l = k8 ? k8h + (size_t)M * d : nullptr;
-                g.K8h = k8h; g.K8l = k8l;
+                unsigned char* q8l = k8 && tune().attn_mx != 3 ? reinterpret_cast<unsigned char*>(sb.Ql) : nullptr;   // 3: Q_lo as fp16 (A/B)
+                g.K8h = k8h; g.K8l = k8l; g.Q8l = q8l;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_QKV>(h, KC_GEMM_QKV, g))) return rc;
                 if (!vt_direct) {
                     ProfScope ps(h, KC_VTRANS);
@@ -516,9 +517,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 ProfScope ps(h, KC_ATTN);
                 const int ns = sb.attn_nsplit;   // per call, not per chunk (run_network)
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
-                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2, k8h, k8l};
+                             att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2, k8h, k8l, q8l};
                 HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
-                g.K8h = nullptr; g.K8l = nullptr;
+                g.K8h = nullptr; g.K8l = nullptr; g.Q8l = nullptr;
             } else {
                 g.C = sb.QKV; g.ldc = 3 * d;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_QKV, g))) return rc;
@@ -1377,7 +1378,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
-        {"attn_mx", &Tuning::attn_mx, 0, 2},
+        {"attn_mx", &Tuning::attn_mx, 0, 3},
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced

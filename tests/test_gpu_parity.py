@@ -436,6 +436,38 @@ def test_vt_through_lds_is_bit_identical_to_direct_stores(precision):
     assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
 
 
+def test_f16mx_attention_variants_hold_parity():
+    """JMID_PREC_F16MX, head_dim 128: the default attention (bf8 logit corrections, one fp16 plane of P), the variant that keeps
+    P_lo ("attn_mx" = 1) and F16X2's attention (= 2) differ at rounding level only: each within the gate of the oracle, and all
+    three equally far from the exact-fp32 mode of the same library (the small-M 64 x 64 QKV tiles write the bf8 images with byte
+    stores, the 19-episode batch through the staged 256 x 256 epilogue).  "attn_mx" = 3 (Q_lo as an fp16 plane, its bf8 image made
+    in the attention kernel instead of by the QKV GEMM) must give the default's bits."""
+    eng, w = get_engine(256, 23, True)
+    A, K, T = 5, 20, 12
+    try:
+        for E, step in ((2, 50), (19, 4)):
+            eng.set_step(step)
+            g = torch.Generator().manual_seed(17 + E)
+            ctx = torch.randn([E, A, 256], generator=g).cuda()
+            x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+            out = {}
+            for v in (0, 1, 2, 3):
+                eng.set_tuning("attn_mx", v)
+                out[v] = eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy()
+            np.testing.assert_array_equal(out[3], out[0])
+            with torch.no_grad():
+                ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=step, joint=True).numpy()
+            for v in (0, 1, 2):
+                assert ade(out[v][:2], ref) <= ADE_GATE, (E, v)
+            assert not np.array_equal(out[0], out[2])          # the knob really selects another kernel
+            exact = eng.denoise(x_T, ctx, precision="f32", want_pos=False)[0].cpu().numpy()
+            err = [ade(out[v], exact) for v in (0, 1, 2)]
+            assert max(err) <= ADE_GATE and max(err) <= 1.25 * min(err), (E, err)     # no variant is the less accurate one
+    finally:
+        eng.set_tuning("attn_mx", 0)
+        eng.set_step(4)
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_captured_denoise_loop_replays_bit_identically(precision):
     """Opt-in ("graph" = 1) for one-chunk calls: the 50-step loop runs eagerly the first time a shape is seen, is captured
