@@ -917,7 +917,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2: rerun with JMID_PREC_F32");
+        if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
     } else if (mem == JMID_MEM_HOST) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
