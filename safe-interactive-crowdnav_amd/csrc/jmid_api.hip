@@ -502,7 +502,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.d = d; g.hd = hd; g.S = S; g.Spad = sg.Spad; g.qscale = att_scale * 1.4426950408889634f;
                 // JMID_PREC_F16MX, head_dim 128 (the LDS-DMA attention kernel): bf8 images of K_hi / K_lo in the K_lo plane's memory, for
                 // the logits' correction terms as bf8 MFMAs (attention 7 % faster; "attn_mx" = 2: fp16 terms as in F16X2)
-                const bool k8 = h->mx && hd == 128 && tune().attn_h_variant == 0 && tune().attn_mx != 2;
+                // (the register-staged GEMM variants a knob can force are F16X2's kernels: no image stores)
+                const bool k8 = h->mx && hd == 128 && tune().attn_h_variant == 0 && tune().attn_mx != 2 &&
+                                tune().gemm_h_variant != 1 && tune().gemm_h_variant != 2;
                 unsigned char* k8h = k8 ? reinterpret_cast<unsigned char*>(sb.Kl) : nullptr;
                 unsigned char* k8l = k8 ? k8h + (size_t)M * d : nullptr;
                 unsigned char* q8l = k8 && tune().attn_mx != 3 ? reinterpret_cast<unsigned char*>(sb.Ql) : nullptr;   // 3: Q_lo as fp16 (A/B)

@@ -455,6 +455,15 @@ def test_f16mx_attention_variants_hold_parity():
                 eng.set_tuning("attn_mx", v)
                 out[v] = eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy()
             np.testing.assert_array_equal(out[3], out[0])
+            eng.set_tuning("attn_mx", 0)
+            for var in (1, 3, 5):      # forced GEMM tile variants: F16X2's register-staged kernel (no bf8 images), two F16MX shapes
+                eng.set_tuning("gemm_h_variant", var)
+                o = eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy()
+                eng.set_tuning("gemm_h_variant", 0)
+                if var == 1:
+                    assert ade(o, out[2]) <= ADE_GATE      # F16X2's GEMMs and attention
+                else:
+                    np.testing.assert_array_equal(o, out[0])
             with torch.no_grad():
                 ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=step, joint=True).numpy()
             for v in (0, 1, 2):
@@ -465,6 +474,7 @@ def test_f16mx_attention_variants_hold_parity():
             assert max(err) <= ADE_GATE and max(err) <= 1.25 * min(err), (E, err)     # no variant is the less accurate one
     finally:
         eng.set_tuning("attn_mx", 0)
+        eng.set_tuning("gemm_h_variant", 0)
         eng.set_step(4)
 
 
