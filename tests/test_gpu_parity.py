@@ -436,6 +436,42 @@ def test_vt_through_lds_is_bit_identical_to_direct_stores(precision):
     assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
 
 
+KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
+               ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("tail_fuse", (1,)), ("csl_swap", (2, 3)),
+               ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
+               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,))]
+
+
+@pytest.mark.parametrize("precision", SPLIT_MODES)
+def test_every_tuning_knob_value_holds_parity(precision):
+    """No combination of a mode with ONE knob off its default may leave the gate (a forced kernel variant that cannot
+    produce an operand format the next kernel expects must be caught by the wiring, not by the user): 19 episodes
+    (22 800 tokens: the large-tile kernels) and one scene (the small-M ones), 4 steps, against the oracle."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(4)
+    A, K, T = 5, 20, 12
+    g = torch.Generator().manual_seed(29)
+    ctx = torch.randn([19, A, 256], generator=g).cuda()
+    x_T = torch.randn([19, K * A, T, 2], generator=g).cuda()
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True).numpy()
+    base = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
+    assert ade(base[:2], ref) <= ADE_GATE
+    bad = []
+    for knob, values in KNOB_VALUES:
+        for v in values:
+            try:
+                eng.set_tuning(knob, v)
+                big = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
+                one = eng.denoise(x_T[:1], ctx[:1], precision=precision, want_pos=False)[0].cpu().numpy()
+            finally:
+                eng.set_tuning(knob, 2 if knob == "lanes" else 1 if knob in ("fuse_embed", "attn_pack") else 0)
+            e_big, e_one = ade(big[:2], ref), ade(one, ref[:1])
+            if not (e_big <= ADE_GATE and e_one <= ADE_GATE and ade(big, base) <= ADE_GATE):
+                bad.append((knob, v, e_big, e_one, ade(big, base)))
+    assert not bad, bad
+
+
 def test_f16mx_attention_variants_hold_parity():
     """JMID_PREC_F16MX, head_dim 128: the default attention (bf8 logit corrections, one fp16 plane of P), the variant that keeps
     P_lo ("attn_mx" = 1) and F16X2's attention (= 2) differ at rounding level only: each within the gate of the oracle, and all
