@@ -51,11 +51,11 @@ WORKLOADS = {
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0, "f16x2": 2500.0, "f16mx": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
 # MFMA FLOPs spent per algorithmic FLOP; f16x2: 2 in the GEMMs, (3 + 2) / 2 in attention (logits keep all three terms)
 MFMA_PASSES = {"f32": 1, "f16x3": 3, "f16x2": 2, "f16mx": 1.5}   # f16mx: the fp8 correction term costs half an fp16 pass
-MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.5, "f16mx": 1.5}   # f16mx: logits 1 + 2 x 0.5, P.V 1
+MFMA_PASSES_ATTN = {"f32": 1, "f16x3": 3, "f16x2": 2.0, "f16mx": 1.5}   # f16x2: logits 3, P.V 1; f16mx: logits 1 + 2 x 0.5, P.V 1
 DTYPE_TEXT = {
     "f32": "f32",
     "f16x3": "f32-class: fp16 hi/lo split operands, 3 MFMAs per product, fp32 accumulate",
-    "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; softmax logits, "
+    "f16x2": "fp16 activation x split-fp16 (hi + lo) weight, 2 MFMAs per product, fp32 accumulate; P.V with one fp16 plane of P; softmax logits, "
              "residual stream, LayerNorm and DDIM state at f32-class precision",
     "f16mx": "fp16 activation x split-fp16 (hi + lo) weight: A_hi x W_hi as fp16 MFMAs plus the correction term as ONE bf8 x bf8 MFMA "
              "per k64 (bf8 = top byte of the fp16 activation / of fp16(W_lo)): 1.5 MFMA passes per GEMM product, fp32 accumulate; "

@@ -50,7 +50,7 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *   JMID_PREC_F16X3   fp32 emulated by three fp16 MFMAs per product on hi/lo-split operands
  *                     (~22 significand bits, fp32 accumulate)
  *   JMID_PREC_F16X2   same operand planes, but the linear contractions take the activation as its fp16 hi plane only:
- *                     A_hi x (W_hi + W_lo) in the GEMMs and (P_hi + P_lo) x V_hi in attention, two MFMAs per product;
+ *                     A_hi x (W_hi + W_lo) in the GEMMs, two MFMAs per product, and P_hi x V_hi in attention (P rounded to nearest);
  *                     the softmax logits Q.K keep all three terms (their error is exponentiated) and the residual
  *                     stream, LayerNorm and DDIM state keep hi + lo.  Mean ADE vs the reference 7e-6 m on the cfg3
  *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~25 % more trajectories per second on batches; the lo planes this mode never reads are not written
@@ -186,9 +186,9 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     (bit-identical, 2 % slower per call)
  *   "out_traj"        output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories per chunk,
  *                     1 = always, 2 = one wave per token (bit-identical)
- *   "attn_mx"         JMID_PREC_F16MX, head_dim 128: 0 (default) = the logits' correction terms as bf8 MFMAs and ONE fp16 plane of P
- *                     (rounded to nearest) in P.V; 1 = bf8 corrections, P_hi + P_lo (4.5 % slower per call, same ADE); 2 = F16X2's
- *                     attention (fp16 corrections, P_hi + P_lo; 7 % slower).  Results differ at rounding level between the three.
+ *   "attn_mx"         head_dim 128.  JMID_PREC_F16MX: 0 (default) = the logits' correction terms as bf8 MFMAs and ONE fp16 plane of P
+ *                     (rounded to nearest) in P.V; 1 = P_hi + P_lo (4.5 % slower per call, same ADE; in JMID_PREC_F16X2 too: 5 %); 2 = F16X2's
+ *                     attention (fp16 corrections; 5 % slower).  Results differ at rounding level between the three.
  *                     3 = as 0, with Q_lo written as an fp16 plane and its bf8 image made in the attention kernel (same bits, 1 % slower)
  *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
  *                     LDS; 3 = only Q / K direct

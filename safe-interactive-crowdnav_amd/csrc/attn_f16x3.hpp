@@ -55,7 +55,7 @@ struct AttnHArgs {
     int nsplit;
     float* Opart;      // [nsplit][nseq*S][d] fp32
     float* MLpart;     // [nsplit][nseq*S][nhead][2]
-    int x2;            // JMID_PREC_F16X2: V enters P.V as its hi plane only (P and the logits keep all terms)
+    int x2;            // JMID_PREC_F16X2: V enters P.V as its hi plane only, and so does P in the head_dim-128 DMA kernel (the logits keep all terms)
     // JMID_PREC_F16MX (head_dim 128): bf8 images of K_hi and K_lo, [nseq*S, d] bytes each (written by the QKV GEMM instead
     // of the fp16 K_lo plane): the two correction terms of the logits run as bf8 x bf8 MFMAs.  Null: the fp16 terms.
     const unsigned char *K8h, *K8l;
@@ -852,6 +852,13 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
             else
                 hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, 0,
                                    (unsigned long long*)nullptr);
+        } else if (a.x2 && tune().attn_mx != 1) {     // F16X2 (and F16MX with "attn_mx" = 2): one fp16 plane of P as well
+            static bool p1x_seen[64] = {};
+            if (first_use_on_device(p1x_seen))
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, false, false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, false, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt,
+                               attn_abl_bits(), (unsigned long long*)nullptr);
         } else if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
             hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
                                (unsigned long long*)nullptr);
