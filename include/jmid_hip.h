@@ -61,7 +61,7 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     same ADE as F16X2 on every fixture.  In attention (head_dim 128) the two correction terms of the logits
  *                     take the same path (bf8 images of K from the QKV GEMM, of Q made in the kernel), and P.V is one MFMA per
  *                     product: P_hi . V_hi with P rounded to nearest - the one rounding every other activation of the mode gets.
- *                     ~25 % more trajectories per second than F16X2.
+ *                     ~20 % more trajectories per second than F16X2.
  *                     Bit-identical across batch sizes / chunk plans like the other modes.  The default of the Python class.
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3, JMID_PREC_F16MX = 4 };
