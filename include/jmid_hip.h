@@ -53,7 +53,7 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     A_hi x (W_hi + W_lo) in the GEMMs, two MFMAs per product, and P_hi x V_hi in attention (P rounded to nearest);
  *                     the softmax logits Q.K keep all three terms (their error is exponentiated) and the residual
  *                     stream, LayerNorm and DDIM state keep hi + lo.  Mean ADE vs the reference 7e-6 m on the cfg3
- *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~25 % more trajectories per second on batches; the lo planes this mode never reads are not written
+ *                     shape (F16X3: 1e-6 m; gate 1e-4 m), ~35 % more trajectories per second on batches; the lo planes this mode never reads are not written
  *   JMID_PREC_F16MX   F16X2 with the weight-lo correction term of every GEMM on the fp8 matrix path: A_hi x W_hi as fp16 MFMAs
  *                     plus ONE v_mfma_f32_32x32x64_f8f6f4 per 64-deep block on bf8(A_hi) x bf8(W_lo) (bf8 = e5m2 = the top byte
  *                     of the fp16 value, rounded to nearest; unscaled) - 1.5 instead of 2 MFMA passes per product.  The term is

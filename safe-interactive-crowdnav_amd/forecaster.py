@@ -14,12 +14,13 @@ library through the C ABI (``engine.py`` -> ``include/jmid_hip.h``).  There is n
 
 Arithmetic (``precision``): the contractions run in the library's F16MX mode by default - fp16 activation operand times
 split-fp16 weight, as ``A_hi . W_hi`` on the fp16 matrix cores plus the correction term ``A_hi . W_lo`` as ONE bf8 x bf8
-MFMA per 64-deep block (1.5 MFMA passes per GEMM product), fp32 accumulation; softmax logits, residual stream, LayerNorm
-and DDIM state at fp32-class precision.  It is the mode ``bench.py`` quotes, >= the bf16 BASELINE.json names for this
+MFMA per 64-deep block (1.5 MFMA passes per GEMM product), fp32 accumulation; three-term softmax logits (their correction
+terms on the same fp8 path), one fp16 plane of the attention weights, residual stream, LayerNorm and DDIM state at
+fp32-class precision.  It is the mode ``bench.py`` quotes, >= the bf16 BASELINE.json names for this
 workload, and it holds every reference golden fixture inside the 1e-4 m mean-ADE gate with the same errors as
-``precision="f16x2"`` (the same products with the correction term in fp16: two passes; worst 5.3e-5 m on the 2-step
-fixtures, 4e-6 m on the 50-step cfg3 sample).  ``"f16x3"`` selects the fp32-class three-term
-products (mean ADE ~1e-6 m, the fp32-vs-fp64 noise floor; ~25 % fewer trajectories per second on batches), ``"f32"`` the
+``precision="f16x2"`` (the same products with the correction terms in fp16: two passes; worst 5.7e-5 m on the 2-step
+fixtures, 5e-6 m on the 50-step cfg3 sample).  ``"f16x3"`` selects the fp32-class three-term
+products (mean ADE ~1e-6 m, the fp32-vs-fp64 noise floor; ~40 % fewer trajectories per second on batches), ``"f32"`` the
 exact-fp32 MFMA path.  If an activation ever leaves the fp16 range the call is repeated transparently in the exact-fp32 mode.
 
 RNG contract (``rng_compat``): ``x_T`` is always the first draw of torch's CPU default generator
