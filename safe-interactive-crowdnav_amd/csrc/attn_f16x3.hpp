@@ -812,59 +812,35 @@ inline int attn_pick_nsplit(int base_blocks, int S) {
 }
 
 
+// one instantiation of the LDS-DMA kernel: its dynamic-LDS attribute once per device, then the launch
+template <bool X2, bool MX, bool PIPE, bool P1>
+inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t st) {
+    static bool seen[64] = {};
+    const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1>;
+    if (first_use_on_device(seen))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
+    hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
+}
+
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, hipStream_t st) {
     if (head_dim == 128 && tune().attn_h_variant != 1) {
-        static bool attr_seen[64] = {};
-        if (first_use_on_device(attr_seen)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-        }
         const int nqt = (a.S + 127) / 128;
         const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
+        // the mode is a template parameter (a run-time flag in the key-tile loop costs F16X3 ~4 %).  F16X2 / F16MX: one fp16 plane
+        // of P unless "attn_mx" = 1; F16MX with bf8 K images: the logits' correction terms as bf8 MFMAs
+        const bool p1 = tune().attn_mx != 1;
         if (a.x2 && a.K8h) {
-            static bool mx_seen[64] = {};
-            if (first_use_on_device(mx_seen))
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-            if (tune().attn_mx != 1) {     // default: one fp16 plane of P
-                static bool p1_seen[64] = {};
-                if (first_use_on_device(p1_seen))
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, true, false, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt,
-                                   attn_abl_bits(), (unsigned long long*)nullptr);
-            } else
-                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
-                                   (unsigned long long*)nullptr);
-        } else if (tune().attn_h_variant == 2) {
-            static bool pipe_seen[64] = {};
-            if (first_use_on_device(pipe_seen)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, false, false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-            }
-            if (a.x2)
-                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, 0,
-                                   (unsigned long long*)nullptr);
-            else
-                hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, 0,
-                                   (unsigned long long*)nullptr);
-        } else if (a.x2 && tune().attn_mx != 1) {     // F16X2 (and F16MX with "attn_mx" = 2): one fp16 plane of P as well
-            static bool p1x_seen[64] = {};
-            if (first_use_on_device(p1x_seen))
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f16x3_dma_kernel<false, true, false, false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true, false, false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt,
-                               attn_abl_bits(), (unsigned long long*)nullptr);
-        } else if (a.x2)      // the mode is a template parameter: a run-time flag in the key-tile loop costs F16X3 ~4 %
-            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, true>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
-                               (unsigned long long*)nullptr);
-        else
-            hipLaunchKernelGGL((attn_f16x3_dma_kernel<false, false>), grid1, dim3(256), ATT_DMA_LDS, st, a, nqt, attn_abl_bits(),
-                               (unsigned long long*)nullptr);
+            if (p1) launch_attn_dma<true, true, false, true>(a, grid1, nqt, st);
+            else launch_attn_dma<true, true, false, false>(a, grid1, nqt, st);
+        } else if (tune().attn_h_variant == 2) {      // software-pipelined variant (opt-in; both planes of P)
+            if (a.x2) launch_attn_dma<true, false, true, false>(a, grid1, nqt, st);
+            else launch_attn_dma<false, false, true, false>(a, grid1, nqt, st);
+        } else if (a.x2) {
+            if (p1) launch_attn_dma<true, false, false, true>(a, grid1, nqt, st);
+            else launch_attn_dma<true, false, false, false>(a, grid1, nqt, st);
+        } else {
+            launch_attn_dma<false, false, false, false>(a, grid1, nqt, st);
+        }
         if (a.nsplit > 1) {
             const size_t Mtot = (size_t)nseq * a.S;
             const int blocks = (int)std::min<size_t>((Mtot * (a.d / 4) + 255) / 256, 2048);
