@@ -190,6 +190,8 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  *                     (rounded to nearest) in P.V; 1 = P_hi + P_lo (4.5 % slower per call, same ADE; in JMID_PREC_F16X2 too: 5 %); 2 = F16X2's
  *                     attention (fp16 corrections; 5 % slower).  Results differ at rounding level between the three.
  *                     3 = as 0, with Q_lo written as an fp16 plane and its bf8 image made in the attention kernel (same bits, 1 % slower)
+ *   "attn_pf"         2 = the F16MX / F16X2 attention kernel reads its K / V^T fragments one step ahead instead of three (same bits,
+ *                     1.3 % / 0.5 % slower per call)
  *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
  *                     LDS; 3 = only Q / K direct
  *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with

@@ -273,7 +273,7 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 // tile t + 1 FIRST and does the softmax of tile t (VALU / transcendental work that depends only on the previous iteration's
 // scores) in their shadow, then the P.V MFMAs of tile t - a wave keeps its own MFMA pipe busy through its softmax instead
 // of relying on the other wave of the SIMD to fill the gap.  Same arithmetic per element, same order: bit-identical.
-template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false>
+template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
@@ -561,7 +561,47 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         f32x16 sm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
-        if (MX) {
+        constexpr int PFD = 3;        // PF: fragment reads PFD steps ahead (4: no better)
+        f16x8 vpre[PFD];      // the first V^T fragments, requested before the softmax
+        if (MX && PF) {
+            // PF: fragment reads three steps ahead (one MFMA per step covers 32 cycles of an LDS round trip of > 64), the bf8 K
+            // fragments requested inside the fp16 loop, the first V^T fragments before the softmax
+            auto kread = [&](int ks) { return *reinterpret_cast<const f16x8*>(Kh + kbase + (((2 * ks + hi) ^ kx) << 3)); };
+            const unsigned char* k8 = reinterpret_cast<const unsigned char*>(Kl);
+            const int r8 = l31 * 128, sw = (l31 >> 1) & 7;
+            auto k8read = [&](int img, int blk, int c) {
+                return *reinterpret_cast<const i32x4*>(k8 + img * 4096 + r8 + (((blk * 4 + hi * 2 + c) ^ sw) << 4));
+            };
+            f16x8 kf[NKS];
+            i32x4 k8f[2][2][2];      // [blk][image][chunk]
+#pragma unroll
+            for (int i = 0; i < PFD; ++i) kf[i] = kread(i);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                if (ks + PFD < NKS) kf[ks + PFD] = kread(ks + PFD);
+                if (ks == 5 || ks == 7) {
+                    const int blk = ks == 5 ? 0 : 1;
+                    k8f[blk][0][0] = k8read(0, blk, 0); k8f[blk][0][1] = k8read(0, blk, 1);
+                    k8f[blk][1][0] = k8read(1, blk, 0); k8f[blk][1][1] = k8read(1, blk, 1);
+                }
+                sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qh[ks], sm, 0, 0, 0);
+                if (more && !(abl & 16)) issue_one(kt + 1, ks);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (P1) {
+#pragma unroll
+                for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i >> 1) * 1024 + vbase[i & 1]);
+            }
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const i32x4 h0 = k8f[blk][0][0], h1 = k8f[blk][0][1], l0 = k8f[blk][1][0], l1 = k8f[blk][1][1];
+                const i32x8 kh8 = i32x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const i32x8 kl8 = i32x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                sm = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kh8, q8l[blk], sm, 1, 1, 0, 0, 0, 0);
+                sm = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kl8, q8h[blk], sm, 1, 1, 0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (MX) {
             // fp16 part: K_hi . Q_hi, fragments read one step ahead; the next tile's DMA instructions go out one per step
             f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + kbase + (((0 + hi) ^ kx) << 3));
 #pragma unroll
@@ -611,6 +651,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 kl_c = kl_n;
             }
         }
+        if (PF && P1 && !MX) {
+#pragma unroll
+            for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i >> 1) * 1024 + vbase[i & 1]);
+        }
         ATT_STAMP(4)
         if (!(abl & 2)) {
         if (kt == ntiles_all - 1) {              // only the last tile can hold keys past S
@@ -659,6 +703,17 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             split8(pv + 8, ph[1], pl[1]);
         }
         ATT_STAMP(5)
+        if (PF && P1 && X2) {
+            f16x8 vf[2 * NT];
+#pragma unroll
+            for (int i = 0; i < PFD; ++i) vf[i] = vpre[i];
+#pragma unroll
+            for (int step = 0; step < 2 * NT; ++step) {
+                if (step + PFD < 2 * NT) vf[step + PFD] = *reinterpret_cast<const f16x8*>(Vh + ((step + PFD) >> 1) * 1024 + vbase[(step + PFD) & 1]);
+                ot[step >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[step], ph[step & 1], ot[step >> 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         if (!(abl & 4)) {
             // same pipelining for the V^T fragments: step = (n, mf), 8 steps of three MFMAs
             auto vload = [&](int step, f16x8& vh, f16x8& vl) {
@@ -813,10 +868,10 @@ inline int attn_pick_nsplit(int base_blocks, int S) {
 
 
 // one instantiation of the LDS-DMA kernel: its dynamic-LDS attribute once per device, then the launch
-template <bool X2, bool MX, bool PIPE, bool P1>
+template <bool X2, bool MX, bool PIPE, bool P1, bool PF = false>
 inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t st) {
     static bool seen[64] = {};
-    const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1>;
+    const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1, PF>;
     if (first_use_on_device(seen))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
     hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
@@ -830,13 +885,15 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
         // of P unless "attn_mx" = 1; F16MX with bf8 K images: the logits' correction terms as bf8 MFMAs
         const bool p1 = tune().attn_mx != 1;
         if (a.x2 && a.K8h) {
-            if (p1) launch_attn_dma<true, true, false, true>(a, grid1, nqt, st);
+            if (p1 && tune().attn_pf != 2) launch_attn_dma<true, true, false, true, true>(a, grid1, nqt, st);
+            else if (p1) launch_attn_dma<true, true, false, true>(a, grid1, nqt, st);
             else launch_attn_dma<true, true, false, false>(a, grid1, nqt, st);
         } else if (tune().attn_h_variant == 2) {      // software-pipelined variant (opt-in; both planes of P)
             if (a.x2) launch_attn_dma<true, false, true, false>(a, grid1, nqt, st);
             else launch_attn_dma<false, false, true, false>(a, grid1, nqt, st);
         } else if (a.x2) {
-            if (p1) launch_attn_dma<true, false, false, true>(a, grid1, nqt, st);
+            if (p1 && tune().attn_pf != 2) launch_attn_dma<true, false, false, true, true>(a, grid1, nqt, st);
+            else if (p1) launch_attn_dma<true, false, false, true>(a, grid1, nqt, st);
             else launch_attn_dma<true, false, false, false>(a, grid1, nqt, st);
         } else {
             launch_attn_dma<false, false, false, false>(a, grid1, nqt, st);

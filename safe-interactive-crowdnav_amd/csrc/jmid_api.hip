@@ -1382,6 +1382,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
         {"attn_mx", &Tuning::attn_mx, 0, 3},
         {"out_traj", &Tuning::out_traj, 0, 2},
+        {"attn_pf", &Tuning::attn_pf, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
