@@ -840,16 +840,18 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t M
 }
 
 // number of key-range splits for a launch with `base_blocks` workgroups.
-//  * at most half a round of the 512 resident workgroups (a scene or a few): the largest split count that still
+//  * sequences of fewer than 128 key tiles (S < 4096), or at most one workgroup per CU: the largest split count that still
 //    leaves ONE workgroup per CU (<= 256 workgroups) with >= 4 key tiles each - one scene (40 base workgroups) gets
-//    6 splits = 240 workgroups: measured 13.6 ms per 50-step call against 13.9 (4), 14.3 (8) and 19.1 (1)
-//    (tools/single_scene_sweep.py);
-//  * more than one "round" of the 512 resident workgroups: the smallest split count (<= 8, >= 4 tiles each) that
-//    fills the last round to >= 90 % - one dense scene (N=25, K=64: 600 workgroups = 1.17 rounds, 59 % efficient)
-//    becomes 2400 workgroups = 4.7 rounds (94 %).
+//    6 splits = 240 workgroups: 12.11 ms per 50-step call against 12.12 (5), 12.25 (4), 12.84 (7), 12.90 (8); a 2-scene
+//    launch (80) 3, a 4-scene launch (160) and anything larger none: with 38 tiles per workgroup the partial outputs and
+//    the combine pass cost more than a better filled last round wins (8 episodes as 2 x 4: 28.3 ms unsplit, 30.0 with 3
+//    splits; 16 as 2 x 8: 46.7 against 54.0; tools/single_scene_sweep.py attn_nsplit=... f16mx E);
+//  * long sequences on more than 256 workgroups: the smallest split count (<= 8, >= 4 tiles each) that
+//    fills the last round of the 512 resident workgroups to >= 90 % - one dense scene (N=25, K=64: 600 workgroups of 600
+//    tiles = 1.17 rounds, 59 % efficient) becomes 2400 workgroups = 4.7 rounds (94 %).
 inline int attn_pick_nsplit(int base_blocks, int S) {
     const int ntiles = (S + 31) / 32;
-    if (base_blocks * 2 <= 512) {
+    if (base_blocks <= 256 || ntiles < 128) {
         int ns = 1;
         while (ns < 8 && base_blocks * (ns + 1) <= 256 && ntiles / (ns + 1) >= 4) ++ns;
         return ns;

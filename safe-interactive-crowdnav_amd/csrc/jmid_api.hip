@@ -748,7 +748,10 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     int ns_call = 1;
     if (h->net_kind == JMID_NET_JMID && precision != JMID_PREC_F32 && h->d / h->nhead == 128) {
         const int S = K * A * T;
-        ns_call = attn_pick_nsplit(((S + 127) / 128) * h->nhead * auto_chunk(h, E, S), S);
+        // sized for ONE launch of the default plan (two chunks in flight: a batch that fits one chunk runs as two halves) - a
+        // function of the call's shape only, whatever the chunk size or number of lanes actually set
+        const int c_auto = auto_chunk(h, E, S);
+        ns_call = attn_pick_nsplit(((S + 127) / 128) * h->nhead * (E >= 2 ? (c_auto + 1) / 2 : 1), S);
         if (tune().attn_nsplit > 0) ns_call = std::min(tune().attn_nsplit, (S + 31) / 32);
     }
     // ---- workspace
