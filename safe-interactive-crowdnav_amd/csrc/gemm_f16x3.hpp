@@ -1284,8 +1284,11 @@ inline hipError_t launch_gemm_mx(const GemmHArgs& g, hipStream_t st) {
     auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };
     if constexpr (EPI != EPI_CSL)
         if (g.N % 256 == 0) {
+            // also below one workgroup per CU, from 7168 rows: two chunks are in flight, and the larger tile moves a third
+            // fewer operand bytes per FLOP (2 x 12 episodes per call 60.6 vs 67.6 ms, 2 x 8: 45.1 vs 47.4, 2 x 6 equal,
+            // 2 x 5: 35.8 vs 33.4; tools/single_scene_sweep.py gemm_h_variant=0,6 f16mx E)
             const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
-            if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
+            if ((nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) || (nbq < 256 && g.M >= 7168)) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
         }
     if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
     return launch_gemm_mx_128<EPI, OUT>(g, st);
@@ -1400,8 +1403,10 @@ inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     // 256x256 when N allows it (in_proj, linear1) and the grid still fills the chip; the ConcatSquash epilogue needs
     // too many registers next to the 128 accumulators
     if (EPI != EPI_CSL && g.N % 256 == 0) {
+        // (below one workgroup per CU too from 12288 rows - two chunks are in flight: 2 x 12 episodes per call 76.0 vs 79.7 ms
+        // in F16X2, 102.2 vs 107.5 in F16X3; 2 x 8: within 1 %)
         const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
-        if (nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
+        if ((nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) || (nbq < 256 && g.M >= 12288)) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
     }
     if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_h_dma256<EPI, OUT, X2>(g, st);
     return launch_gemm_h_dma<EPI, OUT, X2>(g, st);
