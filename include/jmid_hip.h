@@ -163,12 +163,32 @@ int jmid_net_eval(jmid_handle_t h, int E, int A, int K, int T, int step_idx, con
 int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const float* pos, const float* gt,
                          float* out, int mem);
 
+/* Joint-KDE ranking of the K sampled futures of every episode and selection of the k most likely ones:
+ * get_most_likely_samples (sicnav_diffusion/JMID/mid_sim_wrapper.py:14-169, the joint branch :20-21 the predictor always takes;
+ * called from predict_ret_best when num_ret_samples < K, :487-492), which the reference runs on its GPU when it has one (:26-30).
+ *   pos   [E, K, A, T, 2]  integrated sample trajectories (jmid_denoise's pos_out layout), or NULL: the positions of the most
+ *                          recent jmid_denoise on this handle (same E, A, K, T, called with p0), still resident in the workspace -
+ *                          the samples then never leave the GPU
+ *   bw    [T] KDE bandwidth per horizon step, exp(linspace(ln .01, ln .1, T)) as the reference computes it (:26-30), or NULL
+ *                          (computed in the library)
+ *   sel   [E, A, k, T, 2]  the kept samples in ascending likelihood (the reference's argsort(...)[-k:], :117-121)
+ *   logw  [E, A, k]        their renormalised log-weights, the same row for every agent (:139-151)
+ * fp64 inside (A <= 32, K <= 1024); exact ties are broken by sample index (torch.argsort's tie order is not reproduced). */
+int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* pos, const float* bw, float* sel, float* logw,
+              int mem);
+
 /* The stream (a hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream; NULL = the legacy default
  * stream) that produces the inputs and consumes the outputs of this handle's JMID_MEM_DEVICE calls - see Conventions. */
 int jmid_set_caller_stream(jmid_handle_t h, void* stream);
 
 /* Number of calls on this handle whose denoise loop ran as a replayed hipGraph (see "graph" below); -1 for a null handle. */
 int64_t jmid_graph_replays(jmid_handle_t h);
+
+/* Number of calls on this handle that ended with JMID_ERANGE (an fp16 operand left the fp16 range in a split-fp16 mode and the
+ * caller had to repeat the call in JMID_PREC_F32 - the Python predictor does, forecaster.py: what the reference computes in fp32
+ * throughout, MID/models/diffusion.py:478-541, so the result is unchanged and only the latency differs); -1 for a null handle.
+ * A deployment with trained weights reads this to see how often the slow path fires. */
+int64_t jmid_erange_count(jmid_handle_t h);
 
 /* ---- tuning / measurement ------------------------------------------------------------------ */
 /* Episodes processed together per pass of the 50-step loop (0 = automatic: a whole number of rounds of the attention

@@ -37,10 +37,13 @@ SIGNATURES = {
                                 C.c_int, C.c_void_p, C.c_int]),
     "jmid_episode_metrics": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_int]),
+    "jmid_topk": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_int]),
     "jmid_set_chunk_episodes": (C.c_int, [Handle, C.c_int]),
     "jmid_set_tuning": (C.c_int, [Handle, C.c_char_p, C.c_int]),
     "jmid_set_caller_stream": (C.c_int, [Handle, C.c_void_p]),
     "jmid_graph_replays": (C.c_int64, [Handle]),
+    "jmid_erange_count": (C.c_int64, [Handle]),
     "jmid_profile_enable": (C.c_int, [Handle, C.c_uint32]),
     "jmid_profile_reset": (C.c_int, [Handle]),
     "jmid_profile_get": (C.c_int, [Handle, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -872,9 +872,9 @@ inline int attn_pick_nsplit(int base_blocks, int S) {
 // one instantiation of the LDS-DMA kernel: its dynamic-LDS attribute once per device, then the launch
 template <bool X2, bool MX, bool PIPE, bool P1, bool PF = false>
 inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t st) {
-    static bool seen[64] = {};
+    static DevSeen seen;
     const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1, PF>;
-    if (first_use_on_device(seen))
+    if (auto once_ = first_use_on_device(seen))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
     hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }

@@ -326,8 +326,8 @@ inline hipError_t launch_attn_f32_hd(const AttnArgs& a, int nseq, hipStream_t st
         const int J = (a.S + 1) / 2;
         const int G = std::min(32 / a.S, 16 / J);
         const size_t lds = size_t(4) * 32 * (HD + 4) * sizeof(float);
-        static bool attr_seen[64] = {};
-        if (first_use_on_device(attr_seen)) {
+        static DevSeen attr_seen;
+        if (auto once_ = first_use_on_device(attr_seen)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_packed_kernel<HD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         }

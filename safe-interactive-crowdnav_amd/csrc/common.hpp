@@ -4,6 +4,9 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 namespace jmid {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -113,14 +116,38 @@ inline int attn_abl_bits() { return 0; }
 inline int gemm_abl_bits() { return 0; }
 #endif
 
-// One-time per-device setup (function attributes are per device): true the first time `seen` meets the current device.
-inline bool first_use_on_device(bool (&seen)[64]) {
+// One-time per-device setup (function attributes are per device).  `if (auto once = first_use_on_device(seen)) { set attributes }`:
+// the body runs once per device; concurrent first users of the same kernel (two handles on two threads) wait on the lock, and
+// the device is marked only AFTER the body has run, so nobody launches before the attribute is set.
+struct DevSeen {
+    std::atomic<bool> v[64];
+    DevSeen() { for (auto& b : v) b.store(false, std::memory_order_relaxed); }
+};
+struct DeviceOnce {
+    std::unique_lock<std::mutex> lk;
+    std::atomic<bool>* slot = nullptr;
+    explicit operator bool() const { return slot != nullptr; }
+    DeviceOnce() = default;
+    DeviceOnce(DeviceOnce&& o) noexcept : lk(std::move(o.lk)), slot(o.slot) { o.slot = nullptr; }
+    ~DeviceOnce() { if (slot) slot->store(true, std::memory_order_release); }
+};
+inline std::mutex& device_once_mutex() {
+    static std::mutex m;
+    return m;
+}
+inline DeviceOnce first_use_on_device(DevSeen& seen) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= 63;
-    if (seen[dev]) return false;
-    seen[dev] = true;
-    return true;
+    DeviceOnce o;
+    if (seen.v[dev].load(std::memory_order_acquire)) return o;
+    o.lk = std::unique_lock<std::mutex>(device_once_mutex());
+    if (seen.v[dev].load(std::memory_order_acquire)) {
+        o.lk.unlock();
+        return o;
+    }
+    o.slot = &seen.v[dev];
+    return o;
 }
 
 // Dynamic LDS the small row-wise kernels request although they use none (tuning knob "bystander_lds").  With a

@@ -409,8 +409,8 @@ inline hipError_t launch_gemm_h_cfg(const GemmHArgs& g, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
     size_t lds = gemm_h_lds_bytes<WM, WN>();
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_kernel<WM, WN, EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
@@ -533,8 +533,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16x3_dma_kernel(GemmHArgs g, int
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 127) / 128, ntn = (g.N + 127) / 128;
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA_LDS_BYTES);
     }
@@ -660,8 +660,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256_kernel(GemmHArgs g, 
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma256(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 255) / 256, ntn = (g.N + 127) / 128;
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA2_LDS_BYTES);
     }
@@ -996,8 +996,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 255) / 256, ntn = g.N / 256;
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma256x256_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA3_LDS_BYTES);
     }
@@ -1254,8 +1254,8 @@ inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
     if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4 && !K8IMG)      // bf8 K images wanted (attn_mx = 1): the variant that can write them
         if (g.K8h) return launch_gemm_mx_cfg<EPI, OUT, WR, WC, WM, WN, NS, true>(g, st);
     const int ntm = (g.M + C::BM - 1) / C::BM, ntn = g.N / C::BN;
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     }
@@ -1372,8 +1372,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_dma64_kernel(GemmHArgs g, i
 template <int EPI, int OUT, bool X2 = false>
 inline hipError_t launch_gemm_h_dma64(const GemmHArgs& g, hipStream_t st) {
     const int ntm = (g.M + 63) / 64, ntn = (g.N + 63) / 64;
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f16x3_dma64_kernel<EPI, OUT, X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DMA64_LDS_BYTES);
     }

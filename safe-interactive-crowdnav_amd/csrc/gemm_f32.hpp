@@ -176,8 +176,8 @@ inline hipError_t launch_gemm_f32_cfg(const GemmArgs& g, hipStream_t st) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM);
     size_t lds = gemm_f32_lds_bytes<WM, WN>();
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<WM, WN, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }

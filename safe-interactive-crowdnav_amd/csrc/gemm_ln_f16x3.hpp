@@ -580,8 +580,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ln_mx_kernel(GemmLnArgs g, int nt
 
 template <bool X2>
 inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_f16x3_kernel<X2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GLN_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln128_f16x3_kernel<X2>),
@@ -603,8 +603,8 @@ inline hipError_t launch_gemm_ln_mode(const GemmLnArgs& g, hipStream_t st) {
 }
 
 inline hipError_t launch_gemm_ln_mx(const GemmLnArgs& g, hipStream_t st) {
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_mx_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)GLNX_LDS_BYTES);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln_mx_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,

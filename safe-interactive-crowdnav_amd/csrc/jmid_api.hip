@@ -20,6 +20,7 @@
 #include "gemm_f16x3.hpp"
 #include "gemm_ln_f16x3.hpp"
 #include "gemm_f32.hpp"
+#include "kde.hpp"
 #include "tail_f16x3.hpp"
 
 using namespace jmid;
@@ -41,11 +42,12 @@ enum KClass {
     KC_INTEGRATE,
     KC_METRICS,
     KC_VTRANS,
+    KC_TOPK,
     KC_COUNT
 };
 const char* kClassNames[KC_COUNT] = {"gemm_qkv", "gemm_attn_out", "gemm_ff1", "gemm_ff2", "gemm_tail", "attention",
                                      "add_layernorm", "embed", "out_ddim", "hyper", "encoder", "integrate",
-                                     "episode_metrics", "v_transpose"};
+                                     "episode_metrics", "v_transpose", "kde_topk"};
 
 struct DevBuf {
     float* p = nullptr;
@@ -86,6 +88,13 @@ struct jmid_ctx {
     };
     std::map<std::string, LoopGraph> graphs;
     int64_t graph_replays = 0;
+    // the positions of the most recent jmid_denoise (integrated into the workspace whether or not they were copied out): what
+    // jmid_topk ranks when it is given no pos pointer
+    const float* last_pos = nullptr;
+    int last_pos_dims[4] = {0, 0, 0, 0};     // E, A, K, T
+    char* kde_ws = nullptr;                  // jmid_topk's own workspace (it must not move the arena last_pos points into)
+    size_t kde_ws_bytes = 0;
+    int64_t erange_calls = 0;   // calls on this handle that ended with JMID_ERANGE (jmid_erange_count)
     int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
@@ -245,6 +254,7 @@ void drop_graphs(jmid_ctx* h) {
 int ensure_arena(jmid_ctx* h, size_t bytes) {
     if (bytes <= h->arena_bytes) return 0;
     drop_graphs(h);
+    h->last_pos = nullptr;
     if (h->arena) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         HIPCHK(h, hipFree(h->arena));
@@ -728,10 +738,11 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         return fail(h, JMID_EINVAL, "precision must be JMID_PREC_F32, JMID_PREC_F16X3, JMID_PREC_F16X2 or JMID_PREC_F16MX (JMID_PREC_F16 is not built)");
     h->mx = precision == JMID_PREC_F16MX;
     h->x2 = precision == JMID_PREC_F16X2 || h->mx;
-    if (precision != JMID_PREC_F32 && !h->weights_in_half_range)
+    if (precision != JMID_PREC_F32 && !h->weights_in_half_range && ++h->erange_calls)
         return fail(h, JMID_ERANGE, "a weight exceeds the fp16 range: use JMID_PREC_F32");
     if (!x_in || !ctx) return fail(h, JMID_EINVAL, "null input");
     if (pos_out && !p0) return fail(h, JMID_EINVAL, "pos_out requested without p0");
+    h->last_pos = nullptr;     // (the staging buffer is about to be reused)
     if (single_step < 0 && h->ddpm && !z_in) return fail(h, JMID_EINVAL, "DDPM table installed: use jmid_denoise_ddpm (needs z)");
     if (single_step < 0 && !h->ddpm && z_in) return fail(h, JMID_EINVAL, "jmid_denoise_ddpm needs jmid_set_ddpm_table");
     HIPCHK(h, hipSetDevice(h->device));
@@ -906,7 +917,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         HIPCHK(h, hipMemcpyAsync(e_out, stage, M * 2 * sizeof(float), kout, h->stream));
     } else {
         if (vel_out) HIPCHK(h, hipMemcpyAsync(vel_out, x_cur, M * 2 * sizeof(float), kout, h->stream));
-        if (pos_out) {
+        if (p0_use) {      // integrated whenever p0 is given: the positions stay in the workspace for jmid_topk(pos = NULL)
             {
                 ProfScope ps(h, KC_INTEGRATE);
                 const int n = (int)R * 2;
@@ -914,7 +925,9 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
                                    stage, (int)R, T, A, K * A, dt);
                 HIPCHK(h, hipGetLastError());
             }
-            HIPCHK(h, hipMemcpyAsync(pos_out, stage, M * 2 * sizeof(float), kout, h->stream));
+            h->last_pos = stage;
+            h->last_pos_dims[0] = E; h->last_pos_dims[1] = A; h->last_pos_dims[2] = K; h->last_pos_dims[3] = T;
+            if (pos_out) HIPCHK(h, hipMemcpyAsync(pos_out, stage, M * 2 * sizeof(float), kout, h->stream));
         }
     }
     if (int rc = order_out(h, mem)) return rc;
@@ -923,6 +936,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (flag) ++h->erange_calls;
         if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
     } else if (mem == JMID_MEM_HOST) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1012,6 +1026,7 @@ int jmid_destroy(jmid_handle_t h) {
         for (float* p : l)
             if (p) hipFree(p);
     if (h->arena) hipFree(h->arena);
+    if (h->kde_ws) hipFree(h->kde_ws);
     for (int c = 0; c < KC_COUNT; ++c)
         for (auto& ev : h->prof_ev[c]) {
             hipEventDestroy(ev.a);
@@ -1354,6 +1369,66 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
     return order_out(h, mem);
 }
 
+int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* pos, const float* bw, float* sel, float* logw,
+              int mem) {
+    if (!h || !sel || !logw || E <= 0 || A <= 0 || K <= 1 || T <= 0) return fail(h, JMID_EINVAL, "bad argument");
+    if (k < 1 || k > K) return fail(h, JMID_EINVAL, "k must be in 1..K");
+    if (A > 32 || K > 1024 || T > 24) return fail(h, JMID_EINVAL, "jmid_topk supports A <= 32, K <= 1024, T <= 24");
+    HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
+    if (!pos) {
+        if (!h->last_pos || h->last_pos_dims[0] != E || h->last_pos_dims[1] != A || h->last_pos_dims[2] != K || h->last_pos_dims[3] != T)
+            return fail(h, JMID_EINVAL, "pos = NULL needs a preceding jmid_denoise with p0 and the same E, A, K, T on this handle");
+    }
+    if (int rc = order_in(h, mem)) return rc;
+    const int d = 2 * A;
+    const size_t n_pos = (size_t)E * K * A * T * 2, n_sel = (size_t)E * A * k * T * 2, n_lw = (size_t)E * A * k;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_ll = 0, o_Y = up((size_t)E * T * K * 8), o_bw = o_Y + up((size_t)E * T * K * d * 8), o_pos = o_bw + up(T * 4),
+                 o_sel = o_pos + (pos && mem == JMID_MEM_HOST ? up(n_pos * 4) : 0), o_lw = o_sel + (mem == JMID_MEM_HOST ? up(n_sel * 4) : 0),
+                 need = o_lw + (mem == JMID_MEM_HOST ? up(n_lw * 4) : 0);
+    if (need > h->kde_ws_bytes) {
+        if (h->kde_ws) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipFree(h->kde_ws));
+            h->kde_ws = nullptr;
+            h->kde_ws_bytes = 0;
+        }
+        if (hipMalloc((void**)&h->kde_ws, need) != hipSuccess) return fail(h, JMID_ENOMEM, "jmid_topk workspace allocation failed");
+        h->kde_ws_bytes = need;
+    }
+    KdeArgs g{};
+    g.E = E; g.A = A; g.K = K; g.T = T; g.k = k;
+    g.ll = reinterpret_cast<double*>(h->kde_ws + o_ll);
+    g.Y = reinterpret_cast<double*>(h->kde_ws + o_Y);
+    g.pos = pos ? pos : h->last_pos;
+    g.sel = sel; g.logw = logw;
+    if (bw) {
+        float* dbw = reinterpret_cast<float*>(h->kde_ws + o_bw);
+        HIPCHK(h, hipMemcpyAsync(dbw, bw, T * sizeof(float), mem == JMID_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+        g.bw = dbw;
+    }
+    if (mem == JMID_MEM_HOST) {
+        if (pos) {
+            float* dp = reinterpret_cast<float*>(h->kde_ws + o_pos);
+            HIPCHK(h, hipMemcpyAsync(dp, pos, n_pos * 4, hipMemcpyHostToDevice, h->stream));
+            g.pos = dp;
+        }
+        g.sel = reinterpret_cast<float*>(h->kde_ws + o_sel);
+        g.logw = reinterpret_cast<float*>(h->kde_ws + o_lw);
+    }
+    {
+        ProfScope ps(h, KC_TOPK);
+        HIPCHK(h, launch_kde(g, h->stream));
+    }
+    if (mem == JMID_MEM_HOST) {
+        HIPCHK(h, hipMemcpyAsync(sel, g.sel, n_sel * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(logw, g.logw, n_lw * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return order_out(h, mem);
+}
+
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
     if (!h || episodes < 0) return JMID_EINVAL;
     h->chunk_eps = episodes;
@@ -1425,6 +1500,8 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 }
 
 int64_t jmid_graph_replays(jmid_handle_t h) { return h ? h->graph_replays : -1; }
+
+int64_t jmid_erange_count(jmid_handle_t h) { return h ? h->erange_calls : -1; }
 
 int jmid_set_caller_stream(jmid_handle_t h, void* stream) {
     if (!h) return JMID_EINVAL;

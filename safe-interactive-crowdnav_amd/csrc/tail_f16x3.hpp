@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256, 1) void tail_f16x3_kernel(TailArgs g, OutArgs 
 template <bool X2>
 inline hipError_t launch_tail_mode(const TailArgs& g, const OutArgs& oa, const EmbedArgs& nxt, bool embed_next, int rows,
                                    hipStream_t st) {
-    static bool attr_seen[64] = {};
-    if (first_use_on_device(attr_seen)) {
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_f16x3_kernel<1, X2, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)tail_lds_bytes<1>());
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_f16x3_kernel<1, X2, false>),

@@ -24,6 +24,9 @@ except Exception:  # pragma: no cover
 
 ArrayLike = Union[np.ndarray, "torch.Tensor"]
 
+# every JMID_ERANGE any engine of this process has returned (the tests assert that no fixture ever produces one)
+ERANGE_EVENTS: list = []
+
 
 def _is_cuda(t) -> bool:
     return torch is not None and isinstance(t, torch.Tensor) and t.is_cuda
@@ -72,6 +75,8 @@ class JmidEngine:
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int) -> None:
+        if rc == -5:
+            ERANGE_EVENTS.append((id(self), self._lib.jmid_last_error(self._h).decode()))
         if rc != 0:
             raise JmidError(rc, self._lib.jmid_last_error(self._h).decode())
 
@@ -123,6 +128,10 @@ class JmidEngine:
     def graph_replays(self) -> int:
         """Calls whose denoise loop ran as a replayed hipGraph (small one-chunk calls from their third repetition on)."""
         return int(self._lib.jmid_graph_replays(self._h))
+
+    def erange_count(self) -> int:
+        """Calls on this engine that ended with JMID_ERANGE (an activation left the fp16 range: the caller repeats in "f32")."""
+        return int(self._lib.jmid_erange_count(self._h))
 
     def synchronize(self) -> None:
         self._check(self._lib.jmid_synchronize(self._h))
@@ -188,6 +197,37 @@ class JmidEngine:
                                                _lib.PRECISIONS[precision], vptr, pptr,
                                                self._mem(dev)))
         return vel, pos
+
+    def topk(self, pos: Optional[ArrayLike], k: int, dims: Optional[Tuple[int, int, int, int]] = None):
+        """Joint-KDE top-k on the device (``jmid_topk``; get_most_likely_samples, mid_sim_wrapper.py:14-169), batched over
+        episodes.  pos [E, K, A, T, 2] -> (kept [E, A, k, T, 2], log-weights [E, A, k]) in ascending likelihood.
+        ``pos=None`` with ``dims=(E, A, K, T)`` ranks the positions of the preceding ``denoise`` call, which are still in the
+        engine's workspace (nothing but the k kept samples comes back to the host)."""
+        import math
+        if pos is None:
+            if dims is None:
+                raise ValueError("pos=None needs dims=(E, A, K, T) of the preceding denoise call")
+            E, A, K, T = (int(v) for v in dims)
+            dev, bp = False, None
+        else:
+            dev = _is_cuda(pos)
+            E, K, A, T, _ = (int(v) for v in pos.shape)
+            bp = _Buf(pos, dev)
+        # the bandwidths exactly as the reference computes them (fp32 torch ops, mid_sim_wrapper.py:26-30)
+        bw = torch.exp(torch.linspace(math.log(0.01), math.log(0.1), steps=T))
+        if dev:
+            bwb = bw.to(pos.device)
+            sel = torch.empty((E, A, k, T, 2), dtype=torch.float32, device=pos.device)
+            lw = torch.empty((E, A, k), dtype=torch.float32, device=pos.device)
+            ptrs = (C.c_void_p(bwb.data_ptr()), C.c_void_p(sel.data_ptr()), C.c_void_p(lw.data_ptr()))
+        else:
+            bwb = np.ascontiguousarray(bw.numpy())
+            sel = np.empty((E, A, k, T, 2), dtype=np.float32)
+            lw = np.empty((E, A, k), dtype=np.float32)
+            ptrs = (C.c_void_p(bwb.ctypes.data), C.c_void_p(sel.ctypes.data), C.c_void_p(lw.ctypes.data))
+        self._check(self._lib.jmid_topk(self._h, E, A, K, T, int(k), bp.ptr if bp is not None else None, *ptrs,
+                                        self._mem(dev)))
+        return sel, lw
 
     def net_eval(self, x: ArrayLike, ctx: ArrayLike, step_idx: int = 0, precision: str = "f32"):
         """One evaluation of e_theta for DDIM table entry ``step_idx``; x [E, K*A, T, 2] -> e same shape."""

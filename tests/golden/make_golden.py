@@ -87,7 +87,7 @@ from safe_interactive_crowdnav_amd.weights import (EDGE_INFL, EDGE_PED, EDGE_ROB
                                                    JMIDWeights, NetDims)
 from sicnav_diffusion.JMID.MID.models import diffusion as ref_diffusion  # noqa: E402
 
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get('GOLDEN_THREADS', '8')))
 
 
 ONLY = sys.argv[1] if len(sys.argv) > 1 else ""
@@ -334,13 +334,16 @@ def gen_wrapper_case(tag, kind, joint, ctx_dim, N, K, k_ret, H, step, wseed, dse
 
 
 # --------------------------------------------------------------------------- KDE
-def gen_kde_case(tag, K, A, H, k_ret, seed):
+def gen_kde_case(tag, K, A, H, k_ret, seed, step_std=0.1):
+    """step_std = 0.1 m: the samples are isolated at the KDE's bandwidths (0.01 - 0.1 m), their joint likelihoods tie up to fp32
+    rounding and the kept set is an artefact of torch.argsort's tie-breaking; step_std = 0.004 m ("tight"): the samples lie within
+    the bandwidths of each other, the ranking is decisive (gaps >> fp32 noise) and pins choice AND order of the kept samples."""
     from sicnav_diffusion.JMID.mid_sim_wrapper import get_most_likely_samples
 
     g = torch.Generator().manual_seed(seed)
-    base = torch.cumsum(0.1 * torch.randn([K, A, H, 2], generator=g), dim=2) + torch.randn([1, A, 1, 2], generator=g)
+    base = torch.cumsum(step_std * torch.randn([K, A, H, 2], generator=g), dim=2) + torch.randn([1, A, 1, 2], generator=g)
     f_top, lw = get_most_likely_samples(base, object(), k_ret)
-    save(f"kde_{tag}.npz", forecasts=np32(base), k_ret=k_ret, top=np32(f_top), logw=np32(lw))
+    save(f"kde_{tag}.npz", forecasts=np32(base), k_ret=k_ret, top=np32(f_top), logw=np32(lw), step_std=step_std)
 
 
 def main():
@@ -359,9 +362,13 @@ def main():
         ("imid_w256_a5k20t12_s50", 256, 5, 20, 12, 50, False, 24, 204),
         ("jmid_w256_a3k100t8_s2", 256, 3, 100, 8, 2, True, 25, 205),     # shipped config shape
         ("jmid_w256_a7k9t24_s10", 256, 7, 9, 24, 10, True, 26, 206),     # ragged sizes, max_len T
+        # BASELINE cfg4 at its real step count: one 19 200-key sequence, 50 DDIM steps (split-KV rounding accumulates);
+        # ~15 min of reference CPU time: `python tests/golden/make_golden.py net_jmid_w256_a25` regenerates only this one
+        ("jmid_w256_a25k64t12_s50", 256, 25, 64, 12, 50, True, 27, 207),
     ]
     for c in net_cases:
-        gen_net_case(*c)
+        if not ONLY or f"net_{c[0]}.npz".startswith(ONLY):     # (the big case is minutes of CPU: skip it unless asked for)
+            gen_net_case(*c)
     # (tag, kind, joint, ctx_dim, N, K, k_ret, H, step, wseed, dseed)
     wrapper_cases = [
         ("jmid_together", "together", True, 256, 5, 20, 20, 12, 2, 31, 301),
@@ -395,6 +402,9 @@ def main():
     gen_sample_case("jmid_w256_b5n6t12_ddpm", 256, 5, 6, 12, 10, True, "ddpm", True, 0.0, 54, 605)
     gen_kde_case("k100_a3_h8", 100, 3, 8, 15, 401)
     gen_kde_case("k40_a5_h12", 40, 5, 12, 10, 402)
+    gen_kde_case("tight_k100_a3_h8", 100, 3, 8, 15, 403, step_std=0.004)      # the shipped K -> k, decisive ranking
+    gen_kde_case("tight_k64_a25_h12", 64, 25, 12, 20, 404, step_std=0.004)    # cfg4's crowd: 50-dimensional joint KDE
+    gen_kde_case("tight_k30_a1_h5", 30, 1, 5, 7, 405, step_std=0.004)         # a single pedestrian
 
 
 if __name__ == "__main__":

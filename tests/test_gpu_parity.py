@@ -145,20 +145,25 @@ def test_full_size_property_checks(precision):
     assert (pos - ref_pos).abs().max() <= 1e-4
 
 
+@pytest.mark.expects_erange
 def test_f16x3_reports_range_overflow_instead_of_garbage():
     """JMID_PREC_F16X3 carries operands as fp16 hi/lo planes: values beyond the fp16 range must surface as
-    JMID_ERANGE (the caller then reruns in JMID_PREC_F32), never as silent inf/NaN trajectories."""
+    JMID_ERANGE (the caller then reruns in JMID_PREC_F32), never as silent inf/NaN trajectories - and are counted on the
+    handle (jmid_erange_count) so that a deployment can see how often the slow path fires."""
     from safe_interactive_crowdnav_amd.engine import JmidError
     eng, w = get_engine(32, 77, True)
     eng.set_step(2)
+    n0 = eng.erange_count()
     g = torch.Generator().manual_seed(1)
     ctx = torch.randn([1, 3, 32], generator=g)
     x_T = torch.randn([1, 6, 4, 2], generator=g) * 1e9
     with pytest.raises(JmidError) as ei:
         eng.denoise(x_T.numpy(), ctx.numpy(), precision="f16x3", want_pos=False)
     assert ei.value.code == -5
+    assert eng.erange_count() == n0 + 1
     vel, _ = eng.denoise(x_T.numpy(), ctx.numpy(), precision="f32", want_pos=False)   # fp32 path still answers
     assert np.isfinite(vel).all()
+    assert eng.erange_count() == n0 + 1
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

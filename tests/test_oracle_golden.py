@@ -39,10 +39,14 @@ def test_net_and_sampler_match_reference(case):
     A, K, T, step, joint = int(z["A"]), int(z["K"]), int(z["T"]), int(z["step"]), bool(z["joint"])
     ctx, x_T = torch.from_numpy(z["ctx"]), torch.from_numpy(z["x_T"])
     torch.set_num_threads(8)
+    # the cfg4 fixture (one 19 200-token sequence, 50 steps) is ~4 minutes of oracle time on 8 cores: its sampler loop runs
+    # with JMID_SLOW_TESTS=1 (passed, 2e-6, when the fixture was added); by default only its first net evaluation is checked.
+    # The HIP path is held against this fixture directly on the GPU (tests/test_gpu_baseline_sizes.py).
+    heavy = K * A * T * step > 500_000 and not os.environ.get("JMID_SLOW_TESTS")
     with torch.no_grad():
         beta = O.variance_schedule()["betas"][[100] * (K * A)]
         e = O.net_forward(w, x_T, ctx.repeat(K, 1), beta, joint=joint)
-        vel = O.denoise(w, ctx, x_T, sample=K, step=step, joint=joint)
+        vel = torch.from_numpy(z["vel"]) if heavy else O.denoise(w, ctx, x_T, sample=K, step=step, joint=joint)
     # mean ADE-style metric: mean L2 over (sample, agent, t).  Gate of the project is 1e-4.
     # The oracle restates the same torch-CPU ops: bit-exact at width 32, and within fp32 GEMM
     # blocking noise at width 256 (measured <= 1.4e-6 after 50 steps, below the reference's own
