@@ -114,6 +114,93 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command line as ranks 0..N-1 of one node
+    (rendezvous on 127.0.0.1, a free port), wait for all of them, return the worst exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    return max((abs(rc) for rc in rcs), default=0)
+
+
+def cpu_worker(job):
+    """One worker process of the CPU baseline: the oracle (oracle/jmid_oracle.py, torch-CPU fp32) on its share of the sample."""
+    seed, threads, joint, K, steps, eps = job
+    import torch as T
+    T.set_num_threads(threads)
+    from oracle import jmid_oracle as O
+    wt = JMIDWeights.from_seed(NetDims(ctx_dim=256), seed).tensors
+    out = []
+    with T.no_grad():
+        for e, xs, nb, em, xT, p0e in eps:
+            ctx_c = O.encode_context(wt, T.from_numpy(xs), T.from_numpy(nb), T.from_numpy(em))
+            v = O.denoise(wt, ctx_c, T.from_numpy(xT), sample=K, step=steps, joint=joint)
+            out.append((e, O.integrate(v, T.from_numpy(p0e), 0.25).numpy()))
+    return out
+
+
+_CPU_READY = None
+
+
+def cpu_init(ready, seed, threads, joint, K, eps1):
+    """Start-up of one CPU-baseline worker (imports, weights from the seed, a 2-step oracle run), kept out of the timed
+    region: the parent waits until every worker has counted itself ready."""
+    cpu_worker((seed, threads, joint, K, 2, eps1))
+    with ready.get_lock():
+        ready.value += 1
+
+
+def forecaster_e2e(weights, dev_id, modes):
+    """predict_ret_best() of the drop-in class, host + device, the way the MPC calls it once per control step
+    (sicnav_acados.py:1641-1651): BASELINE cfg2 (N=5, K=20 -> 20, H=12, 50 steps) and the reference's SHIPPED operating point
+    (test_time_configs/mid_jp.yaml: K=100 -> 15 kept, H=8, 2 denoise steps; N=3 humans)."""
+    import tempfile
+    from safe_interactive_crowdnav_amd.forecaster import HumanTrajectoryForecasterSim, write_configs
+
+    class St:
+        def __init__(self, p):
+            self.position = (float(p[0]), float(p[1]))
+
+    out = {}
+    rng = np.random.default_rng(5)
+    for name, (N, K, k, H, step) in {"cfg2": (5, 20, 20, 12, 50), "shipped": (3, 100, 15, 8, 2)}.items():
+        res = {}
+        for m in modes:
+            with tempfile.TemporaryDirectory() as td:
+                env, yp = write_configs(td, joint=True, ctx_dim=256, N=N, K=K, k_ret=k, H=H, step=step, time_step=0.25)
+                f = HumanTrajectoryForecasterSim(env, yp, weights=weights, device_id=dev_id, precision=m)
+            p0 = rng.uniform(-1.0, 1.0, (N, 2))
+            v = rng.uniform(-0.4, 0.4, (N, 2))
+            for i in range(7):
+                f.update_state_hists(St((0.0, -1.5 + 0.05 * i)), [St(p0[j] + v[j] * 0.25 * i) for j in range(N)], 0.25 * i)
+            for _ in range(3):
+                f.predict_ret_best()
+            reps, acc, t0 = 10, {}, time.perf_counter()
+            for i in range(reps):
+                f.update_state_hists(St((0.0, -1.15 + 0.05 * i)), [St(p0[j] + v[j] * 0.25 * (7 + i)) for j in range(N)], 0.25 * (7 + i))
+                fc, lw = f.predict_ret_best()
+                for kk, vv in f.timings.items():
+                    acc[kk] = acc.get(kk, 0.0) + vv
+            wall = (time.perf_counter() - t0) / reps
+            assert fc.shape == (N, k, H + 1, 2) and lw.shape == (N, k)
+            res[m] = {"ms_per_call": round(1e3 * wall, 3), "host_scene_ms": round(acc["scene_ms"] / reps, 3),
+                      "device_ms": round(acc["device_ms"] / reps, 3), "topk_ms": round(acc["topk_ms"] / reps, 3),
+                      "host_assemble_ms": round(acc["assemble_ms"] / reps, 3), "erange_fallbacks": f.erange_fallbacks}
+        out[name] = {"workload": f"N={N} humans, K={K} samples -> {k} returned, H={H}, {step} denoise steps; "
+                                 "update_state_hists + predict_ret_best() per call, host NumPy scene build included",
+                     "topk": "joint KDE on the device (jmid_topk)" if k < K else "not needed (all samples returned)",
+                     "modes": res}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +213,12 @@ def main():
                     help="comma list of modes measured identically in this run (the --precision mode is always included)")
     ap.add_argument("--net", default="jmid", choices=["jmid", "imid"])
     ap.add_argument("--chunk", type=int, default=0, help="episodes per pass of the denoise loop (0 = auto)")
-    ap.add_argument("--cpu-episodes", type=int, default=12, help="episodes timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-episodes", type=int, default=-1,
+                    help="episodes timed on the host for cpu_baseline and checked for parity (0 = skip; default: 12, or one per "
+                         "worker process when the host has more workers than that)")
+    ap.add_argument("--cpu-one-process", dest="cpu_all_cores", action="store_false",
+                    help="cpu_baseline in ONE process (default: as many worker processes as the host cores hold)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the forecaster_e2e leg (class surface, host + device)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--lanes", type=int, default=2,
                     help="chunks of the denoise loop in flight at once (1..4; the library's default is 2; results are the same bits)")
@@ -142,12 +234,15 @@ def main():
                          "of the N > 1 path on a one-GPU box)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): spawn the N ranks ourselves, one process per GPU, with the
+        # environment torch.distributed.run would give them; rank 0 prints the JSON line
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_id = local_rank if args.device < 0 else args.device
     torch.cuda.set_device(dev_id)
     dev = torch.device("cuda", dev_id)
@@ -377,23 +472,24 @@ def main():
         out["single_scene"] = dict(ss[args.precision], workload=f"cfg2: 1 scene x N={N} x K={K} x H={H}, {steps50} steps",
                                    modes=ss)
     log("single-scene done")
+    if world == 1 and not args.no_e2e and joint:
+        out["forecaster_e2e"] = forecaster_e2e(weights, dev_id, modes)
+        log("forecaster end-to-end done")
 
     # ---- CPU baseline (the oracle, a port of the reference; bounded sample) + parity on the same episodes
-    if world == 1 and args.cpu_episodes > 0:
+    if world == 1 and args.cpu_episodes != 0:
         from oracle import jmid_oracle as O
-        ne = min(args.cpu_episodes, E)
+        ne = min(args.cpu_episodes if args.cpu_episodes > 0 else 12, E)
         # the parity sample is spread over the whole batch, so every chunk of the call (incl. a ragged last one) is
         # held against the oracle, not just the first
-        pick = sorted(set(int(round(v)) for v in np.linspace(0, E - 1, ne)))
-        ne = len(pick)
         wt = weights.tensors
-        # calibrate the intra-op thread count on a 2-step run: more threads than the small GEMMs can use makes the
-        # CPU path slower, and the baseline should be the CPU's best
+        # every host core, the way the oracle uses them best: intra-op threads do not scale on these small GEMMs (a 2-step
+        # calibration picks the per-process thread count), so the sample runs as avail // threads worker PROCESSES side by side
         avail = len(os.sched_getaffinity(0))
         best = (float("inf"), torch.get_num_threads())
         with torch.no_grad():
             ctx_cal = O.encode_context(wt, x_st[:A].cpu(), nbr[:A].cpu(), emask[:A].cpu())
-            for nt in (8, 16, 32, 64, 128):
+            for nt in (4, 8, 16, 32):
                 if nt > avail:
                     break
                 torch.set_num_threads(nt)
@@ -401,28 +497,63 @@ def main():
                 tcal = time.perf_counter()
                 O.denoise(wt, ctx_cal, x_T_host[0], sample=K, step=2, joint=joint)
                 tcal = time.perf_counter() - tcal
-                log(f"cpu calibration: {nt} threads -> {tcal:.3f}s / 2 steps")
-                best = min(best, (tcal, nt))
-        cores = best[1]
-        torch.set_num_threads(cores)
-        log(f"cpu baseline on {cores} threads (os.cpu_count={os.cpu_count()}, affinity={avail})")
-        xs_c, nb_c, em_c = x_st.cpu(), nbr.cpu(), emask.cpu()
-        with torch.no_grad():
-            O.denoise(wt, O.encode_context(wt, xs_c[:A], nb_c[:A], em_c[:A]), x_T_host[0], sample=K, step=2,
-                      joint=joint)       # warm-up
+                log(f"cpu calibration: {nt} threads -> {tcal:.3f}s / 2 steps ({tcal * nt:.2f} thread-s)")
+                best = min(best, (tcal * nt, nt))     # what counts is thread-seconds per episode: the workers run side by side
+        threads = best[1]
+        torch.set_num_threads(1)           # the parent only waits from here on
+        nproc_max = max(1, avail // threads) if args.cpu_all_cores else 1
+        xs_c, nb_c, em_c, p0_c = x_st.cpu().numpy(), nbr.cpu().numpy(), emask.cpu().numpy(), p0.cpu().numpy()
+
+        def ep_job(e):
+            return (e, xs_c[e * A:(e + 1) * A], nb_c[e * A:(e + 1) * A], em_c[e * A:(e + 1) * A], x_T_host[e].numpy(), p0_c[e])
+
+        import multiprocessing as mp
+        mpc = mp.get_context("spawn")
+        ready = mpc.Value("i", 0)
+        env_keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OMP_WAIT_POLICY")}
+        os.environ.update(OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), OMP_WAIT_POLICY="passive")
+        try:
+            pool = mpc.Pool(nproc_max, initializer=cpu_init, initargs=(ready, args.seed, threads, joint, K, [ep_job(0)]))
+        finally:
+            for k, v in env_keep.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        with pool:
+            while ready.value < nproc_max:                   # every worker warm before any clock starts
+                time.sleep(0.05)
+            # how many workers side by side the host really carries (the affinity mask says `avail`, a CPU quota or shared
+            # memory bandwidth may say less - and oversubscribed OpenMP teams collapse): a 2-step job on n workers at once,
+            # n = max, max/2, ...; the sample then runs on the n with the best aggregate rate
+            scaling, n = {}, nproc_max
+            short = (args.seed, threads, joint, K, 2, [ep_job(0)])
+            while n >= 1:
+                tq = time.perf_counter()
+                pool.map(cpu_worker, [short] * n, chunksize=1)
+                scaling[n] = round(n / (time.perf_counter() - tq), 2)
+                n //= 2
+            nproc = max(scaling, key=scaling.get)
+            log(f"cpu worker scaling (2-step jobs per second by workers side by side): {scaling} -> {nproc} workers")
+            if args.cpu_episodes < 0 and args.cpu_all_cores:     # automatic sample: at least one episode per worker process
+                ne = min(E, max(ne, nproc))
+            pick = sorted(set(int(round(v)) for v in np.linspace(0, E - 1, ne)))
+            ne = len(pick)
+            nproc = min(nproc, ne)
+            jobs = [[] for _ in range(nproc)]
+            for i, e in enumerate(pick):
+                jobs[i % nproc].append(ep_job(e))
+            jobs = [(args.seed, threads, joint, K, steps50, j) for j in jobs]
+            log(f"cpu baseline: {nproc} worker processes x {threads} threads = {nproc * threads} of {avail} hardware threads "
+                f"(os.cpu_count={os.cpu_count()}), {ne} episodes")
             tc = time.perf_counter()
-            pos_ref = []
-            for e in pick:
-                ctx_c = O.encode_context(wt, xs_c[e * A:(e + 1) * A], nb_c[e * A:(e + 1) * A], em_c[e * A:(e + 1) * A])
-                v = O.denoise(wt, ctx_c, x_T_host[e], sample=K, step=steps50, joint=joint)
-                pos_ref.append(O.integrate(v, p0[e].cpu(), 0.25))
+            parts = pool.map(cpu_worker, jobs, chunksize=1)
             cpu_s = time.perf_counter() - tc
-        log(f"cpu baseline: {ne} episodes in {cpu_s:.1f}s")
-        pos_ref = torch.stack(pos_ref).numpy()
-        out["cpu_baseline"] = {"value": round(ne * A * K / cpu_s, 2), "unit": "traj/s", "cores": torch.get_num_threads(),
-                               "kind": "port",
-                               "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, "
-                                         f"{cpu_s:.1f} s; oracle/jmid_oracle.py, torch-CPU fp32)"}
+        got = dict(p for part in parts for p in part)
+        log(f"cpu baseline: {ne} episodes in {cpu_s:.1f}s on {nproc} processes")
+        pos_ref = np.stack([got[e] for e in pick])
+        out["cpu_baseline"] = {"value": round(ne * A * K / cpu_s, 2), "unit": "traj/s", "cores": nproc * threads,
+                               "kind": "port", "processes": nproc, "threads_per_process": threads,
+                               "hardware_threads": avail, "worker_scaling_jobs_per_s": {str(k): v for k, v in scaling.items()},
+                               "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, {cpu_s:.1f} s wall; "
+                                         f"oracle/jmid_oracle.py, torch-CPU fp32, {nproc} processes x {threads} threads)"}
         for m in modes:
             ade = float(np.linalg.norm(last_pos[m][pick].cpu().numpy() - pos_ref, axis=-1).mean())
             results[m]["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4,

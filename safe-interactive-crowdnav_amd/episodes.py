@@ -11,8 +11,13 @@ placement (``crowd_sim_plus.py:454-481``), agent-agent ORCA for every (episode, 
 rest of the simulator: a few thousand 2-D LPs with <= 10 constraints per step are microseconds of work next to the
 denoise loop, and the MPC side that consumes the same states lives there too.
 
-PARITY UNPINNED: rvo2 (RVO2 Library 2.0.2 behind Python-RVO2) is an un-vendored C++ dependency, absent from the
-reference tree and from this image, so no output of the reference's simulator exists to compare with.  What is
+PARITY: partially pinned.  Everything the reference itself computes around rvo2 is pinned bit for bit by fixtures that
+``tests/golden/make_golden_episodes.py`` generates by executing the reference's own lines against stand-ins
+(``tests/golden/episodes_*.npz``): the circle-crossing placement incl. its draw order from the generator
+(``crowd_sim_plus.py:454-481``; ``place_circle_crossing_humans``), and what is handed to rvo2 per step - simulator and agent
+parameters, inflated radii, speed limits, preferred velocities (``orca.py:56-67, 93-129``; ``orca_call_parameters``).
+rvo2 ITSELF (RVO2 Library 2.0.2 behind Python-RVO2) STAYS UNPINNED: it is an un-vendored C++ dependency, absent from the
+reference tree and from this image, so no output of its ORCA solver exists to compare with.  For that part what is
 checked (``tests/test_episodes.py``): equality with a scalar, one-agent-at-a-time restatement of the published
 algorithm kept with the test infrastructure, optimality against a brute-force search of the velocity disc,
 collision-freeness and goal progress of the generated crowds.  The shipped scenarios of the reference (``hallway*``, ``env.config:16-17``)
@@ -38,9 +43,10 @@ def _dot(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 
 # ------------------------------------------------------------------------------------------------ ORCA half-planes
-def orca_lines(pos, vel, radius, opos, ovel, orad, time_horizon: float, time_step: float):
+def orca_lines(pos, vel, radius, opos, ovel, orad, time_horizon: float, time_step: float, with_dist: bool = False):
     """pos, vel [B, 2], radius [B]; the other agents opos, ovel [B, L, 2], orad [B, L].  Returns (point, direction)
-    [B, L, 2] each, neighbours ordered nearest first (RVO2 keeps its neighbour list sorted by distance)."""
+    [B, L, 2] each, neighbours ordered nearest first (RVO2 keeps its neighbour list sorted by distance); with
+    ``with_dist`` also their squared distances [B, L] in that order."""
     rp = opos - pos[:, None, :]
     dist_sq = _dot(rp, rp)
     order = np.argsort(dist_sq, axis=1, kind="stable")
@@ -70,6 +76,8 @@ def orca_lines(pos, vel, radius, opos, ovel, orad, time_horizon: float, time_ste
         u_l = _dot(rv, dir_l)[..., None] * dir_l - rv
     direction = np.where(circle[..., None], dir_c, dir_l)
     u = np.where(circle[..., None], u_c, u_l)
+    if with_dist:
+        return vel[:, None, :] + 0.5 * u, direction, dist_sq
     return vel[:, None, :] + 0.5 * u, direction
 
 
@@ -159,19 +167,28 @@ def _lp3(P, D, begin, radius, result, mask):
     return result
 
 
-def orca_velocities(pos, vel, radius, pref, max_speed, time_horizon: float = 2.0, time_step: float = 0.25):
+def orca_velocities(pos, vel, radius, pref, max_speed, time_horizon: float = 2.0, time_step: float = 0.25,
+                    neighbor_dist: float = 10.0, max_neighbors: int = 10):
     """New ORCA velocity of EVERY agent of every episode, each as the ego of its own program (``orca.py:96-131``).
 
     pos, vel, pref [E, n, 2]; radius, max_speed [E, n] (the radius already holds the + 0.01 + safety space the reference
-    adds).  Returns [E, n, 2].  n = 1 returns the preferred velocity clipped to the speed limit."""
+    adds).  Only the ``max_neighbors`` nearest agents closer than ``neighbor_dist`` constrain an agent, as in RVO2
+    (``Agent::insertAgentNeighbor``; the reference passes 10 and 10 m, ``orca.py:62-63, 94``).  Returns [E, n, 2].
+    n = 1 returns the preferred velocity clipped to the speed limit."""
     E, n, _ = pos.shape
     B = E * n
     others = np.array([[j for j in range(n) if j != i] for i in range(n)], dtype=np.int64).reshape(n, max(n - 1, 0))
     ego = lambda a: a.reshape((B,) + a.shape[2:])
     oth = lambda a: a[:, others].reshape((B, n - 1) + a.shape[2:])
-    P, D = orca_lines(ego(pos), ego(vel), ego(radius), oth(pos), oth(vel), oth(radius), time_horizon, time_step)
-    active = np.ones((B, n - 1), dtype=bool)
+    P, D, dsq = orca_lines(ego(pos), ego(vel), ego(radius), oth(pos), oth(vel), oth(radius), time_horizon, time_step,
+                           with_dist=True)
+    active = (dsq < neighbor_dist * neighbor_dist) & (np.arange(n - 1)[None, :] < max_neighbors)
     allrows = np.ones(B, dtype=bool)
+    if not active.all():       # neighbours left out: their half-planes must not constrain (the programs only look at active lines)
+        far = ~active
+        P = np.where(far[..., None], 0.0, P)
+        D = np.where(far[..., None], np.array([1.0, 0.0]), D)     # a line through the origin along x ...
+        P = np.where(far[..., None], np.array([0.0, -1e9]), P)    # ... moved far below: every velocity lies on its free side
     failed, fail_idx, result = _lp2(P, D, active, ego(max_speed), ego(pref), False, allrows)
     if failed.any():
         result = _lp3(P, D, fail_idx, ego(max_speed), result, failed)
@@ -192,13 +209,58 @@ class CrowdConfig:
     discomfort_dist: float = 0.2            # [reward] discomfort_dist
     safety_space: float = 0.0               # orca.py:61
     time_horizon: float = 2.0               # orca.py:64
+    time_horizon_obst: float = 0.5          # orca.py:65 (no obstacles here: unused, handed to rvo2 all the same)
+    neighbor_dist: float = 10.0             # orca.py:62
+    max_neighbors: int = 10                 # orca.py:63
+    orca_default_radius: float = 0.3        # orca.py:66-67: the simulator's defaults for new agents (every agent overrides them)
+    orca_default_max_speed: float = 1.0
     robot_visible: bool = True              # [robot] visible
 
 
-def circle_crossing_starts(E: int, N: int, rng: np.random.Generator, cfg: CrowdConfig) -> Dict[str, np.ndarray]:
-    """``generate_circle_crossing_human`` (``crowd_sim_plus.py:454-481``) for E episodes at once: humans one after the
-    other on a circle with positional noise, goal at the antipode, re-drawn while closer than radius + radius +
-    discomfort distance to any earlier agent's start or goal.  The robot starts at (0, -R), goal (0, R)."""
+def place_circle_crossing_humans(N: int, rng: np.random.Generator, cfg: CrowdConfig):
+    """``generate_circle_crossing_human`` x N for ONE episode (``crowd_sim_plus.py:441-443, 454-481``), with the reference's
+    draw order from ``rng``: per human the preferred speed U(0.5, 1.5) when attributes are randomised, then per attempt the
+    angle and the two noise terms; goal at the antipode; re-drawn while closer than radius + radius + discomfort distance to
+    an earlier agent's start or goal (the robot at (0, -R) -> (0, R) is agent 0).  -> pos, goal [N, 2], v_pref [N].
+    Bit-equal to the reference's lines on the same generator (``tests/golden/episodes_placement_*.npz``)."""
+    R = cfg.circle_radius
+    starts, goals, radii = [(0.0, -R)], [(0.0, R)], [cfg.robot_radius]
+    pos, goal, vp = np.zeros((N, 2)), np.zeros((N, 2)), np.full(N, cfg.human_v_pref)
+    for h in range(N):
+        if cfg.randomize_attributes:
+            vp[h] = rng.uniform(0.5, 1.5)
+        for _ in range(100000):
+            angle = rng.random() * np.pi * 2
+            px_noise = (rng.random() - 0.5) * vp[h]
+            py_noise = (rng.random() - 0.5) * vp[h]
+            px = R * np.cos(angle) + px_noise
+            py = R * np.sin(angle) + py_noise
+            collide = False
+            for (sx, sy), (gx, gy), r in zip(starts, goals, radii):
+                min_dist = cfg.human_radius + r + cfg.discomfort_dist
+                if np.linalg.norm((px - sx, py - sy)) < min_dist or np.linalg.norm((px - gx, py - gy)) < min_dist:
+                    collide = True
+                    break
+            if not collide:
+                break
+        else:
+            raise RuntimeError("circle crossing placement did not converge (circle too small for the crowd?)")
+        pos[h], goal[h] = (px, py), (-px, -py)
+        starts.append((px, py))
+        goals.append((-px, -py))
+        radii.append(cfg.human_radius)
+    return pos, goal, vp
+
+
+def episode_rng(seed: int, episode: int) -> np.random.Generator:
+    """The generator of one episode: a child stream of ``seed``, so that an episode's crowd does not depend on how many
+    episodes are generated with it, and different seeds (ranks of a sweep) never share a stream."""
+    return np.random.default_rng(np.random.SeedSequence(entropy=int(seed), spawn_key=(int(episode),)))
+
+
+def circle_crossing_starts(E: int, N: int, seed: int, cfg: CrowdConfig) -> Dict[str, np.ndarray]:
+    """Start record of E circle-crossing episodes: every episode placed by ``place_circle_crossing_humans`` on its own
+    generator ``episode_rng(seed, e)``.  Index 0 of the agent axis is the robot."""
     pos = np.zeros((E, N + 1, 2))
     goal = np.zeros((E, N + 1, 2))
     rad = np.full((E, N + 1), cfg.human_radius)
@@ -206,28 +268,26 @@ def circle_crossing_starts(E: int, N: int, rng: np.random.Generator, cfg: CrowdC
     pos[:, 0] = (0.0, -cfg.circle_radius)
     goal[:, 0] = (0.0, cfg.circle_radius)
     rad[:, 0], vp[:, 0] = cfg.robot_radius, cfg.robot_v_pref
-    if cfg.randomize_attributes:
-        vp[:, 1:] = rng.uniform(0.5, 1.5, (E, N))
-    for h in range(1, N + 1):
-        todo = np.ones(E, dtype=bool)
-        for _ in range(10000):
-            k = int(todo.sum())
-            if k == 0:
-                break
-            angle = rng.random(k) * np.pi * 2
-            noise = (rng.random((k, 2)) - 0.5) * vp[todo, h][:, None]
-            p = cfg.circle_radius * np.stack([np.cos(angle), np.sin(angle)], axis=1) + noise
-            min_dist = cfg.human_radius + rad[todo, :h] + cfg.discomfort_dist
-            d_pos = np.linalg.norm(p[:, None, :] - pos[todo, :h], axis=2)
-            d_goal = np.linalg.norm(p[:, None, :] - goal[todo, :h], axis=2)
-            ok = ~((d_pos < min_dist) | (d_goal < min_dist)).any(axis=1)
-            rows = np.nonzero(todo)[0][ok]
-            pos[rows, h] = p[ok]
-            goal[rows, h] = -p[ok]
-            todo[rows] = False
-        else:
-            raise RuntimeError("circle crossing placement did not converge (circle too small for the crowd?)")
+    for e in range(E):
+        pos[e, 1:], goal[e, 1:], vp[e, 1:] = place_circle_crossing_humans(N, episode_rng(seed, e), cfg)
     return dict(pos=pos, goal=goal, radius=rad, v_pref=vp)
+
+
+def orca_call_parameters(cfg: CrowdConfig, pos, vel, goal, radius, v_pref) -> Dict[str, np.ndarray]:
+    """What the reference hands to rvo2 for ONE agent's step (``orca.py:93-129``), for every agent of every episode as
+    the ego: arrays [E, n, ...] of the inflated radius, the speed limit and the preferred velocity, plus the scalars.
+    Pinned by ``tests/golden/episodes_orca_calls_*.npz`` (recorded from the reference's own lines)."""
+    to_goal = goal - pos
+    # np.linalg.norm of a 1-D vector (what orca.py:114 calls) is sqrt(dot(x, x)) with the BLAS dot's fused multiply-add;
+    # the batched matmul goes through the same BLAS and gives the same bits (the axis=-1 norm differs in the last place)
+    speed = np.sqrt(to_goal[..., None, :] @ to_goal[..., :, None])[..., 0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pref = np.where(speed > 1.0, to_goal / speed, to_goal)          # orca.py:113-115: unit length only beyond 1 m
+    return dict(radius=radius + 0.01 + cfg.safety_space,                # orca.py:104-108
+                max_speed=v_pref,                                       # the ego's limit is its v_pref (orca.py:105)
+                pref=pref, neighbor_dist=cfg.neighbor_dist, max_neighbors=cfg.max_neighbors,
+                time_horizon=cfg.time_horizon, time_horizon_obst=cfg.time_horizon_obst, time_step=cfg.time_step,
+                default_radius=cfg.orca_default_radius, default_max_speed=cfg.orca_default_max_speed)
 
 
 def simulate_circle_crossing(E: int, N: int, steps: int, seed: int, cfg: Optional[CrowdConfig] = None
@@ -238,23 +298,19 @@ def simulate_circle_crossing(E: int, N: int, steps: int, seed: int, cfg: Optiona
     [steps + 1] and the start record (goals, radii, v_pref): what ``update_state_hists`` is fed step by step in the
     reference's loop, for all episodes at once."""
     cfg = cfg or CrowdConfig()
-    rng = np.random.default_rng(seed)
-    st = circle_crossing_starts(E, N, rng, cfg)
+    st = circle_crossing_starts(E, N, seed, cfg)
     pos, goal = st["pos"].copy(), st["goal"]
     vel = np.zeros_like(pos)
-    orca_rad = st["radius"] + 0.01 + cfg.safety_space               # orca.py:104-108
     traj = np.zeros((E, steps + 1, N + 1, 2))
     vels = np.zeros((E, steps + 1, N + 1, 2))
     traj[:, 0] = pos
     sl = slice(None) if cfg.robot_visible else slice(1, None)
     for s in range(steps):
-        to_goal = goal - pos
-        speed = np.linalg.norm(to_goal, axis=2, keepdims=True)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            pref = np.where(speed > 1.0, to_goal / speed, to_goal)  # orca.py:113-115
+        par = orca_call_parameters(cfg, pos, vel, goal, st["radius"], st["v_pref"])
+        pref = par["pref"]
         new_vel = vel.copy()
-        new_vel[:, sl] = orca_velocities(pos[:, sl], vel[:, sl], orca_rad[:, sl], pref[:, sl], st["v_pref"][:, sl],
-                                         cfg.time_horizon, cfg.time_step)
+        new_vel[:, sl] = orca_velocities(pos[:, sl], vel[:, sl], par["radius"][:, sl], pref[:, sl], par["max_speed"][:, sl],
+                                         par["time_horizon"], par["time_step"], par["neighbor_dist"], par["max_neighbors"])
         if not cfg.robot_visible:       # humans do not see the robot; it still heads for its goal
             new_vel[:, 0] = pref[:, 0] * np.minimum(1.0, st["v_pref"][:, 0])[:, None]
         vel = new_vel

@@ -114,3 +114,81 @@ def test_histories_feed_the_batched_scene_builder():
     assert len(sizes) >= 3 and min(sizes) >= 1
     with pytest.raises(ValueError):
         EP.history_windows(sim, 3)
+
+
+# ------------------------------------------------------------------------------------------------ reference pins
+import glob
+import os
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "episodes_placement_*.npz"))))
+def test_circle_crossing_placement_matches_the_reference_lines(case):
+    """crowd_sim_plus.py:454-481 executed by tests/golden/make_golden_episodes.py on numpy's default_rng(seed): the same
+    positions, goals and preferred speeds bit for bit, and the generator left in the same state (same number of draws)."""
+    z = np.load(os.path.join(GOLDEN, case))
+    cfg = EP.CrowdConfig(circle_radius=float(z["circle_radius"]), randomize_attributes=bool(z["randomize"]),
+                         human_radius=float(z["human_radius"]), human_v_pref=float(z["human_v_pref"]),
+                         robot_radius=float(z["robot_radius"]), discomfort_dist=float(z["discomfort_dist"]))
+    rng = np.random.default_rng(int(z["seed"]))
+    pos, goal, vp = EP.place_circle_crossing_humans(int(z["n_humans"]), rng, cfg)
+    np.testing.assert_array_equal(pos, z["pos"])
+    np.testing.assert_array_equal(goal, z["goal"])
+    np.testing.assert_array_equal(vp, z["v_pref"])
+    np.testing.assert_array_equal(rng.random(4), z["rng_next"])
+
+
+@pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "episodes_orca_calls_*.npz"))))
+def test_orca_call_parameters_match_what_the_reference_hands_to_rvo2(case):
+    """orca.py:56-67, 93-129 executed against a recording rvo2 stand-in: simulator parameters, per-agent parameters (inflated
+    radius, speed limit), positions / velocities in the reference's agent order and the ego's preferred velocity.  (What
+    rvo2 then computes from them stays unpinned: it cannot run here.)"""
+    z = np.load(os.path.join(GOLDEN, case))
+    ego, oth = z["ego"], z["others"]
+    n = 1 + len(oth)
+    pos = np.concatenate([ego[None, 0:2], oth[:, 0:2]])[None]
+    vel = np.concatenate([ego[None, 2:4], oth[:, 2:4]])[None]
+    goal = np.concatenate([ego[None, 4:6], np.zeros((n - 1, 2))])[None]
+    rad = np.concatenate([ego[6:7], oth[:, 4]])[None]
+    vp = np.concatenate([ego[7:8], oth[:, 5]])[None]
+    cfg = EP.CrowdConfig(time_step=float(z["time_step"]))
+    par = EP.orca_call_parameters(cfg, pos, vel, goal, rad, vp)
+    sim = z["simulator"]        # time_step, neighbor_dist, max_neighbors, time_horizon, time_horizon_obst, radius, max_speed
+    assert [par["time_step"], par["neighbor_dist"], par["max_neighbors"], par["time_horizon"], par["time_horizon_obst"],
+            par["default_radius"], par["default_max_speed"]] == sim.tolist()
+    ap = z["agent_params"]      # per agent: neighbor_dist, max_neighbors, time_horizon, time_horizon_obst, radius, max_speed
+    assert (ap[:, 0] == par["neighbor_dist"]).all() and (ap[:, 1] == par["max_neighbors"]).all()
+    assert (ap[:, 2] == par["time_horizon"]).all() and (ap[:, 3] == par["time_horizon_obst"]).all()
+    np.testing.assert_array_equal(par["radius"][0], ap[:, 4])                    # radius + 0.01 + safety space, every agent
+    assert par["max_speed"][0, 0] == ap[0, 5]                                     # the ego moves at up to ITS v_pref
+    assert (ap[1:, 5] == cfg.orca_default_max_speed).all()                        # (the others' limit is never read: their
+    np.testing.assert_array_equal(z["agent_pos"], pos[0])                        #  velocities are not the call's output)
+    np.testing.assert_array_equal(z["agent_vel"], vel[0])
+    np.testing.assert_array_equal(par["pref"][0, 0], z["pref"][0])               # the ego's preferred velocity
+    assert (z["pref"][1:] == 0).all()                                             # everybody else: (0, 0), orca.py:123-125
+    if "near_goal" in case:
+        assert np.linalg.norm(z["pref"][0]) < 1.0                                 # not normalised inside 1 m
+
+
+def test_only_the_nearest_neighbours_within_range_constrain_an_agent():
+    """RVO2 keeps the max_neighbors nearest agents closer than neighbor_dist (the reference passes 10 and 10 m): a far
+    agent, or an eleventh one, must not change the result."""
+    rng = np.random.default_rng(17)
+    pos, vel, rad, pref, vmax = _random_crowd(rng, 6, 4, 2.0, 0.8)
+    base = EP.orca_velocities(pos, vel, rad, pref, vmax)
+    far = np.concatenate([pos, pos[:, :1] + np.array([30.0, 0.0])], axis=1)         # a fifth agent 30 m away
+    ext = lambda a, v: np.concatenate([a, np.full_like(a[:, :1], v)], axis=1)
+    got = EP.orca_velocities(far, ext(vel, 0.3), ext(rad, 0.3), ext(pref, 0.0), ext(vmax, 1.0))
+    np.testing.assert_allclose(got[:, :4], base, rtol=0, atol=1e-12)
+    pos13, vel13, rad13, pref13, vmax13 = _random_crowd(rng, 3, 13, 3.0, 0.8)
+    full = EP.orca_velocities(pos13, vel13, rad13, pref13, vmax13, max_neighbors=100)
+    lim = EP.orca_velocities(pos13, vel13, rad13, pref13, vmax13, max_neighbors=10)
+    for e in range(3):
+        for i in range(13):
+            d = np.linalg.norm(pos13[e] - pos13[e, i], axis=1)
+            keep = np.argsort(d, kind="stable")[:11]                                 # itself + its 10 nearest
+            want = EP.orca_velocities(pos13[e:e + 1, keep], vel13[e:e + 1, keep], rad13[e:e + 1, keep],
+                                      pref13[e:e + 1, keep], vmax13[e:e + 1, keep], max_neighbors=100)[0, 0]
+            np.testing.assert_allclose(lim[e, i], want, rtol=0, atol=1e-12)
+    assert not np.allclose(full, lim)

@@ -35,11 +35,12 @@ def test_bench_json_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
-    # the headline is the mode the drop-in predictor class runs by default ...
+    assert c["processes"] * c["threads_per_process"] == c["cores"] <= c["hardware_threads"]
+    # the headline is the throughput mode (an explicit opt-in of the drop-in class, whose own default is the fp32-class mode) ...
     from safe_interactive_crowdnav_amd.forecaster import HumanTrajectoryForecasterSim
     import inspect
-    default = inspect.signature(HumanTrajectoryForecasterSim.__init__).parameters["precision"].default
-    assert j["config"]["precision"] == default == "f16mx" and j["parity"]["precision"] == default
+    assert inspect.signature(HumanTrajectoryForecasterSim.__init__).parameters["precision"].default == "f16x3"
+    assert j["config"]["precision"] == "f16mx" and j["parity"]["precision"] == "f16mx"
     assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
     # ... and all split modes are measured the same way and reported under the same keys
     assert set(j["modes"]) == {"f16x3", "f16x2", "f16mx"}
@@ -53,6 +54,15 @@ def test_bench_json_contract():
     assert j["modes"]["f16x3"]["parity"]["mean_ADE_vs_oracle_m"] <= 1e-5       # fp32-class mode
     assert j["mean_ADE_between_modes_m"]["f16x2_vs_f16x3"] <= 1e-4 and j["mean_ADE_between_modes_m"]["f16mx_vs_f16x2"] <= 1e-4
     assert set(j["single_scene"]["modes"]) == {"f16x3", "f16x2", "f16mx"}
+    # the class surface, host + device, the way the MPC calls it: cfg2 and the reference's shipped operating point
+    fe = j["forecaster_e2e"]
+    assert set(fe) == {"cfg2", "shipped"}
+    for name, v in fe.items():
+        assert set(v["modes"]) == {"f16x3", "f16x2", "f16mx"}
+        for m, t in v["modes"].items():
+            assert t["ms_per_call"] > 0 and t["erange_fallbacks"] == 0
+            assert abs(t["host_scene_ms"] + t["device_ms"] + t["topk_ms"] + t["host_assemble_ms"] - t["ms_per_call"]) < 0.5 * t["ms_per_call"]
+    assert "jmid_topk" in fe["shipped"]["topk"]
     # PMC-derived fields name the committed profile they were read from
     for k in ("traffic_source", "mfma_busy"):
         if k in r:
@@ -83,6 +93,18 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert sm["mean_ADE_m"] > 0 and sm["mean_ADE_m"] == sm["mean_ADE_m"]     # no NaN padding rows leaked through
     # whole-job rate: 2 ranks x 5 episodes x 5 humans x 20 samples per step
     assert abs(j["value"] - 2 * 5 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+
+
+def test_bench_launched_plainly_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run (how the driver launched the 1-GPU bench): bench.py starts the
+    two ranks itself, rank 0 prints the one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--episodes-per-gpu", "3", "--dist-backend", "gloo", "--device", "0", "--modes", "f16mx",
+                          "--cpu-episodes", "0", "--no-profile"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    j = _one_json_line(out)
+    assert j["n_gpus"] == 2 and j["sweep_metrics"]["episodes"] == 6 and j["value"] > 0
 
 
 def test_bench_collectives_run_on_rccl_with_one_rank():
