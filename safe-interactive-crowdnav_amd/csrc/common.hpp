@@ -90,6 +90,7 @@ struct Tuning {
     int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
     int out_traj = 0;        // output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories, 1 = always, 2 = one wave per token
     int attn_mx = 0;         // head_dim 128: F16MX 0 = bf8 logit corrections + one fp16 plane of P, 1 = P_hi + P_lo (F16X2 too), 2 = F16X2's attention, 3 = as 0 with Q_lo as an fp16 plane (A/B; same bits)
+    int mx_ln = 0;           // F16MX at d_model 512: 0 = second-generation GEMM + LayerNorm (gemm_ln2_mx.hpp: byte lo plane of the residual stream, two workgroups per CU), 2 = the first generation
     int attn_pf = 0;         // F16MX / F16X2 attention with one plane of P: 2 = fragment reads one step ahead instead of three (A/B; same bits)
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS
     int gemm_abl = 0;

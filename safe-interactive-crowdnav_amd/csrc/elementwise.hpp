@@ -22,6 +22,7 @@ struct EmbedArgs {
     RowMap rmap;
     half_t* Xh;          // optional hi/lo planes of X (blocked panel layout) for the split-fp16 GEMMs
     half_t* Xl;
+    unsigned char* Xl8;  // JMID_PREC_F16MX at d_model 512: the lo plane as bf8 bytes (gemm_ln2_mx.hpp::blk8_index) instead of Xl
 };
 
 // channels j..j+3 of token m (row t of the positional table): ConcatSquash(2 -> d) + PE, stored as fp32 and / or planes.
@@ -59,7 +60,13 @@ __device__ __forceinline__ void embed_store_cols(const EmbedArgs& a, int m, int 
         }
         const size_t ob = blk_index(m, j, a.d);
         *reinterpret_cast<f16x4*>(a.Xh + ob) = vh;
-        *reinterpret_cast<f16x4*>(a.Xl + ob) = vl;
+        if (a.Xl8) {
+            const i32x2_e dl = __builtin_bit_cast(i32x2_e, vl);
+            *reinterpret_cast<int*>(a.Xl8 + ((((size_t)(m >> 7) * (a.d >> 5) + (j >> 5)) * 128 + (m & 127)) * 32 + (j & 31))) =
+                bf8_of_f16x4(dl[0], dl[1]);
+        } else {
+            *reinterpret_cast<f16x4*>(a.Xl + ob) = vl;
+        }
     }
 }
 __device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, int t, float x0, float x1, const float* hrow) {

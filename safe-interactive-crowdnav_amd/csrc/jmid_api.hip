@@ -19,6 +19,7 @@
 #include "encoder.hpp"
 #include "gemm_f16x3.hpp"
 #include "gemm_ln_f16x3.hpp"
+#include "gemm_ln2_mx.hpp"
 #include "gemm_f32.hpp"
 #include "kde.hpp"
 #include "tail_f16x3.hpp"
@@ -337,8 +338,14 @@ int make_w8(jmid_ctx* h, const float* dW, int N, int K, jmid_ctx::W8Image* out) 
 }
 
 int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const float* bt, int M, int d,
-               half_t* Xh = nullptr, half_t* Xl = nullptr) {
+               half_t* Xh = nullptr, half_t* Xl = nullptr, bool mxv2 = false, int no_lo_out = 0) {
     ProfScope ps(h, KC_ADD_LN);
+    if (mxv2) {      // gemm_ln2_mx.hpp: byte lo plane, that file's summation order (d == 512); 8 rows per wave
+        hipLaunchKernelGGL(add_ln2_kernel, dim3((M + 31) / 32), dim3(256), bystander_lds(add_ln2_kernel), h->stream, Y, gm, bt, M, 1e-5f,
+                           Xh, reinterpret_cast<unsigned char*>(Xl), no_lo_out, h->range_flag);
+        HIPCHK(h, hipGetLastError());
+        return 0;
+    }
     const int rows_per_block = 4;
     dim3 grid((M + rows_per_block - 1) / rows_per_block);
     const int vpl = (d + 255) / 256;
@@ -437,16 +444,18 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
     RowMap rm{T, A, K * A};
+    // JMID_PREC_F16MX at d_model 512: second-generation LayerNorm kernels (gemm_ln2_mx.hpp) - the lo plane of the residual stream
+    // is a byte plane (it lives in the memory of the fp16 one), the row statistics are summed in that file's order
+    const bool mxv2 = split && h->mx && d == GLN_BN && tune().mx_ln != 2;
+    unsigned char* Xl8 = mxv2 ? reinterpret_cast<unsigned char*>(sb.Xl) : nullptr;
     const auto embed_args = [&](const float* th) {
         return EmbedArgs{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, th,
                          split ? nullptr : sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
-                         split ? sb.Xl : nullptr};
+                         split && !mxv2 ? sb.Xl : nullptr, Xl8};
     };
     if (!embed_done) {
         ProfScope ps(h, KC_EMBED);
-        EmbedArgs ea{x_chunk, W(h, "concat1._layer.weight"), W(h, "concat1._layer.bias"), h->pe, hyp_chunk, thyp,
-                     split ? nullptr : sb.X, M, d, h->hl.total, h->hl.g1, h->hl.b1, rm, split ? sb.Xh : nullptr,
-                     split ? sb.Xl : nullptr};
+        EmbedArgs ea = embed_args(thyp);
         const long total = (long)M * (d / 4);
         int blocks = (int)std::min<long>((total + 255) / 256, 256L * 16);
         hipLaunchKernelGGL(embed_kernel, dim3(blocks), dim3(256), bystander_lds(embed_kernel), h->stream, ea);
@@ -543,7 +552,13 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             // per launch: 36.8 vs 39.1 ms per 12-episode call; 5: 33.8 vs 33.5, 4: 29.6 vs 28.8)
             // (enough row tiles to occupy the chip); otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
             const bool ln_fused = d == GLN_BN && tune().ln_fuse != 2 && (tune().ln_fuse == 1 || M >= 7168);
-            if (ln_fused) {
+            if (ln_fused && mxv2) {
+                GemmLn2Args g2{sb.Ah, h->w16[p + ".self_attn.out_proj.weight"].hi, h->w8[p + ".self_attn.out_proj.weight"].p,
+                               W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), sb.Xh, Xl8,
+                               M, d, 1e-5f, h->range_flag, 0};
+                ProfScope ps(h, KC_GEMM_OUT);
+                HIPCHK(h, launch_gemm_ln2_mx(g2, h->stream));
+            } else if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".self_attn.out_proj.weight"];
                 GemmLnArgs gl{sb.Ah, sb.Al, w16.hi, w16.lo, W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"),
                               W(h, p + ".norm1.bias"), sb.Xh, sb.Xl, M, d, 1e-5f, h->range_flag, h->x2};
@@ -560,7 +575,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
-                                        sb.Xl))
+                                        sb.Xl, mxv2, 0))
                     return rc;
             }
             const HalfPair& w1 = h->wsplit[p + ".linear1.weight"];
@@ -568,7 +583,13 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             set_w8(h, g, p + ".linear1.weight");
             g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
             if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
-            if (ln_fused) {
+            if (ln_fused && mxv2) {
+                GemmLn2Args g2{sb.H1h, h->w16[p + ".linear2.weight"].hi, h->w8[p + ".linear2.weight"].p, W(h, p + ".linear2.bias"),
+                               W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), sb.Xh, Xl8, M, ff, 1e-5f, h->range_flag,
+                               l + 1 == h->tf_layer};       // the residual stream ends here: concat3 reads X_hi only
+                ProfScope ps(h, KC_GEMM_FF2);
+                HIPCHK(h, launch_gemm_ln2_mx(g2, h->stream));
+            } else if (ln_fused) {
                 const HalfPair& w16 = h->w16[p + ".linear2.weight"];
                 GemmLnArgs gl{sb.H1h, sb.H1l, w16.hi, w16.lo, W(h, p + ".linear2.bias"), W(h, p + ".norm2.weight"),
                               W(h, p + ".norm2.bias"), sb.Xh, sb.Xl, M, ff, 1e-5f, h->range_flag, h->x2};
@@ -586,7 +607,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
-                                        sb.Xl))
+                                        sb.Xl, mxv2, l + 1 == h->tf_layer))
                     return rc;
             }
         }
@@ -1462,6 +1483,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_mx", &Tuning::attn_mx, 0, 3},
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"attn_pf", &Tuning::attn_pf, 0, 2},
+        {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
