@@ -53,6 +53,8 @@ SIGNATURES = {
     "jmid_dbg_gemm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_void_p]),
     "jmid_dbg_attention": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "jmid_dbg_gemm_ln_mx": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int]),
     "jmid_dbg_add_layernorm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 

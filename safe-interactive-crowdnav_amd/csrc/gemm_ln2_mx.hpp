@@ -10,13 +10,11 @@
 //   * the residual stream's lo plane is a BYTE plane in this mode (bf8 of fp16(x - hi): hi + lo carries x to ~14 bits, and the
 //     only readers of X_lo in F16X2 / F16MX are these LayerNorms - the GEMMs take X_hi; ADE against exact fp32 1.163e-5 vs
 //     1.158e-5 m): 3 instead of 4 bytes per element each way, as 16-byte (hi) and 8-byte (lo) accesses per lane;
-//   * bf8(W_lo) goes L2 -> registers directly (it is wave-private: staging it in LDS bought nothing), so the rings are 60 KB and
-//     TWO workgroups of 4 waves (wave tile 64 rows x 128 columns = 128 accumulators) share a CU: one's epilogue runs under the
-//     other's K loop.
-// The row statistics are summed in a fixed order that add_ln2_kernel (the unfused path for launches too small to fill the chip)
-// reproduces, so fused and unfused rows stay bit-identical and a chunk plan cannot change a result:
-//     partial(w, h) = sum over (j, p, e) in that order of v[128 w + 32 j + 16 p + 8 h + e]        w = 0..3, h = 0..1
-//     total = (((P0 + P1) + P2) + P3),  Pw = partial(w, 0) + partial(w, 1)
+//   * bf8(W_lo) goes L2 -> registers directly (it is wave-private: staging it in LDS bought nothing), so the rings are 60 - 72 KB.
+// The row statistics are summed in a fixed order that both tile shapes and add_ln2_kernel (the unfused path for launches too
+// small to fill the chip) reproduce, so fused and unfused rows stay bit-identical and a chunk plan cannot change a result:
+//     partial(c, h) = sum over (j, p, e) in that order of v[64 c + 32 j + 16 p + 8 h + e]         c = 0..7, j, p, h = 0..1, e = 0..7
+//     total = ((((((P0 + P1) + P2) + P3) + P4) + P5) + P6) + P7,  Pc = partial(c, 0) + partial(c, 1)
 #pragma once
 #include "gemm_ln_f16x3.hpp"
 
@@ -64,20 +62,35 @@ struct GemmLn2Args {
     int no_lo_out;                // the last LayerNorm of the net: nobody reads its lo plane
 };
 
-constexpr int GL2_BM = 64;
-constexpr int GL2_NSW = 3, GL2_NSA = 3;
-constexpr int GL2_W_STAGE = GLN_BN * 16;                 // halfs: the hi plane of a k16 slice, 16 KB
-constexpr int GL2_A_STAGE = GL2_BM * 32;                 // halfs: a k32 tile of 64 rows, 4 KB
-constexpr int GL2_A_OFF = GL2_NSW * GL2_W_STAGE;         // halfs
-constexpr size_t GL2_RING_BYTES = size_t(GL2_A_OFF + GL2_NSA * GL2_A_STAGE) * sizeof(half_t);    // 48 + 12 = 60 KB
-constexpr size_t GL2_LDS_BYTES = GL2_RING_BYTES + 3 * GLN_BN * sizeof(float);                    // + bias, gamma, beta: 66 KB
+// Tile shapes: wave tile (32 WM) rows x (32 WN) columns = 128 accumulators either way; 16 / WN waves side by side cover the 512 columns.
+//   <4, 2>  128 rows, 8 waves, one workgroup per CU: W streams L2 -> LDS once per 128 rows (the production shape for full launches:
+//           with 64-row tiles two workgroups per CU pull 64 B / clk / CU of W, which is all a CU gets from L2 - measured 10 % slower)
+//   <2, 4>  64 rows, 4 waves, 66 KB of LDS: two workgroups per CU, for launches that fill the chip better with 64-row tiles
+template <int WM, int WN>
+struct Gl2Cfg {
+    static constexpr int NWAVES = 16 / WN, NT = 64 * NWAVES, BM = 32 * WM;
+    static constexpr int NSW = 3, NSA = 3;
+    static constexpr int W_STAGE = GLN_BN * 16;                 // halfs: the hi plane of a k16 slice, 16 KB
+    static constexpr int A_STAGE = BM * 32;                     // halfs: a k32 tile of BM rows
+    static constexpr int A_OFF = NSW * W_STAGE;                 // halfs
+    // bf8(W_lo) of a k64 block: through LDS (a wave-private 4 KB buffer, refilled by DMA right after the block's fp8 MFMAs took it
+    // out) in the one-workgroup-per-CU shape; straight into registers in the other, whose LDS budget has no room for it - there
+    // the compiler waits vmcnt(0) before the fp8 MFMAs (it treats ordinary loads next to LDS-DMA copies as out of order)
+    static constexpr bool W8_LDS = WM == 4;
+    static constexpr size_t W8_OFF = size_t(A_OFF + NSA * A_STAGE) * sizeof(half_t);           // bytes: 48 KB + 12 / 24 KB of rings
+    static constexpr size_t RING_BYTES = W8_OFF + (W8_LDS ? size_t(GLN_BN) * 64 : 0);          // + 32 KB
+    static constexpr size_t LDS_BYTES = RING_BYTES + 3 * GLN_BN * sizeof(float);               // + bias, gamma, beta
+    static_assert(2 * 8 * BM * sizeof(float) <= size_t(A_OFF) * sizeof(half_t), "reduction scratch must fit the W ring");
+};
 
 // the weight row (column of the output) MFMA row `r` of a 32-row fragment carries: bits 2 and 3 of r swapped, so that the
 // accumulator registers 8p .. 8p+7 of a lane are the 8 consecutive columns 16 p + 8 hi + 0..7 of its token row
 __device__ __forceinline__ int gl2_frag_row(int r) { return (r & 0x13) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-__global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
-    constexpr int WM = 2, WN = 4, d = GLN_BN;
+template <int WM, int WN>
+__global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
+    using C = Gl2Cfg<WM, WN>;
+    constexpr int d = GLN_BN, BM = C::BM, WCOLS = 32 * WN;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half_t* lds = reinterpret_cast<half_t*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, wc = tid >> 6;
@@ -85,12 +98,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int m0 = tm * GL2_BM;
+    const int m0 = tm * BM;
     const int nk = g.K / 32, nsteps = g.K / 16;
     // bias, gamma, beta of all 512 columns into LDS (6 KB): the epilogue reads them with LDS latency.  These are ordinary VMEM
     // loads: the ds_writes retire them before the DMA ring starts, so that vmcnt counts only the ring (+ the bf8(W_lo) loads).
-    float* par = reinterpret_cast<float*>(lds_raw + GL2_RING_BYTES);
-    {
+    float* par = reinterpret_cast<float*>(lds_raw + C::RING_BYTES);
+    if (tid < 256) {
         const f32x4 pb = *reinterpret_cast<const f32x4*>((tid < 128 ? g.bias : g.gamma) + (tid & 127) * 4);
         const f32x4 pc = tid < 128 ? *reinterpret_cast<const f32x4*>(g.beta + tid * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(par + (tid < 128 ? 0 : GLN_BN) + (tid & 127) * 4) = pb;
@@ -100,25 +113,26 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
     auto dma16 = [](const void* s, void* dd) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)dd, 16, 0, 0);
     };
-    // A: the 4 KB half of a panel image that holds this tile's 64 rows; one wave-instruction per wave and k32 tile.  Past the
-    // end the last tile / slice is copied again into its own stage (identical bytes: harmless), which keeps the number of
-    // DMA instructions in flight at every wait a compile-time constant.
-    const half_t* a_src = g.Ahi + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + tid * 8;
+    // A: this tile's rows of a k32 panel image (a whole 8 KB image for 128 rows, its 4 KB half for 64); one wave-instruction per
+    // wave and tile.  Past the end the last tile / slice is copied again into its own stage (identical bytes: harmless), which
+    // keeps the number of DMA instructions in flight at every wait a compile-time constant.
+    const half_t* a_src = WM == 4 ? g.Ahi + (size_t)tm * nk * 4096 + tid * 8
+                                  : g.Ahi + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + tid * 8;
     auto issueA = [&](int ka) {
         const int kk = ka < nk ? ka : nk - 1;
-        dma16(a_src + (size_t)kk * 4096, lds + GL2_A_OFF + (kk % GL2_NSA) * GL2_A_STAGE + wc * 512);
+        dma16(a_src + (size_t)kk * 4096, lds + C::A_OFF + (kk % C::NSA) * C::A_STAGE + wc * 512);
     };
-    // W_hi: the wave's own 128 rows of a k16 slice (4 KB, four wave-instructions): wave-private, no workgroup barrier
-    const half_t* w_src = g.W16hi + (size_t)(wc * 128) * 16 + lane * 8;
+    // W_hi: the wave's own 32 WN rows of a k16 slice (WN wave-instructions of 1 KB): wave-private, no workgroup barrier
+    const half_t* w_src = g.W16hi + (size_t)(wc * WCOLS) * 16 + lane * 8;
     auto issueW = [&](int s) {
         const int ss = s < nsteps ? s : nsteps - 1;
-        half_t* st = lds + (ss % GL2_NSW) * GL2_W_STAGE + wc * 2048;
+        half_t* st = lds + (ss % C::NSW) * C::W_STAGE + wc * (WCOLS * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(w_src + ((size_t)ss * GLN_BN + q * 32) * 16, st + q * 512);
+        for (int q = 0; q < WN; ++q) dma16(w_src + ((size_t)ss * GLN_BN + q * 32) * 16, st + q * 512);
     };
-    // bf8(W_lo) of a k64 block: this wave's four 32-column blocks, two 16-byte pieces each, straight into registers
+    // bf8(W_lo) of a k64 block: this wave's WN 32-column blocks, two 16-byte pieces each, L2 -> registers (wave-private data)
     const int frow = gl2_frag_row(l31);
-    const unsigned char* w8src = g.W8 + (size_t)(wc * 4) * 2048 + (size_t)(frow + 32 * hi) * 16;
+    const unsigned char* w8src = g.W8 + (size_t)(wc * WN) * 2048 + (size_t)(frow + 32 * hi) * 16;
     const size_t w8_kstride = (size_t)(GLN_BN / 32) * 2048;
     i32x8 w8[WN];
     auto loadW8 = [&](int kb) {
@@ -129,6 +143,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
             const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
             w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
         }
+    };
+    // W8_LDS: the wave's WN blocks x 2 pieces of 1 KB in image order (lane-linear copies); fragment reads pick the permuted row
+    unsigned char* w8buf = lds_raw + C::W8_OFF + wc * (WN * 2048);
+    const unsigned char* w8dma = g.W8 + (size_t)(wc * WN) * 2048 + lane * 16;
+    const int nkb = g.K / 64;
+    auto issueW8 = [&](int kb) {
+        const int kk = kb < nkb ? kb : nkb - 1;
+#pragma unroll
+        for (int q = 0; q < 2 * WN; ++q) dma16(w8dma + (size_t)kk * w8_kstride + q * 1024, w8buf + q * 1024);
     };
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -145,27 +168,31 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
         for (int ks = 0; ks < 2; ++ks) offA[i][ks] = row * 32 + (((ks * 2 + hi) ^ ((row >> 2) & 3)) * 8);
     }
 #pragma unroll
-    for (int j = 0; j < WN; ++j) offW[j] = (wc * 128 + j * 32 + frow) * 16 + hi * 8;
+    for (int j = 0; j < WN; ++j) offW[j] = (wc * WCOLS + j * 32 + frow) * 16 + hi * 8;
     i32x8 a8[WM];
 
-    // VMEM issue order: A0 W0 A1 W1 | step s: W(s+2) [A(s/2+2) on even s] [the 8 loads of bf8(W_lo) at s % 4 == 0].
-    // Younger than W(s) at the top of step s:  s%4 == 0: A, W = 5;  1: W, A, the 8 loads = 13;  3: W, A = 5;  2: A, W = 5 plus the 8
-    // loads IF they went out after W(s) - the compiler may order them either way inside step s - 2, so that wait takes them along.
+    // VMEM issue order: A0 W0 A1 W1 [W8(0)] | step s: W(s+2) [A(s/2+2) on even s], and
+    //   W8_LDS: the 2 WN copies of the next block's bf8(W_lo) at the END of step s % 4 == 3.  Younger than W(s) at the top of
+    //           step s:  s%4 == 0: A, W, W8 = 1 + 3 WN;  1: W8, W, A = 1 + 3 WN;  2 and 3: A, W = 1 + WN;
+    //   else:   the 2 WN register loads at s % 4 == 0.  s%4 == 0: A, W = 1 + WN;  1: W, A, the loads = 1 + 3 WN;  3: W, A = 1 + WN;
+    //           2: A, W = 1 + WN plus the loads IF they went out after W(s) - the compiler may order them either way inside
+    //           step s - 2, so that wait takes them along.
     issueA(0);
     issueW(0);
     issueA(1);
     issueW(1);
+    if (C::W8_LDS) issueW8(0);
     auto step = [&](const int s, auto q_c) {
         constexpr int Q = decltype(q_c)::value, ks = Q & 1;
-        if (Q == 1) wait_vmcnt<13>();
-        else wait_vmcnt<5>();
+        if (C::W8_LDS ? Q <= 1 : Q == 1) wait_vmcnt<1 + 3 * WN>();
+        else wait_vmcnt<1 + WN>();
         if (ks == 0) __builtin_amdgcn_s_barrier();      // A tile s/2 landed for everybody; A stage (s/2 - 1) % 3 is free again
         __builtin_amdgcn_sched_barrier(0);
         issueW(s + 2);
         if (ks == 0) issueA((s >> 1) + 2);
-        if (Q == 0) loadW8(s >> 2);
-        const half_t* stA = lds + GL2_A_OFF + ((s >> 1) % GL2_NSA) * GL2_A_STAGE;
-        const half_t* stW = lds + (s % GL2_NSW) * GL2_W_STAGE;
+        if (!C::W8_LDS && Q == 0) loadW8(s >> 2);
+        const half_t* stA = lds + C::A_OFF + ((s >> 1) % C::NSA) * C::A_STAGE;
+        const half_t* stW = lds + (s % C::NSW) * C::W_STAGE;
         f16x8 ah[WM], wh[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) ah[i] = *reinterpret_cast<const f16x8*>(stA + offA[i][ks]);
@@ -182,11 +209,24 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
             a8[i][Q * 2 + 1] = bf8_of_f16x4(dw[2], dw[3]);
         }
         if (Q == 3) {
+            if (C::W8_LDS) {
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    const unsigned char* p = w8buf + j * 2048 + (frow + 32 * hi) * 16;
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
+                    const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
+                    w8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                }
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)       // both operands bf8, literal zero scales: the UNSCALED instruction (gemm_f16x3.hpp)
                     acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8[j], a8[i], acc[i][j], 1, 1, 0, 0, 0, 0);
+            if (C::W8_LDS) {
+                __builtin_amdgcn_sched_barrier(0);
+                issueW8((s >> 2) + 1);      // the buffer is out of LDS (its reads were waited for before the MFMAs)
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -197,32 +237,33 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
         step(s + 3, std::integral_constant<int, 3>{});
     }
     wait_vmcnt<0>();                     // the copies past the end
-    __builtin_amdgcn_s_barrier();        // everybody is done with the rings: their first 2 KB become the reduction scratch
-    float* red = reinterpret_cast<float*>(lds_raw);      // [2 passes][4 waves][64 rows]
+    __builtin_amdgcn_s_barrier();        // everybody is done with the rings: their first KBs become the reduction scratch
+    float* red = reinterpret_cast<float*>(lds_raw);      // [2 passes][8 column blocks of 64][BM rows]
 
-    // ---- epilogue, in the accumulators: register 8p + e of acc[i][j] is column 128 wc + 32 j + 16 p + 8 hi + e of row 32 i + l31.
-    // The residual chunks of a row come in two batches of eight (16 + 8 bytes each) requested together: two memory round trips per
-    // row instead of sixteen; the second workgroup of the CU computes meanwhile.
+    // ---- epilogue, in the accumulators: register 8p + e of acc[i][j] is column 32 WN wc + 32 j + 16 p + 8 hi + e of row 32 i + l31.
+    // Statistics in the canonical order of this file's header: a partial per 64-column block c (j = 2 c', 2 c' + 1) and lane half.
+    constexpr int NC = WN / 2;            // 64-column blocks per wave
     float mean[WM], rstd[WM];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    // one row block (a literal at every call site: every accumulator index is a compile-time constant).  The residual chunks of
+    // a row (16 + 8 bytes each) are requested together: one memory round trip per row block.
+    auto pass1 = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
         const int row = m0 + i * 32 + l31;      // rows past M exist in the padded planes: loads need no guard
-        float s = 0.f;
+        f16x8 xh[2 * WN];
+        i32x2 xb[2 * WN];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f16x8 xh[8];
-            i32x2 xb[8];
+        for (int u = 0; u < 2 * WN; ++u) {
+            const int c0 = wc * WCOLS + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
+            xh[u] = *reinterpret_cast<const f16x8*>(g.Xh + blk_index(row, c0, d));
+            xb[u] = *reinterpret_cast<const i32x2*>(g.Xl8 + blk8_index(row, c0, d));
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int c0 = wc * 128 + (half * 2 + (u >> 1)) * 32 + (u & 1) * 16 + hi * 8;
-                xh[u] = *reinterpret_cast<const f16x8*>(g.Xh + blk_index(row, c0, d));
-                xb[u] = *reinterpret_cast<const i32x2*>(g.Xl8 + blk8_index(row, c0, d));
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int c = 0; c < NC; ++c) {
+            float s = 0.f;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int j = half * 2 + (u >> 1), p = u & 1;
-                const int c0 = wc * 128 + j * 32 + p * 16 + hi * 8;
+            for (int u = 4 * c; u < 4 * c + 4; ++u) {
+                const int j = u >> 1, p = u & 1;
+                const int c0 = wc * WCOLS + j * 32 + p * 16 + hi * 8;
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(par + c0), b1 = *reinterpret_cast<const f32x4*>(par + c0 + 4);
                 float xl[8];
                 f32_of_bf8x8(xb[u], xl);
@@ -235,37 +276,43 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
                     s += v;
                 }
             }
+            // both lane halves of a row write the same sum (a + b == b + a) to the same word: no divergent store
+            red[(wc * NC + c) * BM + i * 32 + l31] = s + __shfl_xor(s, 32, 64);
         }
-        s += __shfl_xor(s, 32, 64);
-        if (hi == 0) red[wc * 64 + i * 32 + l31] = s;
-    }
-    __syncthreads();
+    };
+    auto row_total = [&](const float* r8p, int r) {      // the 8 partials of row r, summed in column order
+        float t = r8p[r] + r8p[BM + r];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+        for (int c = 2; c < 8; ++c) t += r8p[c * BM + r];
+        return t;
+    };
+    auto pass2 = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
         const int r = i * 32 + l31;
-        mean[i] = (((red[r] + red[64 + r]) + red[128 + r]) + red[192 + r]) / (float)d;
-        float q = 0.f;
+        mean[i] = row_total(red, r) / (float)d;
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+        for (int c = 0; c < NC; ++c) {
+            float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float t = acc[i][j][e] - mean[i];
-                q += t * t;
-            }
-        q += __shfl_xor(q, 32, 64);
-        if (hi == 0) red[256 + wc * 64 + r] = q;
-    }
-    __syncthreads();
+            for (int j = 2 * c; j < 2 * c + 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float t = acc[i][j][e] - mean[i];
+                    q += t * t;
+                }
+            red[8 * BM + (wc * NC + c) * BM + r] = q + __shfl_xor(q, 32, 64);
+        }
+    };
     bool overflow = false;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    auto pass3 = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
         const int r = i * 32 + l31, row = m0 + r;
-        rstd[i] = rsqrtf((((red[256 + r] + red[320 + r]) + red[384 + r]) + red[448 + r]) / (float)d + g.eps);
+        rstd[i] = rsqrtf(row_total(red + 8 * BM, r) / (float)d + g.eps);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int c0 = wc * 128 + j * 32 + p * 16 + hi * 8;
+                const int c0 = wc * WCOLS + j * 32 + p * 16 + hi * 8;
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(par + GLN_BN + c0), g1 = *reinterpret_cast<const f32x4*>(par + GLN_BN + c0 + 4);
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(par + 2 * GLN_BN + c0), t1 = *reinterpret_cast<const f32x4*>(par + 2 * GLN_BN + c0 + 4);
                 f16x8 vh, vl;
@@ -274,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
                     const float o = (acc[i][j][8 * p + e] - mean[i]) * rstd[i] * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
                     half_t hh, ll;
                     split_f32(o, hh, ll);
-                    overflow |= !(fabsf(o) <= kHalfMax);
+                    overflow |= !(fabsf(o) <= kHalfMax) && row < g.M;      // (rows past M hold whatever the padding held)
                     vh[e] = hh;
                     vl[e] = ll;
                 }
@@ -283,85 +330,128 @@ __global__ __launch_bounds__(256, 2) void gemm_ln2_mx_kernel(GemmLn2Args g) {
                     if (!g.no_lo_out) *reinterpret_cast<i32x2*>(g.Xl8 + blk8_index(row, c0, d)) = bf8x8_of_f16(vl);
                 }
             }
-    }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    pass1(I0{}); pass1(I1{});
+    if constexpr (WM == 4) { pass1(I2{}); pass1(I3{}); }
+    __syncthreads();
+    pass2(I0{}); pass2(I1{});
+    if constexpr (WM == 4) { pass2(I2{}); pass2(I3{}); }
+    __syncthreads();
+    pass3(I0{}); pass3(I1{});
+    if constexpr (WM == 4) { pass3(I2{}); pass3(I3{}); }
     if (overflow) atomicOr(g.range_flag, 1);
 }
 
-inline hipError_t launch_gemm_ln2_mx(const GemmLn2Args& g, hipStream_t st) {
+template <int WM, int WN>
+inline void launch_gemm_ln2_cfg(const GemmLn2Args& g, hipStream_t st) {
+    using C = Gl2Cfg<WM, WN>;
     static DevSeen seen;
     if (auto once_ = first_use_on_device(seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln2_mx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)GL2_LDS_BYTES);
-    const int ntm = (g.M + GL2_BM - 1) / GL2_BM;
-    hipLaunchKernelGGL(gemm_ln2_mx_kernel, dim3(ntm), dim3(256), GL2_LDS_BYTES, st, g);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln2_mx_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)C::LDS_BYTES);
+    hipLaunchKernelGGL((gemm_ln2_mx_kernel<WM, WN>), dim3((g.M + C::BM - 1) / C::BM), dim3(C::NT), C::LDS_BYTES, st, g);
+}
+inline hipError_t launch_gemm_ln2_mx(const GemmLn2Args& g, hipStream_t st) {
+    // the row tile by how well the grid fills whole rounds of the resident slots (one 128-row workgroup or two 64-row ones per
+    // CU); at equal fill the 128-row kernel wins (W streams through L2 -> LDS half as often)
+    auto fill = [](long n, long slots) { return (double)n / (double)(((n + slots - 1) / slots) * slots); };
+    const long n128 = (g.M + 127) / 128, n64 = (g.M + 63) / 64;
+    const int rows = tune().ln_rows;
+    if (rows == 128 || (rows == 0 && 1.1 * fill(n128, 256) >= fill(n64, 512))) launch_gemm_ln2_cfg<4, 2>(g, st);
+    else launch_gemm_ln2_cfg<2, 4>(g, st);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The unfused partner (launches too small to fill the chip with 64-row tiles): X <- LN(X + Y) for the same planes, with the
-// row statistics summed in gemm_ln2_mx_kernel's order - lane (row, w, h) of a wave of 8 rows owns the 64 columns of partial(w, h).
+// The unfused partner (launches too small to fill the chip): X <- LN(X + Y) for the same planes, with the row statistics
+// summed in the canonical order - lane (row, c, h) of a wave of 4 rows owns the 32 columns of partial(c, h).
 __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, const float* gamma, const float* beta, int M, float eps,
                                                       half_t* Xh, unsigned char* Xl8, int no_lo_out, int* range_flag) {
     constexpr int d = GLN_BN;
     const int lane = threadIdx.x & 63;
-    const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (lane >> 3);
-    const int w = (lane >> 1) & 3, hi = lane & 1;
+    const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const int c = (lane >> 1) & 7, hi = lane & 1;
     const int rowc = row < M ? row : M - 1;
-    float v[64];
+    float v[32];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < 4; ++u) {
+        const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(Xh + blk_index(rowc, c0, d));
+        const i32x2 xb = *reinterpret_cast<const i32x2*>(Xl8 + blk8_index(rowc, c0, d));
+        const f32x4 y0 = *reinterpret_cast<const f32x4*>(Y + (size_t)rowc * d + c0), y1 = *reinterpret_cast<const f32x4*>(Y + (size_t)rowc * d + c0 + 4);
+        float xl[8];
+        f32_of_bf8x8(xb, xl);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int c0 = w * 128 + j * 32 + p * 16 + hi * 8;
-            const f16x8 xh = *reinterpret_cast<const f16x8*>(Xh + blk_index(rowc, c0, d));
-            const i32x2 xb = *reinterpret_cast<const i32x2*>(Xl8 + blk8_index(rowc, c0, d));
-            const f32x4 y0 = *reinterpret_cast<const f32x4*>(Y + (size_t)rowc * d + c0), y1 = *reinterpret_cast<const f32x4*>(Y + (size_t)rowc * d + c0 + 4);
-            float xl[8];
-            f32_of_bf8x8(xb, xl);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = (float)xh[e] + xl[e];
-                const float t = a + (e < 4 ? y0[e] : y1[e - 4]);
-                v[(j * 2 + p) * 8 + e] = t;
-                s += t;
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float a = (float)xh[e] + xl[e];
+            const float t = a + (e < 4 ? y0[e] : y1[e - 4]);
+            v[u * 8 + e] = t;
+            s += t;
         }
-    const int base = lane & ~7;
-    s += __shfl_xor(s, 1, 64);
-    const float mean = (((__shfl(s, base, 64) + __shfl(s, base + 2, 64)) + __shfl(s, base + 4, 64)) + __shfl(s, base + 6, 64)) / (float)d;
+    }
+    const int base = lane & ~15;
+    auto row_total = [&](float part) {      // partial(c, 0) + partial(c, 1), then the 8 blocks in column order
+        part += __shfl_xor(part, 1, 64);
+        float t = __shfl(part, base, 64) + __shfl(part, base + 2, 64);
+#pragma unroll
+        for (int k = 2; k < 8; ++k) t += __shfl(part, base + 2 * k, 64);
+        return t;
+    };
+    const float mean = row_total(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int e = 0; e < 64; ++e) {
+    for (int e = 0; e < 32; ++e) {
         const float t = v[e] - mean;
         q += t * t;
     }
-    q += __shfl_xor(q, 1, 64);
-    const float rstd = rsqrtf((((__shfl(q, base, 64) + __shfl(q, base + 2, 64)) + __shfl(q, base + 4, 64)) + __shfl(q, base + 6, 64)) / (float)d + eps);
+    const float rstd = rsqrtf(row_total(q) / (float)d + eps);
     bool overflow = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int u = 0; u < 4; ++u) {
+        const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(beta + c0), t1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+        f16x8 vh, vl;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int c0 = w * 128 + j * 32 + p * 16 + hi * 8;
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(beta + c0), t1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
-            f16x8 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float o = (v[(j * 2 + p) * 8 + e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
-                half_t hh, ll;
-                split_f32(o, hh, ll);
-                overflow |= !(fabsf(o) <= kHalfMax);
-                vh[e] = hh;
-                vl[e] = ll;
-            }
-            if (row < M) {
-                *reinterpret_cast<f16x8*>(Xh + blk_index(row, c0, d)) = vh;
-                if (!no_lo_out) *reinterpret_cast<i32x2*>(Xl8 + blk8_index(row, c0, d)) = bf8x8_of_f16(vl);
-            }
+        for (int e = 0; e < 8; ++e) {
+            const float o = (v[u * 8 + e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+            half_t hh, ll;
+            split_f32(o, hh, ll);
+            overflow |= !(fabsf(o) <= kHalfMax);
+            vh[e] = hh;
+            vl[e] = ll;
         }
+        if (row < M) {
+            *reinterpret_cast<f16x8*>(Xh + blk_index(row, c0, d)) = vh;
+            if (!no_lo_out) *reinterpret_cast<i32x2*>(Xl8 + blk8_index(row, c0, d)) = bf8x8_of_f16(vl);
+        }
+    }
     if (overflow && row < M) atomicOr(range_flag, 1);
+}
+
+// fp32 row-major [rows, 512] <-> the residual-stream planes of this mode (fp16 hi, blocked; bf8 image of lo): diagnostics
+__global__ void split_planes_lo8_kernel(const float* in, half_t* hi, unsigned char* lo8, int rows) {
+    const size_t n = (size_t)rows * GLN_BN;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / GLN_BN), k = (int)(i % GLN_BN);
+        half_t h, l;
+        split_f32(in[i], h, l);
+        hi[blk_index(r, k, GLN_BN)] = h;
+        lo8[blk8_index(r, k, GLN_BN)] = bf8_of_f16(l);
+    }
+}
+__global__ void merge_planes_lo8_kernel(const half_t* hi, const unsigned char* lo8, float* out, int rows) {
+    const size_t n = (size_t)rows * GLN_BN;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / GLN_BN), k = (int)(i % GLN_BN);
+        const unsigned short lb = (unsigned short)(lo8[blk8_index(r, k, GLN_BN)]) << 8;
+        out[i] = (float)hi[blk_index(r, k, GLN_BN)] + (float)__builtin_bit_cast(half_t, lb);
+    }
 }
 
 }  // namespace jmid

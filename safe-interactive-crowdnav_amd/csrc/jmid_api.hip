@@ -340,8 +340,8 @@ int make_w8(jmid_ctx* h, const float* dW, int N, int K, jmid_ctx::W8Image* out) 
 int run_add_ln(jmid_ctx* h, float* X, const float* Y, const float* gm, const float* bt, int M, int d,
                half_t* Xh = nullptr, half_t* Xl = nullptr, bool mxv2 = false, int no_lo_out = 0) {
     ProfScope ps(h, KC_ADD_LN);
-    if (mxv2) {      // gemm_ln2_mx.hpp: byte lo plane, that file's summation order (d == 512); 8 rows per wave
-        hipLaunchKernelGGL(add_ln2_kernel, dim3((M + 31) / 32), dim3(256), bystander_lds(add_ln2_kernel), h->stream, Y, gm, bt, M, 1e-5f,
+    if (mxv2) {      // gemm_ln2_mx.hpp: byte lo plane, that file's summation order (d == 512); 4 rows per wave
+        hipLaunchKernelGGL(add_ln2_kernel, dim3((M + 15) / 16), dim3(256), bystander_lds(add_ln2_kernel), h->stream, Y, gm, bt, M, 1e-5f,
                            Xh, reinterpret_cast<unsigned char*>(Xl), no_lo_out, h->range_flag);
         HIPCHK(h, hipGetLastError());
         return 0;
@@ -1710,6 +1710,75 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
     if (!rc) HIPCHK(h, hipMemcpy(OUT, dO, Mt * d * 4, hipMemcpyDeviceToHost));
     hipFree(dQ); hipFree(dO);
     for (half_t* p : tmp) hipFree(p);
+    return rc;
+}
+
+int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const float* Wt, const float* bias, const float* gamma,
+                        const float* beta, float* X, int fused) {
+    // X <- LayerNorm(X + A . Wt^T + bias) in JMID_PREC_F16MX at d_model 512 with the second-generation kernels
+    // (gemm_ln2_mx.hpp): fused = 1 the row-complete kernel, 0 the GEMM + add_ln2 pair.  X comes back as hi + bf8(lo).
+    if (!h || !A || !Wt || !bias || !gamma || !beta || !X || M <= 0 || K % 64 != 0) return JMID_EINVAL;
+    constexpr int N = GLN_BN;
+    HIPCHK(h, hipSetDevice(h->device));
+    TuneScope tune_scope(&h->tune);
+    h->mx = 1;
+    h->x2 = 1;
+    if (!h->range_flag) {
+        HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
+        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+    }
+    std::vector<void*> tmp;
+    auto dalloc = [&](size_t bytes, const void* host) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+        tmp.push_back(p);
+        if (host) (void)hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
+        else (void)hipMemset(p, 0, bytes);
+        return p;
+    };
+    float* dA = (float*)dalloc((size_t)M * K * 4, A);
+    float* dW = (float*)dalloc((size_t)N * K * 4, Wt);
+    float* dB = (float*)dalloc(N * 4, bias);
+    float* dG = (float*)dalloc(N * 4, gamma);
+    float* dT = (float*)dalloc(N * 4, beta);
+    float* dX = (float*)dalloc((size_t)M * N * 4, X);
+    float* dY = (float*)dalloc((size_t)M * N * 4, nullptr);
+    const size_t pa = blk_plane_elems(M, K) * 2, pw = blk_plane_elems(N, K) * 2, px = blk_plane_elems(M, N) * 2;
+    half_t* ah = (half_t*)dalloc(pa, nullptr);
+    half_t* al = (half_t*)dalloc(pa, nullptr);
+    half_t* wh = (half_t*)dalloc(pw, nullptr);
+    half_t* wl = (half_t*)dalloc(pw, nullptr);
+    half_t* w16h = (half_t*)dalloc((size_t)N * K * 2, nullptr);
+    half_t* w16l = (half_t*)dalloc((size_t)N * K * 2, nullptr);
+    half_t* xh = (half_t*)dalloc(px, nullptr);
+    unsigned char* xl8 = (unsigned char*)dalloc(px, nullptr);
+    for (void* p : tmp)
+        if (!p) return fail(h, JMID_ENOMEM, "jmid_dbg_gemm_ln_mx: allocation failed");
+    hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(512), dim3(256), 0, h->stream, dA, ah, al, M, K, h->range_flag, 1.0f);
+    hipLaunchKernelGGL(split_planes_blocked_kernel, dim3(512), dim3(256), 0, h->stream, dW, wh, wl, N, K, h->range_flag, kWScale);
+    hipLaunchKernelGGL(split_planes_k16_kernel, dim3(256), dim3(256), 0, h->stream, dW, w16h, w16l, N, K);
+    hipLaunchKernelGGL(split_planes_lo8_kernel, dim3(512), dim3(256), 0, h->stream, dX, xh, xl8, M);
+    jmid_ctx::W8Image img;
+    if (int rc = make_w8(h, dW, N, K, &img)) return rc;
+    tmp.push_back(img.p);
+    int rc = 0;
+    if (fused) {
+        GemmLn2Args g2{ah, w16h, img.p, dB, dG, dT, xh, xl8, M, K, 1e-5f, h->range_flag, 0};
+        hipError_t e = launch_gemm_ln2_mx(g2, h->stream);
+        if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+    } else {
+        GemmHArgs g{};
+        g.Ahi = ah; g.Alo = al; g.Whi = wh; g.Wlo = wl; g.W8 = img.p; g.bias = dB; g.C = dY; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        rc = run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g);
+        if (!rc) rc = run_add_ln(h, nullptr, dY, dG, dT, M, N, xh, reinterpret_cast<half_t*>(xl8), true, 0);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(merge_planes_lo8_kernel, dim3(512), dim3(256), 0, h->stream, xh, xl8, dX, M);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
+    }
+    if (!rc) HIPCHK(h, hipMemcpy(X, dX, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    for (void* p : tmp) hipFree(p);
     return rc;
 }
 

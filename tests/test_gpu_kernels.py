@@ -111,3 +111,30 @@ def test_f16x3_gemm_variants_agree_bitwise(engine, variant, M, N, K, precision):
     np.testing.assert_array_equal(out, ref)
     exact = A.astype(np.float64) @ W.astype(np.float64).T + b
     assert np.abs(out - exact).max() <= TOL[precision] * max(1.0, np.abs(exact).max())
+
+
+@pytest.mark.parametrize("rows", [64, 128])
+@pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (7200, 1024), (1000, 64)])
+def test_f16mx_fused_gemm_layernorm_gen2_matches_float64_and_its_unfused_pair(M, K, rows):
+    """gemm_ln2_mx_kernel (JMID_PREC_F16MX, d_model 512: transposed product, row statistics in the accumulators, byte lo
+    plane of the residual stream) against float64, and bit for bit against the GEMM + add_ln2 pair small launches use -
+    nn.TransformerEncoderLayer's x = norm(x + sublayer(x)) as built at MID/models/diffusion.py:161-166."""
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
+    try:
+        rng = np.random.default_rng(M + K)
+        A = rng.standard_normal((M, K)).astype(np.float32) * np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
+        W = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32) * np.linspace(1.5, 0.5, 512, dtype=np.float32)[:, None]
+        b, g, t = (rng.standard_normal(512).astype(np.float32) for _ in range(3))
+        X = rng.standard_normal((M, 512)).astype(np.float32) * 2.0
+        eng.set_tuning("ln_rows", rows)          # both tile shapes of the fused kernel (128 rows x 8 waves, 64 rows x 4 waves)
+        fused = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=True)
+        pair = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=False)
+    finally:
+        eng.close()
+    v = X.astype(np.float64) + A.astype(np.float64) @ W.astype(np.float64).T + b
+    ref = (v - v.mean(1, keepdims=True)) / np.sqrt(v.var(1, keepdims=True) + 1e-5) * g + t
+    bad = np.argwhere(np.abs(fused - ref) > 2e-2)
+    assert len(bad) == 0, (len(bad), bad[:10], np.unique(bad[:, 1] % 128)[:40])
+    # inputs enter as fp16 (A_hi, X as hi + bf8(lo)): 2^-11 relative per operand, outputs leave as hi + bf8(lo)
+    assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
+    np.testing.assert_array_equal(fused, pair)
