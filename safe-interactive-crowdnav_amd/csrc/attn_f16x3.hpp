@@ -269,10 +269,8 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 // P1 (the mode's default): P.V with ONE fp16 plane of P, rounded to nearest - the same single rounding the mode gives every other
 // activation (V itself is one plane): 8 instead of 16 MFMAs per key tile and no lo half of the split.  ADE against exact fp32
 // 1.164e-5 m with or without the P_lo term.
-// PIPE: software-pipelined key-tile loop.  The K ring runs one tile ahead of the V^T ring: iteration t issues the QK^T MFMAs of
-// tile t + 1 FIRST and does the softmax of tile t (VALU / transcendental work that depends only on the previous iteration's
-// scores) in their shadow, then the P.V MFMAs of tile t - a wave keeps its own MFMA pipe busy through its softmax instead
-// of relying on the other wave of the SIMD to fill the gap.  Same arithmetic per element, same order: bit-identical.
+// (PIPE, a software-pipelined key-tile loop - the softmax of tile t in the shadow of the QK^T MFMAs of tile t + 1 - measured 1.7 %
+// slower in round 2 and was removed in round 3; the template parameter is kept so that kernel names stay comparable across profiles.)
 template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
@@ -365,35 +363,54 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int k_row = tid >> 4, k_c = (tid & 15) ^ (k_row & 15);             // rows 0-15 (+16 for odd rounds)
     const int v_row = tid >> 2, v_c = (tid & 3) ^ ((v_row >> 2) & 3);       // rows 0-63 (+64 for odd rounds)
     const int last_vchunk = a.Spad / 8 - 1;
-    // one of the 8 DMA wave-instructions of key tile kt (i < 4: K planes, else V^T planes)
+    // one of the 8 DMA wave-instructions of key tile kt (i < 4: K planes, else V^T planes): source = wave-uniform base (scalar
+    // registers: plane pointer + kt * tile stride) + a per-thread 32-bit offset - no vector address arithmetic per copy (the
+    // per-copy form cost ~110 VALU instructions per key tile, more than the softmax).  The offsets come in two sets, computed
+    // once: the regular one, and the one of the sequence's LAST tile, whose rows past S / chunks past Spad are clamped to valid
+    // memory (the keys are masked afterwards); `use_last_offsets` switches sets when that tile's copies are due.
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    const char* const kh_b = reinterpret_cast<const char*>(kh_g);
+    const char* const kl_b = reinterpret_cast<const char*>(kl_g);
+    const char* const k8h_b = reinterpret_cast<const char*>(a.K8h) + (tok0 * d + h * HD);
+    const char* const k8l_b = reinterpret_cast<const char*>(a.K8l) + (tok0 * d + h * HD);
+    const char* const vth_b = reinterpret_cast<const char*>(a.Vthi + vt0);
+    const char* const vtl_b = reinterpret_cast<const char*>(a.Vtlo + vt0);
+    const int last_tile = (S + KT - 1) / KT - 1;
+    const int rows_last = S - last_tile * KT - 1;                 // highest valid row of the last tile
+    const int chunks_last = last_vchunk - last_tile * 4;          // highest valid 16-byte chunk of its V^T rows
+    auto rowc = [&](int r) { return r < rows_last ? r : rows_last; };
+    unsigned offK16[2] = {(unsigned)(k_row * d + k_c * 8) * 2u, (unsigned)((16 + k_row) * d + k_c * 8) * 2u};   // fp16 K planes
+    unsigned offK8 = (unsigned)((tid >> 3) * d) + (unsigned)(((tid & 7) ^ (((tid >> 3) >> 1) & 7)) << 4);          // bf8 images
+    unsigned offV = (unsigned)(v_row * a.Spad + v_c * 8) * 2u;                                                   // V^T planes, rows 0-63 (+ 64)
+    const unsigned offK16_last[2] = {(unsigned)(rowc(k_row) * d + k_c * 8) * 2u, (unsigned)(rowc(16 + k_row) * d + k_c * 8) * 2u};
+    const unsigned offK8_last = (unsigned)(rowc(tid >> 3) * d) + (unsigned)(((tid & 7) ^ (((tid >> 3) >> 1) & 7)) << 4);
+    const unsigned offV_last = (unsigned)(v_row * a.Spad + (v_c < chunks_last ? v_c : chunks_last) * 8) * 2u;
+    auto use_last_offsets = [&]() {
+        offK16[0] = offK16_last[0];
+        offK16[1] = offK16_last[1];
+        offK8 = offK8_last;
+        offV = offV_last;
+    };
     auto issue_one = [&](int kt, int i) {
-        half_t* st = lds + (kt & 1) * ATT_STAGE + wid * 512;
         if (i >= 6 && X2) return;   // F16X2: the V^T lo plane is neither written by the QKV epilogue nor read here
+        half_t* st = lds + (kt & 1) * ATT_STAGE + wid_s * 512;
+        const char* src;
+        half_t* dst;
         if (MX && (i == 2 || i == 3)) {
             // a whole bf8 K image: 32 keys x 128 bytes; thread = (key row tid / 8, stored 16-byte chunk tid % 8), which
             // holds source chunk (tid % 8) ^ ((row >> 1) & 7): conflict-free ds_read_b128 of a lane-half's two chunks
-            const int row = tid >> 3;
-            int key = kt * KT + row;
-            key = key < S ? key : S - 1;
-            const unsigned char* src = (i == 2 ? a.K8h : a.K8l) + (tok0 + key) * d + h * HD + (((tid & 7) ^ ((row >> 1) & 7)) << 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
+            src = (i == 2 ? k8h_b : k8l_b) + (size_t)kt * (KT * d) + offK8;
+            dst = st + i * 2048;
         } else if (i < 4) {
-            int key = kt * KT + 16 * (i & 1) + k_row;
-            key = key < S ? key : S - 1;
-            const half_t* src = ((i >> 1) ? kl_g : kh_g) + (size_t)key * d + k_c * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + i * 2048), 16, 0, 0);
+            src = ((i >> 1) ? kl_b : kh_b) + (size_t)kt * (KT * d) * 2 + offK16[i & 1];
+            dst = st + i * 2048;
         } else {
-            i -= 4;
-            const int row = 64 * (i & 1) + v_row;
-            int kc = kt * 4 + v_c;
-            kc = kc < last_vchunk ? kc : last_vchunk;
-            const half_t* src = ((i >> 1) ? a.Vtlo : a.Vthi) + vt0 + (size_t)row * a.Spad + kc * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + 2 * ATT_KPLANE + i * 2048), 16,
-                                             0, 0);
+            const int j = i - 4;
+            src = ((j >> 1) ? vtl_b : vth_b) + (size_t)(64 * (j & 1)) * a.Spad * 2 + (size_t)kt * 64 + offV;
+            dst = st + 2 * ATT_KPLANE + j * 2048;
         }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
     auto issue = [&](int kt) {
 #pragma unroll
@@ -410,135 +427,12 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int ntiles_all = (S + KT - 1) / KT;
     const int kt_begin = (int)((long)split * ntiles_all / a.nsplit);
     const int ntiles = (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
-    if constexpr (PIPE) {
-        // one of the 8 DMA wave-instructions of an iteration: i < 4 -> K planes of tile tk, else V^T planes of tile tv
-        // (branch-free: past the end the last tile is copied again - valid bytes into a stage nobody reads any more - so that the
-        // MFMAs and the softmax of an iteration stay in ONE basic block, which is what the scheduler can interleave)
-        auto issue_kv = [&](int tk, int tv, int i) {
-            const int t = i < 4 ? tk : tv;
-            issue_one(t < ntiles ? t : ntiles - 1, i);
-        };
-        auto qk_step = [&](const half_t* Kh, const half_t* Kl, int ks, f32x16& sm) {
-            const int ok = kbase + (((2 * ks + hi) ^ kx) << 3);
-            const f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + ok);
-            const f16x8 kl_c = *reinterpret_cast<const f16x8*>(Kl + ok);
-            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[MX ? 0 : ks], sm, 0, 0, 0);
-            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_c, qh[ks], sm, 0, 0, 0);
-        };
-        f32x16 sm_cur;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sm_cur[r] = 0.f;
-        // prologue: K(b), K(b + 1), V(b); scores of the first tile
-#pragma unroll
-        for (int i = 0; i < 4; ++i) issue_one(kt_begin, i);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!wave_idle) {
-            const half_t* Kh = lds + (kt_begin & 1) * ATT_STAGE;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                qk_step(Kh, Kh + ATT_KPLANE, ks, sm_cur);
-                issue_kv(kt_begin + 1, kt_begin, ks);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) issue_kv(kt_begin + 1, kt_begin, i);
-        }
-        for (int kt = kt_begin; kt < ntiles; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(kt + 1) and V(kt) have landed (this wave's share) ...
-            __builtin_amdgcn_s_barrier();                      // ... and everybody else's; everybody is done with iteration kt - 1
-            __builtin_amdgcn_sched_barrier(0);
-            const bool nxt = kt + 1 < ntiles;
-            if (wave_idle) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) issue_kv(kt + 2, kt + 1, i);
-                continue;
-            }
-            const half_t* Kn = lds + ((kt + 1) & 1) * ATT_STAGE;                       // K planes of tile kt + 1
-            const half_t* Vh = lds + (kt & 1) * ATT_STAGE + 2 * ATT_KPLANE;            // V^T planes of tile kt
-            const half_t* Vl = Vh + ATT_VPLANE;
-            f32x16 sm_next;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sm_next[r] = 0.f;
-            // ---- the next tile's scores (MFMA) and this tile's softmax (VALU), interleaved by hand: after the three MFMAs of a
-            // QK^T step (96 MFMA cycles in flight) comes one slice of the softmax of the previous scores.  (After the last tile
-            // the scores are computed on stale K bytes and dropped.)
-            f32x16 sm = sm_cur;
-            float tmax, m_new, alpha, psum = 0.f;
-            bool rescale;
-            f16x8 ph[2], pl[2];
-            float pv[16];
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                qk_step(Kn, Kn + ATT_KPLANE, ks, sm_next);
-                issue_kv(kt + 2, kt + 1, ks);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == 0) {                           // only the last tile can hold keys past S
-                    const int lim = kt == ntiles_all - 1 ? S - kt * KT : KT;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sm[r] = frag_row(r, hi) >= lim ? -INFINITY : sm[r];
-                    tmax = sm[0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sm[r]);
-                } else if (ks == 1) {
-                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-                    m_new = fmaxf(m_run, tmax);
-                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                    rescale = !__all(m_new == m_run);
-                } else if (ks <= 5) {
-#pragma unroll
-                    for (int r = 4 * (ks - 2); r < 4 * (ks - 1); ++r) {
-                        sm[r] = __builtin_amdgcn_exp2f(sm[r] - m_new);
-                        pv[r] = sm[r];
-                    }
-                    if (ks == 3) split8(pv, ph[0], pl[0]);
-                    if (ks == 5) split8(pv + 8, ph[1], pl[1]);
-                } else if (ks == 6) {
-                    // the row sum in the order of the plain loop: r = 0 .. 15, then the other lane half
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) psum += sm[r];
-                    psum += __shfl_xor(psum, 32, 64);
-                    l_run = fmaf(l_run, alpha, psum);
-                    m_run = m_new;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (rescale) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
-            }
-            // ---- P.V of this tile (fragment reads one step ahead, as in the plain loop)
-            auto vload = [&](int step, f16x8& vh, f16x8& vl) {
-                const int n = step >> 1, mf = step & 1;
-                vh = *reinterpret_cast<const f16x8*>(Vh + n * 1024 + vbase[mf]);
-                if (!X2) vl = *reinterpret_cast<const f16x8*>(Vl + n * 1024 + vbase[mf]);
-            };
-            f16x8 vh_c, vl_c;
-            vload(0, vh_c, vl_c);
-#pragma unroll
-            for (int step = 0; step < 2 * NT; ++step) {
-                f16x8 vh_n = vh_c, vl_n = vl_c;
-                if (step + 1 < 2 * NT) vload(step + 1, vh_n, vl_n);
-                const int n = step >> 1, mf = step & 1;
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, ph[mf], ot[n], 0, 0, 0);
-                ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh_c, pl[mf], ot[n], 0, 0, 0);
-                if (!X2) ot[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl_c, ph[mf], ot[n], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                vh_c = vh_n;
-                vl_c = vl_n;
-            }
-            sm_cur = sm_next;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the copies past the end
-    } else {
+    {
+    if (kt_begin == last_tile) use_last_offsets();
     issue(kt_begin);
     ATT_STAMP(0)   // prologue: Q loads, first DMA issue
     for (int kt = kt_begin; kt < ntiles; ++kt) {
+        if (kt + 1 == last_tile) use_last_offsets();       // (uniform: the copies of tile kt + 1 go out during this iteration)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
         ATT_STAMP(1)
         __builtin_amdgcn_s_barrier();                      // ... and everybody else's; stage (kt+1)&1 is free again
@@ -738,7 +632,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
         ATT_STAMP(6)
     }
-    }   // !PIPE
+    }
     if (TRACE) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
@@ -890,9 +784,6 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, 
             if (p1 && tune().attn_pf != 2) launch_attn_dma<true, true, false, true, true>(a, grid1, nqt, st);
             else if (p1) launch_attn_dma<true, true, false, true>(a, grid1, nqt, st);
             else launch_attn_dma<true, true, false, false>(a, grid1, nqt, st);
-        } else if (tune().attn_h_variant == 2) {      // software-pipelined variant (opt-in; both planes of P)
-            if (a.x2) launch_attn_dma<true, false, true, false>(a, grid1, nqt, st);
-            else launch_attn_dma<false, false, true, false>(a, grid1, nqt, st);
         } else if (a.x2) {
             if (p1 && tune().attn_pf != 2) launch_attn_dma<true, false, false, true, true>(a, grid1, nqt, st);
             else if (p1) launch_attn_dma<true, false, false, true>(a, grid1, nqt, st);
