@@ -196,33 +196,16 @@ int64_t jmid_erange_count(jmid_handle_t h);
  * call; the split-KV factor of the attention launches is a function of (E, A, K, T) only, so calls with different
  * episode counts agree to rounding (ADE ~1e-7 m), not bit for bit, when head_dim is 128. */
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
-/* Implementation knobs for experiments (never needed for correctness).  Keys:
- *   "gemm_h_variant"  F16X3 GEMM kernel: 0 auto, 1 = 64x64 register-staged, 2 = 128x128 register-staged,
- *                     3 = 128x128 LDS-DMA ring, 4 = 256x128 LDS-DMA ring, 5 = 64x64 LDS-DMA ring,
- *                     6 = 256x256 LDS-DMA ring (N % 256 == 0)
- *   "attn_h_variant"  split-fp16 attention kernel: 0 auto (LDS-DMA ring for head_dim 128), 1 = register-staged, 2 = LDS-DMA ring with
- *                     the software-pipelined key-tile loop (bit-identical, measured 1.7 % slower)
- *   "csl_swap"        JMID_PREC_F16MX ConcatSquash (tail) GEMMs: 0 = transposed product + row-wise epilogue, 2 = column-wise epilogue
- *                     (bit-identical, 2 % slower per call)
- *   "out_traj"        output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories per chunk,
- *                     1 = always, 2 = one wave per token (bit-identical)
- *   "attn_mx"         head_dim 128.  JMID_PREC_F16MX: 0 (default) = the logits' correction terms as bf8 MFMAs and ONE fp16 plane of P
- *                     (rounded to nearest) in P.V; 1 = P_hi + P_lo (4.5 % slower per call, same ADE; in JMID_PREC_F16X2 too: 5 %); 2 = F16X2's
- *                     attention (fp16 corrections; 5 % slower).  Results differ at rounding level between the three.
- *                     3 = as 0, with Q_lo written as an fp16 plane and its bf8 image made in the attention kernel (same bits, 1 % slower)
- *   "attn_pf"         2 = the F16MX / F16X2 attention kernel reads its K / V^T fragments one step ahead instead of three (same bits,
- *                     1.3 % / 0.5 % slower per call)
- *   "vt_stage"        2 = the 256x256 QKV kernel writes V^T (and, in F16MX, Q / K) with direct stores instead of full rows through
- *                     LDS; 3 = only Q / K direct
- *   "graph"           1 = the denoise loop of a one-chunk call runs as a captured hipGraph, replayed from the third call with
- *                     the same (E, A, K, T, precision) on (same kernels in the same order: bit-identical; one graph launch
- *                     instead of ~28 x n_steps kernel launches; measured 0-3 % SLOWER than the eager launches, so off by
- *                     default), 0 / 2 = eager launches
- *   "attn_nsplit"     split-KV factor of the head_dim-128 attention launches: 0 auto (attn_pick_nsplit), 1..16 forced
- *   "gemm_ng", "print_occupancy"   diagnostics used by tools/
- *   "gemm_abl", "attn_abl"         timing ablations (WRONG results): exist only in builds with -DJMID_ABLATIONS
- * Every knob belongs to the handle it is set on.  All variants of a key compute the same values (bit-identical for
- * gemm_h_variant, ln_fuse, ln_rows, tail_fuse, tail_rows, vt_stage and no_vt_direct).  Unknown keys return JMID_EINVAL. */
+/* Run-time switches of a handle.  The production library knows ONE key:
+ *   "lanes"           chunks of the denoise loop in flight at once on separate HIP streams, 1..4 (default 2; the results do
+ *                     not depend on it)
+ * The diagnostics flavour of the library (built with -DJMID_DIAGNOSTICS as csrc/libjmid_hip_diag.so; what tests/ and tools/
+ * load) additionally takes the implementation knobs the experiments of docs/NOTEBOOK.md are made with - kernel-variant
+ * selectors such as "gemm_h_variant", "ln_fuse", "ln_rows", "mx_ln", "attn_mx", "attn_nsplit", "vt_stage", "graph",
+ * "tail_fuse", "out_traj", "csl_swap", "attn_pf" (listed with their value ranges in csrc/jmid_api.hip::jmid_set_tuning and
+ * csrc/common.hpp::Tuning; every variant of a key computes the same values, most of them bit-identically) - and, with
+ * -DJMID_ABLATIONS on top, the timing ablations "gemm_abl" / "attn_abl" (WRONG results).  Every switch belongs to the handle it
+ * is set on.  Unknown keys return JMID_EINVAL. */
 int jmid_set_tuning(jmid_handle_t h, const char* key, int value);
 /* Per-kernel-class timing with HIP events recorded on the handle's stream.
  * mask: bit i enables class i (see jmid_kernel_class_name); 0 disables.  Timers accumulate until reset. */
@@ -237,19 +220,22 @@ const char* jmid_kernel_class_name(int cls);
 int jmid_synchronize(jmid_handle_t h);
 
 /* ---- diagnostics: single-kernel entry points for the unit tests (HOST buffers only) ----------- */
+/* Exported by the diagnostics flavour only (-DJMID_DIAGNOSTICS, csrc/libjmid_hip_diag.so). */
+#ifdef JMID_DIAGNOSTICS
 /* C[M,N] = A[M,K] . Wt[N,K]^T + bias (optional ReLU): the nn.Linear contraction of every layer. */
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
                   int precision, float* C);
 /* Multi-head self-attention over `nseq` sequences of length S from a packed QKV buffer
  * [nseq*S, 3*d_model] -> OUT [nseq*S, d_model] (heads/dims of the handle). */
 int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT);
-/* X <- LayerNorm(X + Y) * gamma + beta, eps = 1e-5 (post-norm residual of nn.TransformerEncoderLayer). */
 /* X <- LayerNorm(X + A . Wt^T + bias) * gamma + beta in JMID_PREC_F16MX at d_model 512 (A [M, K], Wt [512, K], X [M, 512]), with the
  * second-generation kernels: fused = 1 the row-complete GEMM + residual + LayerNorm, 0 the GEMM + add_ln2 pair (bit-identical). */
 int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const float* Wt, const float* bias, const float* gamma,
                         const float* beta, float* X, int fused);
+/* X <- LayerNorm(X + Y) * gamma + beta, eps = 1e-5 (post-norm residual of nn.TransformerEncoderLayer). */
 int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float* Y, const float* gamma,
                            const float* beta);
+#endif /* JMID_DIAGNOSTICS */
 
 #ifdef __cplusplus
 }

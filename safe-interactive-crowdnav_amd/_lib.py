@@ -50,6 +50,10 @@ SIGNATURES = {
     "jmid_kernel_class_count": (C.c_int, []),
     "jmid_kernel_class_name": (C.c_char_p, [C.c_int]),
     "jmid_synchronize": (C.c_int, [Handle]),
+}
+
+# exported by the diagnostics flavour only (-DJMID_DIAGNOSTICS, csrc/libjmid_hip_diag.so; include/jmid_hip.h)
+DIAG_SIGNATURES = {
     "jmid_dbg_gemm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                 C.c_int, C.c_void_p]),
     "jmid_dbg_attention": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -87,5 +91,11 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    lib.has_diagnostics = b"diagnostics" in lib.jmid_version()
+    if lib.has_diagnostics:
+        for name, (res, args) in DIAG_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _LIB = lib
     return lib

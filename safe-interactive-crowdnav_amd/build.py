@@ -7,6 +7,9 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libjmid_hip.so")
+# the diagnostics flavour: the same kernels + the jmid_dbg_* single-kernel entry points and the jmid_set_tuning experiment knobs
+# (-DJMID_DIAGNOSTICS).  tests/ and tools/ load it (tests/conftest.py sets JMID_LIB); the product never does.
+LIB_DIAG = os.path.join(CSRC, "libjmid_hip_diag.so")
 SOURCES = ["jmid_api.hip"]
 
 
@@ -24,8 +27,9 @@ def library_path() -> str:
     return os.environ.get("JMID_LIB") or LIB
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile the HIP library in-tree.  Returns the path of the .so."""
+def build_library(force: bool = False, verbose: bool = False, diagnostics: bool = False) -> str:
+    """Compile the HIP library in-tree (``diagnostics``: the -DJMID_DIAGNOSTICS flavour).  Returns the path of the .so."""
+    LIB = LIB_DIAG if diagnostics else globals()["LIB"]
     if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
         return LIB
     # -ffp-contract=off: no implicit FMA contraction, so a value never depends on which template instance /
@@ -40,7 +44,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # chunks in flight.  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
     # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
-           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-o", LIB] + SOURCES
+           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else []) + \
+          ["-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
@@ -51,3 +56,4 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_library(force=True, verbose=True, diagnostics=True))

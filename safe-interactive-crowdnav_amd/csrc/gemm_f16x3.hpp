@@ -46,6 +46,35 @@ __device__ __forceinline__ unsigned char bf8_of_f16(half_t v) {
     return (unsigned char)((__builtin_bit_cast(unsigned short, v) + 0x80u) >> 8);
 }
 
+// hi / lo planes of FOUR fp32 values, two per conversion instruction (v_cvt_pk_f16_f32 rounds to nearest even like the scalar
+// conversion: the same bits as four split_f32 calls) - 16 instead of ~28 VALU instructions, range check included.  The check
+// accumulates the largest |hi| as 15-bit patterns (packed 16-bit max): a value beyond kHalfMax, an Inf or a NaN ends above
+// kHalfMaxBits.  (Epilogues that split value by value spend more VALU time on this than on their stores.)
+typedef int i32x2_s __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2_s __attribute__((ext_vector_type(2)));
+constexpr unsigned kHalfMaxBits = 0x7B53;      // fp16(60000)
+struct Split4 {
+    i32x2_s hi, lo;      // packed fp16 pairs: {v0, v1}, {v2, v3}
+};
+__device__ __forceinline__ Split4 split_f32x4(float a, float b, float c, float d, unsigned& amax16) {
+    asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));      // opaque values, as in split_f32
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f16x2 h01 = __builtin_convertvector(f32x2_{a, b}, f16x2), h23 = __builtin_convertvector(f32x2_{c, d}, f16x2);
+    const f16x2 l01 = __builtin_convertvector(f32x2_{a - (float)h01[0], b - (float)h01[1]}, f16x2);
+    const f16x2 l23 = __builtin_convertvector(f32x2_{c - (float)h23[0], d - (float)h23[1]}, f16x2);
+    Split4 r;
+    r.hi = i32x2_s{__builtin_bit_cast(int, h01), __builtin_bit_cast(int, h23)};
+    r.lo = i32x2_s{__builtin_bit_cast(int, l01), __builtin_bit_cast(int, l23)};
+    u16x2_s m = __builtin_bit_cast(u16x2_s, amax16);
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_s, (unsigned)r.hi[0] & 0x7fff7fffu));
+    m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2_s, (unsigned)r.hi[1] & 0x7fff7fffu));
+    amax16 = __builtin_bit_cast(unsigned, m);
+    return r;
+}
+__device__ __forceinline__ bool split_range_exceeded(unsigned amax16) {
+    return (amax16 & 0xffffu) > kHalfMaxBits || (amax16 >> 16) > kHalfMaxBits;
+}
+
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
 
 
@@ -690,42 +719,56 @@ __device__ __forceinline__ bool vt_staged_store(const GemmHArgs& g, f32x16 (&acc
     for (int j = 0; j < 4; ++j) bv[j] = g.bias ? g.bias[ncol0 + j * 32 + l31] : 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bv[j]));
-    bool overflow = false;
+    // The values once: bias, hi / lo split four at a time into packed fp16 pairs.  In two halves of 64 V^T rows (j = 2 jh, 2 jh + 1):
+    // the hi pairs go straight into the wave's LDS tile, the lo pairs of the half (32 integer registers) wait for its second
+    // plane pass - no more registers than the accumulators they replace.  (Packed pairs must not be parked in FLOAT registers:
+    // measured wrong - a pair can be a denormal / NaN pattern as an fp32.)
+    unsigned amax16 = 0;
     half_t* dst_base[2] = {g.Vthi, g.Vtlo};
+    auto lds_at = [&](int i, int j, int q) {
+        const int vc = j * 32 + l31;
+        const int pos = vt_key_pos(i * 32 + 8 * q + 4 * hi);      // first of 4 consecutive stored positions
+        return reinterpret_cast<f16x4*>(wlds + vc * 64 + ((((pos >> 3) ^ (vc & 7)) << 3) | (pos & 4)));
+    };
 #pragma unroll
-    for (int plane = 0; plane < (X2 ? 1 : 2); ++plane) {
+    for (int jh = 0; jh < 2; ++jh) {
+        i32x2_s lo_pk[2][2][4];      // [j - 2 jh][i][q]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int vc = j * 32 + l31;
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f16x4 pv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[j]);
-                        half_t hh, ll;
-                        split_f32_unscaled(v, hh, ll);
-                        if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax);
-                        pv[e] = plane == 0 ? hh : ll;
-                    }
-                    const int pos = vt_key_pos(i * 32 + 8 * q + 4 * hi);      // first of 4 consecutive stored positions
-                    *reinterpret_cast<f16x4*>(wlds + vc * 64 + ((((pos >> 3) ^ (vc & 7)) << 3) | (pos & 4))) = pv;
+                    const int j = 2 * jh + jj;
+                    const Split4 sp = split_f32x4(fmaf(acc[i][j][4 * q + 0], kWInv, bv[j]), fmaf(acc[i][j][4 * q + 1], kWInv, bv[j]),
+                                                  fmaf(acc[i][j][4 * q + 2], kWInv, bv[j]), fmaf(acc[i][j][4 * q + 3], kWInv, bv[j]), amax16);
+                    *lds_at(i, j, q) = __builtin_bit_cast(f16x4, sp.hi);
+                    lo_pk[jj][i][q] = sp.lo;
                 }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        half_t* dst = dst_base[plane] + (((size_t)seq * nh + head) * g.hd) * g.Spad + key0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int row = t * 8 + (lane >> 3), c = lane & 7;
-            const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 64 + ((c ^ (row & 7)) << 3));
-            *reinterpret_cast<f16x8*>(dst + (size_t)row * g.Spad + c * 8) = v8;
+        for (int plane = 0; plane < (X2 ? 1 : 2); ++plane) {
+            if (plane == 1) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) *lds_at(i, 2 * jh + jj, q) = __builtin_bit_cast(f16x4, lo_pk[jj][i][q]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            half_t* dst = dst_base[plane] + (((size_t)seq * nh + head) * g.hd) * g.Spad + key0;
+#pragma unroll
+            for (int t = 8 * jh; t < 8 * jh + 8; ++t) {
+                const int row = t * 8 + (lane >> 3), c = lane & 7;
+                const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 64 + ((c ^ (row & 7)) << 3));
+                *reinterpret_cast<f16x8*>(dst + (size_t)row * g.Spad + c * 8) = v8;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
     }
+    const bool overflow = split_range_exceeded(amax16);
     if (overflow) atomicOr(g.range_flag, 1);
     return true;
 }
@@ -748,76 +791,81 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
     const int part = nw0 / g.d, nn0 = nw0 - part * g.d;
     half_t* dst_base[2] = {part == 0 ? g.Chi : g.Khi, part == 0 ? g.Clo : g.Klo};
     const float qs = part == 0 ? g.qscale : 1.0f;
-    // the values first, in place (bias, Q scale): 16 bias registers at a time instead of 64 next to the 128 accumulators
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x4 bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(g.bias + nw0 + j * 32 + 8 * q + 4 * hi);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = fmaf(acc[i][j][4 * q + e], kWInv, bv[q][e]);
-                    if (part == 0) v *= qs;
-                    acc[i][j][4 * q + e] = v;
-                }
-    }
-    bool overflow = false;
+    // The values once: bias, Q scale, hi / lo split four at a time into packed fp16 pairs.  In two halves of 32 token rows (i): the
+    // hi pairs go straight into the wave's LDS tile, the lo pairs of the half (32 integer registers) wait for its second plane
+    // pass - no more registers than the accumulators they replace.  Rows past M hold whatever the padding held: they stay out
+    // of the range check.
+    unsigned amax16 = 0;
     const bool k8 = K8IMG && part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
     const bool q8 = K8IMG && part == 0 && g.Q8l != nullptr;     // Q tile: the bf8 image of Q_lo instead of the fp16 plane
+    auto lds_at = [&](int i, int j, int q) {
+        const int row = i * 32 + l31;
+        const int c = (8 * j + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
+        return reinterpret_cast<f16x4*>(wlds + row * 128 + c * 4);
+    };
 #pragma unroll
-    for (int plane = 0; plane < 2; ++plane) {
+    for (int i = 0; i < 2; ++i) {
+        i32x2_s lo_pk[4][4];      // [j][q]
+        unsigned am = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = i * 32 + l31;
+        for (int j = 0; j < 4; ++j) {
+            f32x4 bv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(g.bias + nw0 + j * 32 + 8 * q + 4 * hi);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f16x4 pv;
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = acc[i][j][4 * q + e];
-                        half_t hh, ll;
-                        split_f32_unscaled(v, hh, ll);
-                        if (plane == 0) overflow |= !(fabsf(v) <= kHalfMax) && mw0 + row < g.M;   // rows past M hold whatever the padding held
-                        pv[e] = plane == 0 ? hh : ll;
-                    }
-                    const int c = (8 * j + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
-                    *reinterpret_cast<f16x4*>(wlds + row * 128 + c * 4) = pv;
-                    __builtin_amdgcn_sched_barrier(0);           // (as in the byte phase)
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(acc[i][j][4 * q + e], kWInv, bv[q][e]);
+                    if (part == 0) v[e] *= qs;
                 }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        half_t* dst = dst_base[plane] + (size_t)mw0 * g.d + nn0;
-        // K tile with bf8 images wanted (attn_mx = 1): they are made from the rows on their way out - 8 bytes per lane next to
-        // the 16 of the fp16 plane; the fp16 K_lo plane itself is not written then
-        const bool img = k8 || (q8 && plane == 1);
-        unsigned char* dst8 = img ? (k8 ? (plane == 0 ? g.K8h : g.K8l) : g.Q8l) + (size_t)mw0 * g.d + nn0 : nullptr;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int row = t * 4 + (lane >> 4), u = lane & 15;
-            const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
-            if (mw0 + row < g.M) {
-                if (!((k8 || q8) && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
-                if (img) {
-                    const i32x4_e dw = __builtin_bit_cast(i32x4_e, v8);
-                    i32x2_e b8;
-                    b8[0] = bf8_of_f16x4_e(dw[0], dw[1]);
-                    b8[1] = bf8_of_f16x4_e(dw[2], dw[3]);
-                    *reinterpret_cast<i32x2_e*>(dst8 + (size_t)row * g.d + u * 8) = b8;
-                }
+                const Split4 sp = split_f32x4(v[0], v[1], v[2], v[3], am);
+                *lds_at(i, j, q) = __builtin_bit_cast(f16x4, sp.hi);
+                lo_pk[j][q] = sp.lo;
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        if (mw0 + i * 32 + l31 < g.M) {
+            const u16x2_s m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_s, amax16), __builtin_bit_cast(u16x2_s, am));
+            amax16 = __builtin_bit_cast(unsigned, m);
+        }
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+            if (plane == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *lds_at(i, j, q) = __builtin_bit_cast(f16x4, lo_pk[j][q]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            half_t* dst = dst_base[plane] + (size_t)mw0 * g.d + nn0;
+            // K tile with bf8 images wanted (attn_mx = 1): they are made from the rows on their way out - 8 bytes per lane next to
+            // the 16 of the fp16 plane; the fp16 K_lo plane itself is not written then
+            const bool img = k8 || (q8 && plane == 1);
+            unsigned char* dst8 = img ? (k8 ? (plane == 0 ? g.K8h : g.K8l) : g.Q8l) + (size_t)mw0 * g.d + nn0 : nullptr;
+#pragma unroll
+            for (int t = 8 * i; t < 8 * i + 8; ++t) {
+                const int row = t * 4 + (lane >> 4), u = lane & 15;
+                const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
+                if (mw0 + row < g.M) {
+                    if (!((k8 || q8) && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
+                    if (img) {
+                        const i32x4_e dw = __builtin_bit_cast(i32x4_e, v8);
+                        i32x2_e b8;
+                        b8[0] = bf8_of_f16x4_e(dw[0], dw[1]);
+                        b8[1] = bf8_of_f16x4_e(dw[2], dw[3]);
+                        *reinterpret_cast<i32x2_e*>(dst8 + (size_t)row * g.d + u * 8) = b8;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+    const bool overflow = split_range_exceeded(amax16);
     if (overflow) atomicOr(g.range_flag, 1);
 }
 

@@ -303,11 +303,12 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
             red[8 * BM + (wc * NC + c) * BM + r] = q + __shfl_xor(q, 32, 64);
         }
     };
-    bool overflow = false;
+    unsigned amax16 = 0;
     auto pass3 = [&](auto i_c) {
         constexpr int i = decltype(i_c)::value;
         const int r = i * 32 + l31, row = m0 + r;
         rstd[i] = rsqrtf(row_total(red + 8 * BM, r) / (float)d + g.eps);
+        unsigned am = 0;
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -315,21 +316,22 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
                 const int c0 = wc * WCOLS + j * 32 + p * 16 + hi * 8;
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(par + GLN_BN + c0), g1 = *reinterpret_cast<const f32x4*>(par + GLN_BN + c0 + 4);
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(par + 2 * GLN_BN + c0), t1 = *reinterpret_cast<const f32x4*>(par + 2 * GLN_BN + c0 + 4);
-                f16x8 vh, vl;
+                float o[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float o = (acc[i][j][8 * p + e] - mean[i]) * rstd[i] * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
-                    half_t hh, ll;
-                    split_f32(o, hh, ll);
-                    overflow |= !(fabsf(o) <= kHalfMax) && row < g.M;      // (rows past M hold whatever the padding held)
-                    vh[e] = hh;
-                    vl[e] = ll;
-                }
+                for (int e = 0; e < 8; ++e)
+                    o[e] = (acc[i][j][8 * p + e] - mean[i]) * rstd[i] * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+                const Split4 s0 = split_f32x4(o[0], o[1], o[2], o[3], am), s1 = split_f32x4(o[4], o[5], o[6], o[7], am);
                 if (row < g.M) {
-                    *reinterpret_cast<f16x8*>(g.Xh + blk_index(row, c0, d)) = vh;
-                    if (!g.no_lo_out) *reinterpret_cast<i32x2*>(g.Xl8 + blk8_index(row, c0, d)) = bf8x8_of_f16(vl);
+                    *reinterpret_cast<i32x4*>(g.Xh + blk_index(row, c0, d)) = i32x4{s0.hi[0], s0.hi[1], s1.hi[0], s1.hi[1]};
+                    if (!g.no_lo_out)
+                        *reinterpret_cast<i32x2*>(g.Xl8 + blk8_index(row, c0, d)) =
+                            i32x2{bf8_of_f16x4(s0.lo[0], s0.lo[1]), bf8_of_f16x4(s1.lo[0], s1.lo[1])};
                 }
             }
+        if (row < g.M) {      // (rows past M hold whatever the padding held)
+            const u16x2_s m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_s, amax16), __builtin_bit_cast(u16x2_s, am));
+            amax16 = __builtin_bit_cast(unsigned, m);
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     __syncthreads();
     pass3(I0{}); pass3(I1{});
     if constexpr (WM == 4) { pass3(I2{}); pass3(I3{}); }
-    if (overflow) atomicOr(g.range_flag, 1);
+    if (split_range_exceeded(amax16)) atomicOr(g.range_flag, 1);
 }
 
 template <int WM, int WN>

@@ -970,7 +970,13 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
 // ================================================================================================ C ABI
 extern "C" {
 
-const char* jmid_version(void) { return "jmid_hip 0.6.0 (gfx950; f32-mfma + f16x3 / f16x2 split-mfma + f16mx fp8-correction)"; }
+const char* jmid_version(void) {
+#ifdef JMID_DIAGNOSTICS
+    return "jmid_hip 0.7.0+diagnostics (gfx950; f32-mfma + f16x3 / f16x2 split-mfma + f16mx fp8-correction)";
+#else
+    return "jmid_hip 0.7.0 (gfx950; f32-mfma + f16x3 / f16x2 split-mfma + f16mx fp8-correction)";
+#endif
+}
 
 int jmid_device_count(void) {
     int n = 0;
@@ -1466,6 +1472,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         int lo, hi;
     };
     // every knob belongs to the handle (h->tune); none is process-wide
+#ifdef JMID_DIAGNOSTICS
     static const Knob knobs[] = {
         {"gemm_h_variant", &Tuning::gemm_h_variant, 0, 6},     // 0 auto, 1..6 force a tile variant of the split GEMM
         {"attn_pack", &Tuning::attn_pack, 0, 1},               // 0: one short sequence per wave, 1: packed (iMID)
@@ -1491,11 +1498,13 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_abl", &Tuning::gemm_abl, 0, 1 << 30},
 #endif
     };
+#endif
     if (k == "lanes") {     // chunks of the denoise loop in flight at once: 1..4
         if (value < 1 || value > jmid_ctx::kMaxLanes) return fail(h, JMID_EINVAL, "lanes must be 1..4");
         h->lanes = value;
         return JMID_OK;
     }
+#ifdef JMID_DIAGNOSTICS
     if (k == "print_occupancy") {   // diagnostics: resident workgroups per CU of the main kernels
         int n = -1;
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_f16x3_dma_kernel<false>, 256, ATT_DMA_LDS);
@@ -1518,6 +1527,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
             drop_graphs(h);          // captured loops hold the kernel variants the old knobs selected
             return JMID_OK;
         }
+#endif
     return fail(h, JMID_EINVAL, "unknown tuning key " + k);
 }
 
@@ -1582,6 +1592,7 @@ int jmid_synchronize(jmid_handle_t h) {
     return JMID_OK;
 }
 
+#ifdef JMID_DIAGNOSTICS
 // ---------------------------------------------------------------------------------------------- diagnostics
 // Single-op entry points used by the unit tests (host buffers only).
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
@@ -1805,5 +1816,7 @@ int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float*
     hipFree(dX); hipFree(dY); hipFree(dG); hipFree(dB);
     return rc;
 }
+
+#endif  // JMID_DIAGNOSTICS
 
 }  // extern "C"

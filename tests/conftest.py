@@ -7,6 +7,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
+# the tests drive single kernels (jmid_dbg_*) and kernel-variant knobs: they load the DIAGNOSTICS flavour of the library - the
+# same kernels as the production libjmid_hip.so, which smoke(), bench.py and tests/test_gpu_production_lib.py run on
+PROD_LIB = os.path.join(REPO, "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
+DIAG_LIB = os.path.join(REPO, "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_diag.so")
+os.environ.setdefault("JMID_LIB", DIAG_LIB)
 
 
 def pytest_configure(config):

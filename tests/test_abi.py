@@ -26,11 +26,23 @@ def declared_functions():
 
 
 def test_header_and_binding_agree(lib):
+    """Every function include/jmid_hip.h declares is bound, and exported by the flavour the header says: the production
+    library the product loads exports the ABI proper and NOT the jmid_dbg_* diagnostics; the diagnostics flavour (what the tests
+    load: tests/conftest.py) exports both."""
+    from safe_interactive_crowdnav_amd.build import LIB, LIB_DIAG
     names = declared_functions()
     assert len(names) >= 20
-    assert sorted(_lib.SIGNATURES) == names
-    for n in names:
-        assert hasattr(lib, n), f"libjmid_hip.so does not export {n}"
+    assert sorted(list(_lib.SIGNATURES) + list(_lib.DIAG_SIGNATURES)) == names
+    assert all(n.startswith("jmid_dbg_") for n in _lib.DIAG_SIGNATURES) and not any(n.startswith("jmid_dbg_") for n in _lib.SIGNATURES)
+    prod, diag = C.CDLL(LIB), C.CDLL(LIB_DIAG)
+    prod.jmid_version.restype = diag.jmid_version.restype = C.c_char_p
+    assert b"diagnostics" in diag.jmid_version() and b"diagnostics" not in prod.jmid_version()
+    for n in _lib.SIGNATURES:
+        assert hasattr(prod, n) and hasattr(diag, n), f"the library does not export {n}"
+    for n in _lib.DIAG_SIGNATURES:
+        assert hasattr(diag, n), f"libjmid_hip_diag.so does not export {n}"
+        assert not hasattr(prod, n), f"the production library exports the diagnostics entry point {n}"
+    assert lib.has_diagnostics          # the flavour this test session runs on
 
 
 def test_version_and_class_names(lib):

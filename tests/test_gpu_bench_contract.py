@@ -12,6 +12,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODE_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline", "kernels", "sweep_metrics")
 
 
+# bench.py is the product's measurement: it runs on the PRODUCTION library, not on the diagnostics flavour the tests load
+PROD_ENV = {k: v for k, v in os.environ.items() if k != "JMID_LIB"}
+
+
 def _one_json_line(out):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -22,7 +26,7 @@ def _one_json_line(out):
 def test_bench_json_contract():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
                           "--episodes-per-gpu", "6", "--chunk", "2", "--cpu-episodes", "3"],
-                         capture_output=True, text=True, timeout=600, cwd=REPO)
+                         capture_output=True, text=True, timeout=600, cwd=REPO, env=PROD_ENV)
     j = _one_json_line(out)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -79,7 +83,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(PROD_ENV, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
                           "--gpus", "2", "--steps", "2", "--warmup", "1", "--episodes-per-gpu", "5", "--chunk", "2",
@@ -98,7 +102,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
 def test_bench_launched_plainly_spawns_its_own_ranks():
     """`python bench.py --gpus 2` without torch.distributed.run (how the driver launched the 1-GPU bench): bench.py starts the
     two ranks itself, rank 0 prints the one JSON line."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env = {k: v for k, v in PROD_ENV.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
                           "--episodes-per-gpu", "3", "--dist-backend", "gloo", "--device", "0", "--modes", "f16mx",
                           "--cpu-episodes", "0", "--no-profile"],
@@ -116,7 +120,7 @@ def test_bench_collectives_run_on_rccl_with_one_rank():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(PROD_ENV, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
                           "--gpus", "1", "--steps", "2", "--warmup", "1", "--episodes-per-gpu", "4", "--force-dist",
