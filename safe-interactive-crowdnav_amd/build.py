@@ -41,7 +41,7 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
     # (op_sel:[0,1] op_sel_hi:[1,0]) for float4 arithmetic, and on MI355X such an instruction returns wrong values in
     # lanes 48-63 when its wave shares a CU with waves of the LDS-DMA attention kernel (tools/concurrency_probe8.hip: 397 of
     # 400 overlaps, 0 with straight selects or other co-runners) - the cause of the run-to-run variation with several
-    # chunks in flight.  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
+    # chunks in flight (docs/NOTEBOOK.md section 3).  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
     # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
            "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else []) + \

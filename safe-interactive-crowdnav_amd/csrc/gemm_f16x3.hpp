@@ -9,7 +9,7 @@
 // (fp32 inputs: 6e-8).  Peak is 1/3 of the dense fp16 MFMA rate = 833 TFLOP/s, 5.3x the exact-fp32 MFMA path.
 // JMID_PREC_F16X2 (template parameter X2 of every kernel here): the Alo.Whi term is left out - the activation enters
 // as fp16, the weights stay exact - and the A_lo images are neither copied into LDS nor written by the epilogues
-// whose consumer is such a GEMM.  Two MFMAs per product, 1250 TFLOP/s peak; parity in DESIGN.md section 3.
+// whose consumer is such a GEMM.  Two MFMAs per product, 1250 TFLOP/s peak; parity in docs/NOTEBOOK.md section 3.
 //
 // Operand fragments are 8 consecutive k per lane (lanes 0-31: k 0-7, lanes 32-63: k 8-15 of each 16-wide step);
 // A and W use the same per-lane k assignment, which is all the instruction requires.
@@ -1068,7 +1068,7 @@ inline hipError_t launch_gemm_h_dma256x256(const GemmHArgs& g, hipStream_t st) {
 //   * NO block scales: with literal zero scale operands the compiler emits the plain v_mfma_f32_32x32x64_f8f6f4.  The scaled
 //     form is a PAIR (v_mfma_ld_scale_b32 + MFMA), and a wave of another kernel on the same SIMD (out_ddim_kernel next to the
 //     166-VGPR 64-row GEMM + LayerNorm kernel) made such pairs compute with a wrong scale now and then: tile-wide 1-ulp
-//     differences from run to run (tools/concurrency_probe9.hip).
+//     differences from run to run (tools/concurrency_probe9.hip, docs/NOTEBOOK.md section 3).
 // The instruction sums over its 64 k in any order as long as A and W agree: byte p of lane (row, h) is k = 16 (p / 8) + 8 h + p % 8
 // of the k64 block for both, i.e. exactly the fp16 fragments' assignment.
 // W8 layout: [K / 64][N / 32][2 pieces][64 lanes][16 bytes]: the 32-column blocks of a workgroup tile are contiguous per k64

@@ -77,7 +77,7 @@ def test_product_never_imports_oracle():
 
 def test_device_code_holds_no_packed_fp32_instructions(tmp_path):
     """build.py compiles with -packed-fp32-ops: v_pk_{add,mul,fma}_f32 with crossed operand selects go wrong in lanes 48-63
-    when their wave shares a CU with the LDS-DMA attention kernel (tools/concurrency_probe8.hip), and
+    when their wave shares a CU with the LDS-DMA attention kernel (docs/NOTEBOOK.md section 3, tools/concurrency_probe8.hip), and
     hipcc forms exactly those for float4 arithmetic.  The shipped library must not contain any."""
     import shutil
     import subprocess

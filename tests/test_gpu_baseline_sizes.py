@@ -194,7 +194,7 @@ def test_cfg5_one_gpu_shard_matches_oracle_on_every_chunk(cfg5, precision):
 @pytest.mark.parametrize("precision", SPLIT_MODES)
 def test_cfg3_chunks_in_flight_do_not_change_a_bit(cfg3, precision):
     """256 episodes at full width with 1, 2 (default), 3 and 4 chunks in flight on separate streams: the same bits, call after
-    call.  This is the regression test of the round-1 lane disturbance: a row-wise kernel next to the other
+    call.  This is the regression test of the round-1 lane disturbance (docs/NOTEBOOK.md section 3): a row-wise kernel next to the other
     lane's attention workgroups computed wrong values in lanes 48-63 through packed-fp32 instructions with crossed operand
     selects (tools/concurrency_probe8.hip); the library is built without packed-fp32 instructions."""
     eng = cfg3["eng"]

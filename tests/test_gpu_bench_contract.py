@@ -78,7 +78,7 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     """The N > 1 path of bench.py, for real, on the one GPU of the test box: two ranks (both on device 0) launched the
     way the driver launches them, host collectives over gloo.  Exercises process-group init, per-rank seeds and episode
     shards, the barrier / MAX all-reduce bracketing of the timed region, gather_metrics of device tensors in episode
-    order, and the rank != 0 exit.  (The RCCL flavour of the same calls needs two GPUs)"""
+    order, and the rank != 0 exit.  (The RCCL flavour of the same calls needs two GPUs; docs/NOTEBOOK.md section 5.)"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

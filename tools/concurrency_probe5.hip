@@ -1,4 +1,4 @@
-// Which instruction class of embed_kernel is the one that goes wrong next to the attention kernel?
+// Which instruction class of embed_kernel is the one that goes wrong next to the attention kernel (docs/NOTEBOOK.md section 3)?
 // Victims built from the classes its ISA holds and the round-1 synthetic victims did not: packed fp32 VALU (v_pk_*_f32),
 // integer division by run-time values (RowMap::ea: v_rcp_iflag / v_mul_hi chains), the hi/lo fp16 split, and the real
 // embed_kernel as the control.  Co-runner: the F16X2 attention instance (the one with the higher disturbance rate).

@@ -1,4 +1,4 @@
-// Source-level bisect of embed_kernel as the victim of the attention kernel: the disturbance is always
+// Source-level bisect of embed_kernel as the victim of the attention kernel (docs/NOTEBOOK.md section 3): the disturbance is always
 // ONE component (e = 2) of the 4-wide result in lanes 48-63 of a wave holding a plausible stale-looking value - a VALU result
 // not written for the last 16-lane group.  Which construct of the kernel makes it vulnerable?
 //   bit 0  32-bit index arithmetic (no 64-bit division: no EXEC-masked slow path in the loop head)

@@ -1,4 +1,4 @@
-// Second round of the co-residency hunt: with the packed-fp32 instructions gone, which kernel next to which
+// Second round of the co-residency hunt (docs/NOTEBOOK.md section 3): with the packed-fp32 instructions gone, which kernel next to which
 // co-runner still computes differently?  Victim: the production embed_kernel (built without packed fp32, like the library).
 // Co-runners: the attention kernel, the F16MX GEMM + LayerNorm kernel (64- and 128-row tiles), the F16MX 256 x 256 GEMM.
 // Finding: the F16MX GEMM + LayerNorm kernel with 64-row tiles (166 VGPRs: waves of another kernel fit on its SIMDs) computed

@@ -1,4 +1,4 @@
-"""Prints the figures DESIGN.md section 4b / README / profiles/README quote, from profiles/<round>_* and gpurun_out/<round>/.
+"""Prints the figures docs/NOTEBOOK.md section 4b / README / profiles/README quote, from profiles/<round>_* and gpurun_out/<round>/.
 python tools/doc_numbers.py [r02]"""
 import csv, json, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r02"

@@ -1,5 +1,5 @@
 // What do the block-scaled MX matrix instructions sustain on FRESH RANDOM operands (power-limited clock), next to the
-// f16 MFMA the split products use now?  Planning probe for DESIGN.md section 7 (correction terms on a narrower format).
+// f16 MFMA the split products use now?  Planning probe for docs/NOTEBOOK.md section 7 (correction terms on a narrower format).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_mx_peak.hip -o build/mfma_mx_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>

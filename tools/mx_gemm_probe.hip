@@ -1,4 +1,4 @@
-// Planning probe for DESIGN.md section 7 item 1: what would the 256x256 split-fp16 GEMM gain if the W_lo correction term
+// Planning probe for docs/NOTEBOOK.md section 7 item 1: what would the 256x256 split-fp16 GEMM gain if the W_lo correction term
 // ran on the block-scaled FP8 matrix path?  TIMING ONLY (operands are random bytes, results are meaningless): the K loop of
 // gemm_f16x3_dma256x256_kernel<.., X2 = true> with the same DMA bytes per k64 (A_hi, W_hi as today; an fp8 image of A_hi
 // and an fp8 image of W_lo are one 8 KB panel per k64 each - issued every other k32 tile in place of the W_lo / A_lo

@@ -1,4 +1,4 @@
-// Numerics of a split product whose two correction terms run on the block-scaled MX fp8 matrix path:
+// Numerics of a split product whose two correction terms run on the block-scaled MX fp8 matrix path (docs/NOTEBOOK.md section 7):
 //   D = A_hi . W_hi  [fp16 MFMA]  +  fp8(A_hi) . mx8(W_lo)  +  mx8(A_lo) . fp8(W_hi)  [v_mfma_scale_f32_32x32x64_f8f6f4]
 // on a 32 x 32 tile with K = 512 (the d_model contraction), against fp64, next to the pure-fp16 variants of today.
 // Operands are packed per lane on the host (layouts: gemm_f16x3.hpp header for f16, tools/mfma_mx_layout.hip for MX).

@@ -9,7 +9,8 @@ export TMPDIR=/tmp
 export JMID_PREC=${JMID_PREC:-f16x2}
 O=gpurun_out/pmc; mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
-  timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$c -- python tools/step_only.py 51 > $O/run_$c.log 2>&1
+  # (-k 5: a process that aborts under rocprofv3 hangs in its signal handler; one bad pass must not eat the call's time limit)
+  timeout -k 5 240 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/$c -- python tools/step_only.py 51 > $O/run_$c.log 2>&1 || { echo "pass $c failed"; tail -3 $O/run_$c.log; exit 1; }
 done
 python - <<'PY'
 import collections, csv, glob, json, os

@@ -2,38 +2,38 @@
 # All measurements profiles/ holds for a round, in one GPU-box call (about 15 minutes).  Output: gpurun_out/$R/
 #   R=r02 tools/round_profile.sh ; then python tools/update_profiles.py r02
 export TMPDIR=/tmp
-R=${R:-r02}
+R=${R:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 # PMC first: HBM bytes and MFMA busy per production kernel over one whole call, per mode; the summaries go into profiles/ of
 # this copy right away, so that the bench lines below quote THEM (file name + git blob hash of exactly these bytes)
 for m in f16mx f16x2 f16x3; do
-  JMID_PREC=$m tools/pmc_call.sh > $O/pmc_$m.log 2>&1
+  JMID_PREC=$m tools/pmc_call.sh > $O/pmc_$m.log 2>&1 || { echo "PMC pass failed ($m)"; cat $O/pmc_$m.log; exit 1; }
   cp gpurun_out/pmc/pmc_call_$m.json $O/
   cp gpurun_out/pmc/pmc_call_$m.json profiles/${R}_pmc_call_$m.json
 done
 # default bench (BASELINE configs[2]), all split modes measured identically, parity sample over all chunks
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
-timeout 300 python bench.py --precision f32 --modes f32 --cpu-episodes 0 --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
-timeout 300 python bench.py --workload cfg2 --cpu-episodes 0 --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
-timeout 300 python bench.py --workload cfg4 --cpu-episodes 0 --steps 3 > $O/bench_cfg4.json 2>/dev/null
-timeout 400 python bench.py --workload cfg5 --cpu-episodes 0 --steps 2 > $O/bench_cfg5_1gpu.json 2>/dev/null
-timeout 300 python bench.py --net imid --cpu-episodes 0 --steps 2 > $O/bench_cfg3_imid.json 2>/dev/null
-timeout 300 python bench.py --scenes orca --cpu-episodes 4 --steps 2 > $O/bench_cfg3_orca.json 2>/dev/null
+timeout 300 python bench.py --precision f32 --modes f32 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
+timeout 300 python bench.py --workload cfg2 --cpu-episodes 0 --no-e2e --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
+timeout 300 python bench.py --workload cfg4 --cpu-episodes 0 --no-e2e --steps 3 > $O/bench_cfg4.json 2>/dev/null
+timeout 400 python bench.py --workload cfg5 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg5_1gpu.json 2>/dev/null
+timeout 300 python bench.py --net imid --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_imid.json 2>/dev/null
+timeout 300 python bench.py --scenes orca --cpu-episodes 4 --no-e2e --steps 2 > $O/bench_cfg3_orca.json 2>/dev/null
 # episodes per call sweep (weak-scaling unit), both modes
 for e in 1 2 4 8 16 32 52 104 256 512; do
-  timeout 300 python bench.py --cpu-episodes 0 --episodes-per-gpu $e --steps 2 --warmup 1 --no-profile 2>/dev/null | python -c "
+  timeout 300 python bench.py --cpu-episodes 0 --no-e2e --episodes-per-gpu $e --steps 2 --warmup 1 --no-profile 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print('episodes/call', $e, {m: (v['value'], v['ms_per_step']) for m, v in d['modes'].items()})"
 done > $O/episode_sweep.log
 # rocprofv3 kernel stats of one step on a 51-episode chunk, per mode
 for m in f16mx f16x2 f16x3; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --no-e2e --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
   find $O/prof_$m -name "*kernel_stats.csv" -exec cp {} $O/${m}_kernel_stats.csv \;
   rm -rf $O/prof_$m
 done
 # single-scene kernel stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --workload cfg2 --modes f16mx --steps 20 --warmup 3 --cpu-episodes 0 --no-profile > $O/prof_bench_cfg2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --workload cfg2 --modes f16mx --steps 20 --warmup 3 --cpu-episodes 0 --no-e2e --no-profile > $O/prof_bench_cfg2.log 2>&1
 find $O/prof_ss -name "*kernel_stats.csv" -exec cp {} $O/cfg2_f16mx_kernel_stats.csv \;
 rm -rf $O/prof_ss
 # reproducibility soak of the default path + the documented multi-lane disturbance

@@ -1,4 +1,4 @@
-// Is the run-to-run variation seen with two chunk lanes a MEMORY-VISIBILITY effect rather than a
+// Is the run-to-run variation seen with two chunk lanes (docs/NOTEBOOK.md section 3) a MEMORY-VISIBILITY effect rather than a
 // corrupted register?  The round-1 probes saw "one 16-lane group of one register" of a row-wise kernel go wrong next to
 // the attention kernel: 16 lanes x 8-byte stores = exactly one 128-byte L2 line, and the errors in the real pipeline
 // were 1e-4..1e-2 (a value of the PREVIOUS denoise step looks like that; a corrupted register would not).
