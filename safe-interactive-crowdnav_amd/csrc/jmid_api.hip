@@ -76,7 +76,7 @@ struct jmid_ctx {
     // chunk's kernels and its bandwidth-bound kernels overlap with the other chunk's MFMA kernels (+2-4 % traj/s), and the
     // results are bit-identical to one chunk in flight.  (They were not in round 1: a row-wise kernel sharing a CU with
     // attention workgroups of the other lane computed a few wrong values per run - packed-fp32 instructions with crossed
-    // operand selects, which the library is no longer built with; build.py)
+    // operand selects, which the library is no longer built with; build.py, docs/NOTEBOOK.md section 3.)
     int lanes = 2;
     Tuning tune;         // jmid_set_tuning knobs of THIS handle (installed per call by TuneScope)
     hipStream_t caller_stream = nullptr;   // stream device-mode buffers are ordered on (jmid_set_caller_stream)

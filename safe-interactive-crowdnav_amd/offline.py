@@ -23,8 +23,10 @@ from .engine import JmidEngine
 
 def sample(engine: JmidEngine, num_points: int, context, sample: int, bestof: bool, point_dim: int = 2,
            flexibility: float = 0.0, ret_traj: bool = False, sampling: str = "ddpm", step: int = 100,
-           precision: str = "f32") -> Tuple[np.ndarray, int, int, int, int]:
-    """-> (vel [sample, B, num_points, 2] float32, number_of_steps, 0, 0, 0)   (diffusion.py:603-613)."""
+           precision: str = "f32", _integrate=None) -> Tuple[np.ndarray, int, int, int, int]:
+    """-> (vel [sample, B, num_points, 2] float32, number_of_steps, 0, 0, 0)   (diffusion.py:603-613).
+    ``_integrate`` = (p0 [B, 2], dt): used by ``generate`` - the same call also integrates on the device (integrate_kernel) and
+    the first element of the result is the positions instead."""
     if point_dim != 2:
         raise ValueError("point_dim must be 2")
     if ret_traj:
@@ -44,9 +46,14 @@ def sample(engine: JmidEngine, num_points: int, context, sample: int, bestof: bo
             if t > 1:
                 z[k, i] = torch.randn([B, num_points, point_dim])
     ctx_e = ctx.unsqueeze(0).expand(sample, B, ctx.shape[1]).contiguous().numpy()
+    number_of_steps = sample * (engine.schedule.num_steps // stride + 1)
+    if _integrate is not None:      # every sample is an "episode" of B agents with K = 1: p0 repeats per sample
+        p0 = np.ascontiguousarray(np.broadcast_to(np.asarray(_integrate[0], dtype=np.float32)[None], (sample, B, 2)))
+        _, pos = engine.denoise(x_T.numpy(), ctx_e, p0, dt=float(_integrate[1]), precision=precision, want_vel=False,
+                                z=z.numpy() if sampling == "ddpm" else None)
+        return pos.reshape(sample, B, num_points, 2), number_of_steps, 0, 0, 0
     vel, _ = engine.denoise(x_T.numpy(), ctx_e, None, precision=precision, want_pos=False,
                             z=z.numpy() if sampling == "ddpm" else None)
-    number_of_steps = sample * (engine.schedule.num_steps // stride + 1)
     return vel.reshape(sample, B, num_points, 2), number_of_steps, 0, 0, 0
 
 
@@ -55,8 +62,6 @@ def generate(engine: JmidEngine, context, p0, dt: float, num_points: int, sample
     """Tail of ``AutoEncoder.generate``: ``sample`` + ``SingleIntegrator.integrate_samples``
     (``single_integrator.py:290-321``): pos = cumsum(vel, T) * dt + p0[b].  ``context`` [B, ctx] is the encoder
     output (``JmidEngine.encode``), ``p0`` [B, 2] the current positions.  -> (pos [sample, B, T, 2], steps, 0, 0, 0)."""
-    vel, nsteps, a, b, c = sample(engine, num_points, context, sample_n, bestof, flexibility=flexibility,
-                                  sampling=sampling, step=step, precision=precision)
-    p0 = np.asarray(p0, dtype=np.float32)
-    pos = np.cumsum(vel, axis=2, dtype=np.float32) * np.float32(dt) + p0[None, :, None, :]
-    return pos.astype(np.float32), nsteps, a, b, c
+    pos, nsteps, a, b, c = sample(engine, num_points, context, sample_n, bestof, flexibility=flexibility,
+                                  sampling=sampling, step=step, precision=precision, _integrate=(p0, dt))
+    return np.asarray(pos, dtype=np.float32), nsteps, a, b, c

@@ -225,6 +225,29 @@ def test_offline_sample_matches_reference_golden(case, precision):
     assert d <= ADE_GATE
 
 
+def test_offline_generate_integrates_on_the_device():
+    """offline.generate = sample + SingleIntegrator.integrate_samples (single_integrator.py:290-321): the positions come from
+    integrate_kernel in the same call and equal dt * cumsum(vel) + p0 of offline.sample on the same RNG draws."""
+    from safe_interactive_crowdnav_amd import offline
+    case = sorted(glob.glob(os.path.join(GOLDEN, "sample_*.npz")))[0]
+    z = np.load(case)
+    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    step0, samp0 = eng.step, eng.sampling
+    B = z["ctx"].shape[0]
+    p0 = np.random.default_rng(4).standard_normal((B, 2)).astype(np.float32)
+    kw = dict(flexibility=float(z["flexibility"]), sampling=str(z["sampling"]), step=int(z["step"]), precision="f32")
+    try:
+        torch.manual_seed(int(z["dseed"]))
+        vel = offline.sample(eng, int(z["T"]), z["ctx"], int(z["n_sample"]), bool(z["bestof"]), **kw)[0]
+        torch.manual_seed(int(z["dseed"]))
+        pos, nsteps, a, b, c = offline.generate(eng, z["ctx"], p0, 0.4, int(z["T"]), int(z["n_sample"]), bool(z["bestof"]), **kw)
+    finally:
+        eng.set_step(step0, samp0)
+    assert pos.shape == vel.shape and pos.dtype == np.float32 and nsteps == int(z["nsteps"])
+    ref = np.cumsum(vel.astype(np.float64), axis=2) * 0.4 + p0[None, :, None, :]
+    np.testing.assert_allclose(pos, ref, rtol=0, atol=2e-6 * max(1.0, np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("precision", SPLIT_MODES)
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w32_a5k20t12_s50.npz"])
 def test_fused_vt_epilogue_equals_transpose_kernel(case, precision):
