@@ -377,12 +377,22 @@ def test_split_modes_hold_parity_when_attention_is_peaked():
     ctx = torch.randn([E, A, 256], generator=g).cuda()
     x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
     p0 = (4 * torch.randn([E, A, 2], generator=g)).cuda()
-    ref = eng.denoise(x_T, ctx, p0, precision="f32")[1].cpu().numpy()
-    err = {m: ade(eng.denoise(x_T, ctx, p0, precision=m)[1].cpu().numpy(), ref) for m in SPLIT_MODES}
+    vel32, ref = (t.cpu().numpy() for t in eng.denoise(x_T, ctx, p0, precision="f32"))
+    out = {m: eng.denoise(x_T, ctx, p0, precision=m) for m in SPLIT_MODES}
+    err = {m: ade(out[m][1].cpu().numpy(), ref) for m in SPLIT_MODES}
     print("peaked attention: mean ADE vs exact fp32", err)
     assert err["f16x3"] <= 1e-5, err
     assert err["f16x2"] <= ADE_GATE, err
     assert err["f16mx"] <= ADE_GATE, err
+    # ... and against the ORACLE (not only the library's own fp32 mode) on the first episode: the large-logit case is the one a
+    # trained network presents to the fp16 / bf8 logit corrections
+    with torch.no_grad():
+        oref = O.denoise(w.tensors, ctx[0].cpu(), x_T[0].cpu(), sample=K, step=50, joint=True).reshape(K * A, T, 2).numpy()
+    oerr = {"f32": ade(vel32[0].reshape(K * A, T, 2), oref),
+            **{m: ade(out[m][0][0].cpu().numpy().reshape(K * A, T, 2), oref) for m in SPLIT_MODES}}
+    print("peaked attention: mean velocity ADE vs the oracle (episode 0)", oerr)
+    assert oerr["f32"] <= 1e-5 and oerr["f16x3"] <= 1e-5, oerr
+    assert oerr["f16x2"] <= ADE_GATE and oerr["f16mx"] <= ADE_GATE, oerr
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
