@@ -41,7 +41,9 @@ __device__ __forceinline__ void split_f32(float v, half_t& hi, half_t& lo) {
     lo = (half_t)(v - (float)hi);
 }
 __device__ __forceinline__ void split_f32_unscaled(float v, half_t& hi, half_t& lo) { split_f32(v, hi, lo); }
-// bf8 (e5m2) image of one fp16 value: its top byte after rounding to nearest
+// bf8 (e5m2) image of one fp16 value: its top byte after rounding to nearest.  The carry of the rounding turns magnitudes from
+// 61440 (0x7B80) on into 0x7C = Inf: every producer of a split plane flags |v| > kHalfMax = 60000 (0x7B53) as JMID_ERANGE, so an
+// operand that reaches this conversion is below the carry.
 __device__ __forceinline__ unsigned char bf8_of_f16(half_t v) {
     return (unsigned char)((__builtin_bit_cast(unsigned short, v) + 0x80u) >> 8);
 }
