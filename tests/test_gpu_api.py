@@ -156,3 +156,45 @@ def test_tuning_knobs_belong_to_their_handle():
             a.set_tuning(key, 1)
     a.close()
     b.close()
+
+
+def test_two_handles_run_concurrently_from_two_host_threads():
+    """Several handles may share a GPU and be driven from separate host threads (an iMID and a JMID predictor, two
+    policies).  ctypes drops the GIL for the duration of a call, so the two calls below really overlap: different nets, different
+    modes, different knobs - each thread gets, every time, the bits its engine produces alone.  (Exercises the per-device
+    once-only function attributes under their mutex, the thread-local tuning pointer and the per-handle streams / workspaces.)"""
+    import threading
+    import numpy as np
+    import torch
+    from safe_interactive_crowdnav_amd.engine import JmidEngine
+    from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
+    g = torch.Generator().manual_seed(8)
+    jobs = []
+    for joint, prec, E, knob in ((True, "f16mx", 3, ("lanes", 1)), (False, "f16x3", 5, ("lanes", 3))):
+        eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 11 + int(joint)), joint=joint, step=5)
+        eng.set_tuning(*knob)
+        ctx = torch.randn([E, 5, 256], generator=g).numpy()
+        x_T = torch.randn([E, 100, 12, 2], generator=g).numpy()
+        p0 = torch.randn([E, 5, 2], generator=g).numpy()
+        alone = [np.array(t) for t in eng.denoise(x_T, ctx, p0, precision=prec)]
+        jobs.append((eng, ctx, x_T, p0, prec, alone))
+    errors, start = [], threading.Barrier(2)
+
+    def work(eng, ctx, x_T, p0, prec, alone):
+        try:
+            start.wait()
+            for _ in range(12):
+                vel, pos = eng.denoise(x_T, ctx, p0, precision=prec)
+                np.testing.assert_array_equal(np.asarray(vel), alone[0])
+                np.testing.assert_array_equal(np.asarray(pos), alone[1])
+        except Exception as e:          # noqa: BLE001 - reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for eng, *_ in jobs:
+        eng.close()
+    assert not errors, errors
