@@ -198,6 +198,32 @@ def forecaster_e2e(weights, dev_id, modes):
                                  "update_state_hists + predict_ret_best() per call, host NumPy scene build included",
                      "topk": "joint KDE on the device (jmid_topk)" if k < K else "not needed (all samples returned)",
                      "modes": res}
+    # the batched form of the same call: predict_ret_best() for 64 independent episodes per predict_batch()
+    # at the shipped operating point - vectorised host batch builder, one encode + denoise + jmid_topk per cluster size
+    from safe_interactive_crowdnav_amd.forecaster import predict_batch
+    from safe_interactive_crowdnav_amd.engine import JmidEngine
+    Eb, N, K, k, H, F = 64, 3, 100, 15, 8, 6
+    p0 = rng.uniform(-1.0, 1.0, (Eb, 1, N, 2))
+    v = rng.uniform(-0.4, 0.4, (Eb, 1, N, 2))
+    hum = p0 + v * 0.25 * np.arange(F)[None, :, None, None]
+    rob = np.stack([np.zeros(F), -1.5 + 0.05 * np.arange(F)], axis=-1)[None].repeat(Eb, axis=0)
+    eng = JmidEngine(weights, joint=True, device_id=dev_id, step=2)
+    res = {}
+    for m in modes:
+        kw = dict(num_samples=K, num_ret_samples=k, horizon=H, time_step=0.25, precision=m)
+        for _ in range(2):
+            predict_batch(eng, hum, rob, range(Eb), **kw)
+        reps, t0 = 5, time.perf_counter()
+        for _ in range(reps):
+            fc, lw, inc = predict_batch(eng, hum, rob, range(Eb), **kw)
+        wall = (time.perf_counter() - t0) / reps
+        assert fc.shape == (Eb, N, k, H + 1, 2) and lw.shape == (Eb, N, k)
+        res[m] = {"ms_per_call": round(1e3 * wall, 3), "ms_per_episode": round(1e3 * wall / Eb, 4),
+                  "episodes_per_s": round(Eb / wall, 1)}
+    eng.close()
+    out["shipped_batched"] = {"workload": f"predict_batch(): {Eb} episodes per call, each N={N}, K={K} -> {k}, H={H}, 2 denoise steps "
+                                          "(x_T drawn per episode from its own torch generator, as the per-episode class does)",
+                              "topk": "joint KDE on the device, all episodes of a cluster size in one jmid_topk call", "modes": res}
     return out
 
 

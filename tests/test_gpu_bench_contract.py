@@ -60,9 +60,13 @@ def test_bench_json_contract():
     assert set(j["single_scene"]["modes"]) == {"f16x3", "f16x2", "f16mx"}
     # the class surface, host + device, the way the MPC calls it: cfg2 and the reference's shipped operating point
     fe = j["forecaster_e2e"]
-    assert set(fe) == {"cfg2", "shipped"}
+    assert set(fe) == {"cfg2", "shipped", "shipped_batched"}
+    for m, t in fe["shipped_batched"]["modes"].items():          # predict_batch(): 64 episodes per call
+        assert t["ms_per_call"] > 0 and abs(t["ms_per_episode"] * 64 - t["ms_per_call"]) < 0.01 * t["ms_per_call"] + 0.01
     for name, v in fe.items():
         assert set(v["modes"]) == {"f16x3", "f16x2", "f16mx"}
+        if name == "shipped_batched":
+            continue
         for m, t in v["modes"].items():
             assert t["ms_per_call"] > 0 and t["erange_fallbacks"] == 0
             assert abs(t["host_scene_ms"] + t["device_ms"] + t["topk_ms"] + t["host_assemble_ms"] - t["ms_per_call"]) < 0.5 * t["ms_per_call"]
