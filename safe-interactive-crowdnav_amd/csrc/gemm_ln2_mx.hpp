@@ -10,7 +10,9 @@
 //   * the residual stream's lo plane is a BYTE plane in this mode (bf8 of fp16(x - hi): hi + lo carries x to ~14 bits, and the
 //     only readers of X_lo in F16X2 / F16MX are these LayerNorms - the GEMMs take X_hi; ADE against exact fp32 1.163e-5 vs
 //     1.158e-5 m): 3 instead of 4 bytes per element each way, as 16-byte (hi) and 8-byte (lo) accesses per lane;
-//   * bf8(W_lo) goes L2 -> registers directly (it is wave-private: staging it in LDS bought nothing), so the rings are 60 - 72 KB.
+//   * bf8(W_lo) of a k64 block is wave-private: in the 128-row shape it comes through the LDS-DMA ring like the fp16 operands
+//     (ordinary loads next to DMA copies make hipcc wait vmcnt(0) before the fp8 MFMAs: 121 -> 99 us per launch), in the 64-row
+//     shape - whose 66 KB budget has no room for it - straight into registers.
 // The row statistics are summed in a fixed order that both tile shapes and add_ln2_kernel (the unfused path for launches too
 // small to fill the chip) reproduce, so fused and unfused rows stay bit-identical and a chunk plan cannot change a result:
 //     partial(c, h) = sum over (j, p, e) in that order of v[64 c + 32 j + 16 p + 8 h + e]         c = 0..7, j, p, h = 0..1, e = 0..7
