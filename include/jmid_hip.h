@@ -62,7 +62,8 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     take the same path (bf8 images of K from the QKV GEMM, of Q made in the kernel), and P.V is one MFMA per
  *                     product: P_hi . V_hi with P rounded to nearest - the one rounding every other activation of the mode gets.
  *                     ~20 % more trajectories per second than F16X2.
- *                     Bit-identical across batch sizes / chunk plans like the other modes.  The default of the Python class.
+ *                     Bit-identical across chunk plans like the other modes.  What bench.py quotes; an explicit opt-in of the Python
+ *                     class (precision="f16mx"), whose default is JMID_PREC_F16X3.
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3, JMID_PREC_F16MX = 4 };
 
@@ -167,13 +168,15 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
  * get_most_likely_samples (sicnav_diffusion/JMID/mid_sim_wrapper.py:14-169, the joint branch :20-21 the predictor always takes;
  * called from predict_ret_best when num_ret_samples < K, :487-492), which the reference runs on its GPU when it has one (:26-30).
  *   pos   [E, K, A, T, 2]  integrated sample trajectories (jmid_denoise's pos_out layout), or NULL: the positions of the most
- *                          recent jmid_denoise on this handle (same E, A, K, T, called with p0), still resident in the workspace -
- *                          the samples then never leave the GPU
+ *                          recent jmid_denoise on this handle (same E, A, K, T, called with p0) - the samples then never leave
+ *                          the GPU.  They are forgotten (JMID_EINVAL here) when that call returned JMID_ERANGE and by any later
+ *                          host-mode jmid_encode / jmid_episode_metrics or denoise call on the handle, which reuse the workspace
  *   bw    [T] KDE bandwidth per horizon step, exp(linspace(ln .01, ln .1, T)) as the reference computes it (:26-30), or NULL
  *                          (computed in the library)
  *   sel   [E, A, k, T, 2]  the kept samples in ascending likelihood (the reference's argsort(...)[-k:], :117-121)
  *   logw  [E, A, k]        their renormalised log-weights, the same row for every agent (:139-151)
- * fp64 inside (A <= 32, K <= 1024); exact ties are broken by sample index (torch.argsort's tie order is not reproduced). */
+ * fp64 inside (A <= 32, K <= 1024, T <= 24: JMID_EINVAL beyond); exact ties are broken by sample index (torch.argsort's tie
+ * order is not reproduced); non-finite totals rank lowest. */
 int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* pos, const float* bw, float* sel, float* logw,
               int mem);
 

@@ -167,7 +167,9 @@ __global__ __launch_bounds__(KDE_THREADS) void kde_select_kernel(KdeArgs g) {
     for (int i = tid; i < K; i += KDE_THREADS) {
         double s = 0.0;
         for (int h = 0; h < T; ++h) s += g.ll[((size_t)e * T + h) * K + i];
-        tot[i] = s;
+        // a NaN total (non-finite positions, a covariance whose Cholesky factor fails) ranks lowest: the order below stays
+        // total, every rank is taken exactly once and keep[] is fully written (the reference returns NaNs in that case)
+        tot[i] = s == s ? s : -INFINITY;
     }
     __syncthreads();
     for (int i = tid; i < K; i += KDE_THREADS) {
@@ -199,10 +201,13 @@ __global__ __launch_bounds__(KDE_THREADS) void kde_select_kernel(KdeArgs g) {
     }
 }
 
+// do the whitened points of one (episode, horizon step) fit in LDS next to the [d, d] algebra?  (otherwise KdeArgs::Y)
+inline bool kde_y_in_lds(int A, int K) { return kde_lds_bytes(2 * A, K, true) <= 96 * 1024; }
+
 inline hipError_t launch_kde(const KdeArgs& g0, hipStream_t st) {
     KdeArgs g = g0;
     const int d = 2 * g.A;
-    g.y_in_lds = kde_lds_bytes(d, g.K, true) <= 96 * 1024;
+    g.y_in_lds = kde_y_in_lds(g.A, g.K);
     const size_t lds = kde_lds_bytes(d, g.K, g.y_in_lds != 0);
     static DevSeen seen;
     if (auto once_ = first_use_on_device(seen))

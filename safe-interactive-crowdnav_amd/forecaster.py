@@ -63,6 +63,8 @@ _WEIGHTS_CACHE: Dict[tuple, JMIDWeights] = {}     # (path, size, mtime_ns, dims)
 _CACHE_LOCK = Lock()            # guards the three caches above (forecasters may be built from several threads)
 ERANGE_FALLBACKS = 0            # calls of this process that were repeated in "f32" after JMID_ERANGE
 SELF_CHECK_DOWNGRADES = 0       # instances whose opt-in precision was replaced by "f16x3" by the first-call self check
+# what HumanTrajectoryForecasterSim's keyword arguments default to (safe_interactive_crowdnav_amd.install(**defaults) edits it)
+DEFAULTS = {"device_id": 0, "precision": "f16x3", "rng_compat": "auto", "self_check": False, "device_topk": True}
 
 
 def load_weights(model_path: str, dims: NetDims) -> JMIDWeights:
@@ -129,8 +131,15 @@ class _ModelInfo:
 
 class HumanTrajectoryForecasterSim(ForecasterSimSuper):
     def __init__(self, env_config=None, mid_config_file=None, *, weights: Optional[JMIDWeights] = None,
-                 device_id: int = 0, precision: str = "f16x3", rng_compat: str = "auto", self_check: bool = False,
-                 self_check_tol: float = 2e-5, device_topk: bool = True):
+                 device_id: Optional[int] = None, precision: Optional[str] = None, rng_compat: Optional[str] = None,
+                 self_check: Optional[bool] = None, self_check_tol: float = 2e-5, device_topk: Optional[bool] = None):
+        # keyword arguments left at None take the process-wide defaults (``DEFAULTS``; ``install(**defaults)`` sets them for
+        # a caller that constructs the class with the reference's two positional arguments only, sicnav_acados.py:998-1000)
+        device_id = DEFAULTS["device_id"] if device_id is None else device_id
+        precision = DEFAULTS["precision"] if precision is None else precision
+        rng_compat = DEFAULTS["rng_compat"] if rng_compat is None else rng_compat
+        self_check = DEFAULTS["self_check"] if self_check is None else self_check
+        device_topk = DEFAULTS["device_topk"] if device_topk is None else device_topk
         self.init_super(env_config)
         self.precision = precision
         self.self_check = bool(self_check) and precision in ("f16mx", "f16x2")
@@ -210,6 +219,23 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
             return ref
         return pos
 
+    def get_most_likely_samples(self, forecasts):
+        """mid_sim_wrapper.py:440-441: the ``num_ret_samples`` most likely of the sampled joint futures under the per-step
+        Gaussian KDE (``get_most_likely_samples``, ``:14-169``, joint branch).  forecasts [K, A, H, 2] (tensor or array) ->
+        (kept [A, k, H, 2], log-weights [A, k]) as float32 torch tensors, ascending likelihood like the reference's
+        ``argsort(...)[-k:]``.  On the device (``jmid_topk``) while the shape fits it, on the host twin otherwise."""
+        f = forecasts.detach().cpu().numpy() if isinstance(forecasts, torch.Tensor) else np.asarray(forecasts)
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        K, A, H, _ = f.shape
+        k = self.num_ret_samples
+        if self.device_topk and k <= K and topk_fits_device(A, K, H):
+            with self._engine_lock:
+                sel, lw = self.engine.topk(f[None], k)
+            sel, lw = sel[0], lw[0]
+        else:
+            sel, lw = most_likely_samples(f, k)
+        return torch.from_numpy(np.ascontiguousarray(sel)), torch.from_numpy(np.ascontiguousarray(lw))
+
     def predict_ret_best(self) -> Tuple[np.ndarray, np.ndarray]:
         """mid_sim_wrapper.py:482-510 -> (forecasts [N, k, H+1, 2] float64, log-weights [N, k] float64)."""
         t0 = time.perf_counter()
@@ -231,7 +257,9 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
                 self.engine.set_step(self.step_size, "ddim")   # eval_sicnav hard-codes sampling="ddim" (MID/mid.py:333)
             ctx = self.engine.encode(sb.x_st, sb.nbr_sum, sb.edge_mask)
             x_np = x_T.numpy()[None]
-            on_dev = k < K and self.device_topk           # the K samples stay on the GPU: only the k kept ones come back
+            # the K samples stay on the GPU (only the k kept ones come back) while jmid_topk takes the shape; beyond its limits
+            # - the reference has none - the host twin ranks them
+            on_dev = k < K and self.device_topk and topk_fits_device(A, K, H)
             check = self.self_check and tuple(x_np.shape) not in self._checked_shapes
             pos = self._denoise(x_np, ctx[None], sb.p0[None], want_pos=not on_dev or check)
             if check:        # first call of this shape in an opt-in mode: pos is the result to use (possibly f16x3's)
@@ -262,6 +290,23 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
         self.timings = {"scene_ms": 1e3 * (t1 - t0), "device_ms": 1e3 * (t2 - t1), "topk_ms": 1e3 * (t3 - t2),
                         "assemble_ms": 1e3 * (t4 - t3), "total_ms": 1e3 * (t4 - t0)}
         return out
+
+
+def get_most_likely_samples(forecasts, mid_model, num_ret_samples):
+    """Module-level twin of ``mid_sim_wrapper.get_most_likely_samples`` (``:14-169``; joint branch - the predictor's model has
+    no ``cfg``, ``:20-21``): forecasts [K, A, H, 2] -> (kept [A, k, H, 2], log-weights [A, k]) float32 tensors.  Host arithmetic
+    (``kde.most_likely_samples``); the class method of the same name uses the device kernel."""
+    f = forecasts.detach().cpu().numpy() if isinstance(forecasts, torch.Tensor) else np.asarray(forecasts)
+    sel, lw = most_likely_samples(np.ascontiguousarray(f, dtype=np.float32), int(num_ret_samples))
+    return torch.from_numpy(np.ascontiguousarray(sel)), torch.from_numpy(np.ascontiguousarray(lw))
+
+
+# size limits of the device-side joint-KDE top-k (jmid_topk, include/jmid_hip.h): beyond them the host twin (kde.py) ranks
+TOPK_MAX_AGENTS, TOPK_MAX_SAMPLES, TOPK_MAX_HORIZON = 32, 1024, 24
+
+
+def topk_fits_device(A: int, K: int, H: int) -> bool:
+    return A <= TOPK_MAX_AGENTS and K <= TOPK_MAX_SAMPLES and H <= TOPK_MAX_HORIZON
 
 
 def denoise_with_fallback(engine: JmidEngine, x_T, ctx, p0, dt: float, precision: str, want_pos: bool = True):
@@ -317,12 +362,13 @@ def predict_batch(engine: JmidEngine, human_xy: np.ndarray, robot_xy: np.ndarray
             ctx = engine.encode(b["x_st"][ei, rows].reshape(len(eps) * A, F, 6),
                                 b["nbr_sum"][ei, rows].reshape(len(eps) * A, 2, F, 6),
                                 b["edge_mask"][ei, rows].reshape(len(eps) * A, 2)).reshape(len(eps), A, -1)
-            on_dev = k < K and device_topk     # the samples stay on the GPU; every episode of the group in ONE jmid_topk call
+            # the samples stay on the GPU; every episode of the group in ONE jmid_topk call (host twin beyond its size limits)
+            on_dev = k < K and device_topk and topk_fits_device(A, K, H)
             pos, _ = denoise_with_fallback(engine, x_T, ctx, p0, time_step, precision, want_pos=not on_dev)
             if on_dev:
                 sel_all, lw_all = engine.topk(None, k, dims=(len(eps), A, K, H))   # [Eg, A, k, H, 2], [Eg, A, k]
         for g, e in enumerate(eps):                                                # pos [Eg, K, A, H, 2]
-            if k < K and device_topk:
+            if on_dev:
                 sel, lw = sel_all[g], lw_all[g].astype(np.float64)
             elif k < K:
                 sel, lw = most_likely_samples(pos[g], k)                          # [A, k, H, 2], [A, k]

@@ -138,3 +138,50 @@ def test_mpc_glue_matches_reference_capture(case, golden_dir):
     with pytest.raises(IndexError):          # the reference indexes MID_samples[horiz] and fails the same way
         stage_parameter_blocks(out.samples_by_stage[:horiz], z["goal_states"], z["goal_actions"], z["Q_diag"],
                                z["R_diag"], z["term_Q_diag"], horiz)
+
+
+def test_install_aliases_the_reference_module(monkeypatch):
+    """``install()``: the reference's caller line (sicnav_acados.py:24) resolves to this package's class without an edit -
+    with the reference tree importable (its own parent packages) and without it (stand-in parents)."""
+    import importlib
+    import sys
+    import safe_interactive_crowdnav_amd as P
+    from safe_interactive_crowdnav_amd import forecaster as FC
+
+    saved = dict(FC.DEFAULTS)
+    for with_reference in (False, True):
+        if with_reference and not os.path.isdir("/root/reference/sicnav_diffusion"):
+            continue
+        for name in [n for n in sys.modules if n == "sicnav_diffusion" or n.startswith("sicnav_diffusion.")]:
+            monkeypatch.delitem(sys.modules, name)
+        if with_reference:
+            monkeypatch.syspath_prepend("/root/reference")
+            importlib.invalidate_caches()
+        try:
+            mod = P.install(precision="f16mx", self_check=True)
+            assert mod is FC and FC.DEFAULTS["precision"] == "f16mx" and FC.DEFAULTS["self_check"] is True
+            ns = {}
+            exec("from sicnav_diffusion.JMID.mid_sim_wrapper import HumanTrajectoryForecasterSim", ns)     # the caller's line
+            assert ns["HumanTrajectoryForecasterSim"] is FC.HumanTrajectoryForecasterSim
+            import sicnav_diffusion.JMID.mid_sim_wrapper as W
+            assert W is FC and hasattr(W, "get_most_likely_samples") and hasattr(W, "ForecasterSimSuper")
+            with pytest.raises(TypeError):
+                P.install(no_such_default=1)
+        finally:
+            P.uninstall()
+            FC.DEFAULTS.clear()
+            FC.DEFAULTS.update(saved)
+        assert sys.modules.get("sicnav_diffusion.JMID.mid_sim_wrapper") is not FC
+
+
+def test_module_level_get_most_likely_samples_has_the_reference_signature():
+    """mid_sim_wrapper.get_most_likely_samples(forecasts, mid_model, num_ret_samples) -> torch tensors [A, k, H, 2], [A, k]."""
+    from safe_interactive_crowdnav_amd.forecaster import get_most_likely_samples, topk_fits_device
+    z = np.load(os.path.join(GOLDEN, sorted(glob.glob(os.path.join(GOLDEN, "kde_*.npz")))[0]))
+    top, lw = get_most_likely_samples(torch.from_numpy(z["forecasts"]), object(), int(z["k_ret"]))
+    assert isinstance(top, torch.Tensor) and isinstance(lw, torch.Tensor)
+    np.testing.assert_array_equal(top.numpy(), z["top"])
+    np.testing.assert_allclose(lw.numpy(), z["logw"], rtol=1e-5, atol=1e-5)
+    # the device kernel's size limits (include/jmid_hip.h): beyond them the class falls back to the host twin
+    assert topk_fits_device(32, 1024, 24) and not topk_fits_device(33, 100, 8) and not topk_fits_device(5, 1025, 8) \
+        and not topk_fits_device(5, 100, 25)
