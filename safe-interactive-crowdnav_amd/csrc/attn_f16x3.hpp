@@ -299,8 +299,12 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     // K / V^T tile and meets the barriers, but computes nothing
     const bool wave_idle = (qt * 4 + wid) * 32 >= S;
 
+    // Q operands: the raw loads go out here, their conversions (MX: bf8 images) wait until the first key tile's copies have been
+    // issued (q_finish below) - the two memory round trips of a workgroup's start overlap instead of adding up (one scene: the
+    // prologue was 31 % of a wave's life, tools/attn_small_trace.hip)
     f16x8 qh[NKS], ql[MX ? 1 : NKS];
     i32x8 q8h[2], q8l[2];            // MX: bf8 images of this lane's Q_hi / Q_lo row, 32 head dims per 64-deep block
+    i32x4 q8raw[2][4], q8lraw[2][4];
     {
         const size_t o = (tok0 + qc) * d + h * HD + 8 * hi;
 #pragma unroll
@@ -313,16 +317,36 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const i32x4 vh = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qhi + o8 + 64 * blk + 8 * c));
-                    q8h[blk][2 * c] = bf8_of_f16x4(vh[0], vh[1]);
-                    q8h[blk][2 * c + 1] = bf8_of_f16x4(vh[2], vh[3]);
-                }
+                for (int c = 0; c < 4; ++c)
+                    q8raw[blk][c] = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qhi + o8 + 64 * blk + 8 * c));
             if (a.Q8l) {      // the QKV GEMM wrote the image (wave-uniform)
 #pragma unroll
                 for (int blk = 0; blk < 2; ++blk) {
-                    const i32x4 l0 = *reinterpret_cast<const i32x4*>(a.Q8l + o8 + 64 * blk);
-                    const i32x4 l1 = *reinterpret_cast<const i32x4*>(a.Q8l + o8 + 64 * blk + 16);
+                    q8lraw[blk][0] = *reinterpret_cast<const i32x4*>(a.Q8l + o8 + 64 * blk);
+                    q8lraw[blk][1] = *reinterpret_cast<const i32x4*>(a.Q8l + o8 + 64 * blk + 16);
+                }
+            } else {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        q8lraw[blk][c] = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qlo + o8 + 64 * blk + 8 * c));
+            }
+        }
+    }
+    auto q_finish = [&]() {
+        if (MX) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    q8h[blk][2 * c] = bf8_of_f16x4(q8raw[blk][c][0], q8raw[blk][c][1]);
+                    q8h[blk][2 * c + 1] = bf8_of_f16x4(q8raw[blk][c][2], q8raw[blk][c][3]);
+                }
+            if (a.Q8l) {
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk) {
+                    const i32x4 l0 = q8lraw[blk][0], l1 = q8lraw[blk][1];
                     q8l[blk] = i32x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                 }
             } else {
@@ -330,23 +354,23 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const i32x4 vl = __builtin_bit_cast(i32x4, *reinterpret_cast<const f16x8*>(a.Qlo + o8 + 64 * blk + 8 * c));
-                        q8l[blk][2 * c] = bf8_of_f16x4(vl[0], vl[1]);
-                        q8l[blk][2 * c + 1] = bf8_of_f16x4(vl[2], vl[3]);
+                        q8l[blk][2 * c] = bf8_of_f16x4(q8lraw[blk][c][0], q8lraw[blk][c][1]);
+                        q8l[blk][2 * c + 1] = bf8_of_f16x4(q8lraw[blk][c][2], q8lraw[blk][c][3]);
                     }
             }
         }
-    }
-    // the Q loads are ordinary VMEM loads: retire them before the DMA ring starts so that vmcnt counts only DMAs
+        // the Q loads are ordinary VMEM loads, older than the first tile's copies: pinned here, before the key-tile loop, so that
+        // the loop's waits concern the DMA ring only
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qh[ks]));
-    if (!MX) {
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qh[ks]));
+        if (!MX) {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(ql[ks]));
-    } else {
+            for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(ql[ks]));
+        } else {
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk) asm volatile("" : "+v"(q8h[blk]), "+v"(q8l[blk]));
-    }
+            for (int blk = 0; blk < 2; ++blk) asm volatile("" : "+v"(q8h[blk]), "+v"(q8l[blk]));
+        }
+    };
 
     f32x16 ot[NT];
 #pragma unroll
@@ -429,7 +453,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int ntiles = (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
     {
     if (kt_begin == last_tile) use_last_offsets();
+    ATT_STAMP(7)   // arguments, tile arithmetic, Q loads requested
     issue(kt_begin);
+    q_finish();
     ATT_STAMP(0)   // prologue: Q loads, first DMA issue
     for (int kt = kt_begin; kt < ntiles; ++kt) {
         if (kt + 1 == last_tile) use_last_offsets();       // (uniform: the copies of tile kt + 1 go out during this iteration)
@@ -640,9 +666,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             t[10] = rt0;
             t[11] = __builtin_amdgcn_s_memrealtime();
             for (int i = 0; i < 7; ++i) t[i] = tacc[i];
+            t[9] = tacc[7];
             t[7] = tstart;
             t[8] = tprev;
-            t[9] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         }
     }
 

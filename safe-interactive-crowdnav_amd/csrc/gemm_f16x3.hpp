@@ -77,7 +77,7 @@ __device__ __forceinline__ bool split_range_exceeded(unsigned amax16) {
     return (amax16 & 0xffffu) > kHalfMaxBits || (amax16 >> 16) > kHalfMaxBits;
 }
 
-enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2 };
+enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2, OUT_LN = 3 };     // OUT_LN: gemm_small.hpp only (fp32 tile + residual + LayerNorm by the last workgroup of the row tile)
 
 
 struct GemmHArgs {
@@ -104,6 +104,13 @@ struct GemmHArgs {
     unsigned char *K8h, *K8l; // OUT_QKV, JMID_PREC_F16MX with head_dim 128: bf8 images of K_hi / K_lo, [M, d] bytes each, written
                               // INSTEAD of the fp16 K_lo plane (attn_f16x3_dma_kernel<.., MX>); null: K_lo as fp16
     unsigned char* Q8l;       // with them: bf8 image of Q_lo, [M, d] bytes, INSTEAD of the fp16 Q_lo plane (all that kernel wants of Q_lo)
+    // OUT_LN (gemm_small.hpp, N = 512): X <- LayerNorm(X + C) * gamma + beta by the last-arriving workgroup of each 64-row tile
+    const float *ln_gamma, *ln_beta;
+    half_t *ln_xh, *ln_xl;    // residual stream planes (blocked); F16MX at d_model 512: ln_xl8 instead of ln_xl
+    unsigned char* ln_xl8;    // bf8 image of the lo plane (gemm_ln2_mx.hpp::blk8_index), or null
+    unsigned* ln_cnt;         // [ceil(M / 64)] arrival counters, monotonic over launches (zeroed once per call)
+    float ln_eps;
+    int ln_no_lo;             // the last LayerNorm of the net: nobody reads its lo plane (F16MX)
 };
 
 constexpr int GEMMH_BK = 32;
@@ -1462,9 +1469,15 @@ inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     return launch_gemm_h_dma<EPI, OUT, X2>(g, st);
 }
 
+// launches of at most one workgroup per CU: gemm_small.hpp (defined after the LayerNorm headers it builds on)
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_small(const GemmHArgs& g, int wc, hipStream_t st);
+inline int small_gemm_shape(const GemmHArgs& g);
+
 // the arithmetic mode is a template parameter of every kernel (a run-time flag in the K loops cost F16X3 4 %)
 template <int EPI, int OUT>
 inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
+    if (const int wc = small_gemm_shape(g)) return launch_gemm_small<EPI, OUT>(g, wc, st);      // at most one workgroup per CU
     return g.x2 ? launch_gemm_h_mode<EPI, OUT, true>(g, st) : launch_gemm_h_mode<EPI, OUT, false>(g, st);
 }
 

@@ -1,0 +1,574 @@
+// Split-fp16 GEMMs for launches of AT MOST ONE workgroup per CU - the shape the MPC issues (one scene: M = 1200 tokens) and
+// its neighbours (2 ... 4 scenes per chunk).  Included by gemm_f16x3.hpp (same operands, same epilogues, same bits).
+//
+// What bounds such a launch is not arithmetic (a 64 x 64 tile of a K = 512 product is 40 MFMAs per wave) but how the operands get
+// to the CU (rocprofv3 PMC on the round-3 kernels, tools/small_pmc.sh: every launch fetches its weight 8 times, once per XCD,
+// from the Infinity Cache - in_proj 20.3 MB for 2.4 MB of W - and a K loop of 16 k32 tiles with three 10 KB tiles in flight
+// advances at one Infinity-Cache round trip per three tiles: 3.8 us per 512 of K, 0.24 us per tile):
+//   * the ring holds k64 stages (half the barriers, wait / read / MFMA chains twice as long) and is as deep as the CU's LDS
+//     allows with ONE workgroup per CU (up to 140 KB: six stages = 120 KB of a 160 KB operand set requested before the first
+//     MFMA) - the K loop then runs at the LDS-DMA rate of the CU instead of at the latency of the Infinity Cache;
+//   * the tile order is two-dimensional per XCD: the tile sequence is cut into `pn` column groups, each walked M-major, and XCD
+//     x takes the x-th eighth of the sequence, so an XCD fetches |W| / pn + pn |A| / 8 instead of |W| + |A| / 8 - the host picks
+//     the pn that minimises the bytes all eight XCDs pull (in_proj 20.1 -> 9.6 MB, linear1 13.8 -> 8.0, linear2 15.0 -> 11.2);
+//   * per k64 block and accumulator the MFMA sequence is the one every other tile shape of the mode issues (F16MX: four fp16 steps
+//     in k order, then the fp8 instruction; F16X2 / F16X3: per k16 step hi.hi, hi.lo, [lo.hi]) - results are bit-identical to the
+//     large-tile kernels, so an episode's result still does not depend on the size of its batch.
+// Tile 64 x 32 WC (WC = 2: 4 waves, N <= 512; WC = 4: 8 waves, in_proj / linear1), each wave one 32 x 32 accumulator.
+#pragma once
+#include "elementwise.hpp"
+#include "gemm_ln2_mx.hpp"
+
+namespace jmid {
+
+enum SmallMode { SM_X3 = 0, SM_X2 = 1, SM_MX = 2 };
+
+// tools/small_gemm_trace.hip only: wall-clock stamps (s_memrealtime, 100 MHz) of thread 0 of every workgroup at the phase boundaries
+#ifdef JMID_SMALL_TRACE
+__device__ unsigned long long* g_small_trace;
+#define SM_STAMP(i)                                                                                      \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (threadIdx.x == 0) { sm_trace_p[i] = __builtin_amdgcn_s_memrealtime(); sm_trace_p[8 + (i)] = __builtin_amdgcn_s_memtime(); } \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#ifndef JMID_SMALL_ABL
+#define JMID_SMALL_ABL 0
+#endif
+#define SM_ABL(bit) ((JMID_SMALL_ABL & (bit)) != 0)      // compile-time ablations: 16 no copies, 32 no fp16 MFMAs, 64 the launch alone
+#else
+#define SM_STAMP(i)
+#define SM_ABL(bit) false
+#endif
+
+
+template <int MODE, int WC>
+struct SmCfg {
+    static constexpr int NW = 2 * WC, NT = 64 * NW, BM = 64, BN = 32 * WC;
+    static constexpr int A_SUB = BM * 64, W_SUB = BN * 64;                  // bytes of one k32 sub-tile of a plane
+    static constexpr int A_PLANES = MODE == SM_X3 ? 2 : 1, W_PLANES = MODE == SM_MX ? 1 : 2;
+    static constexpr int BLK = 2 * (A_PLANES * A_SUB + W_PLANES * W_SUB) + (MODE == SM_MX ? BN * 64 : 0);     // one k64 block, all planes
+    // k64 blocks per ring stage: a stage costs a wave one wait + barrier + LDS round trip however deep it is (the wave is alone
+    // on its SIMD: nothing hides them), so stages are k128 wherever three of them fit the CU's LDS
+    static constexpr int KB = 3 * 2 * BLK <= 144 * 1024 ? 2 : 1;
+    static constexpr int A_BYTES = KB * 2 * A_SUB, W_BYTES = KB * 2 * W_SUB;          // one plane of a stage
+    static constexpr int W8_BLOCK = MODE == SM_MX ? BN * 64 : 0;                    // bf8(W_lo) of one k64 block
+    static constexpr int OFF_AH = 0, OFF_AL = A_BYTES, OFF_WH = A_PLANES * A_BYTES, OFF_WL = OFF_WH + W_BYTES;
+    static constexpr int OFF_W8 = OFF_WH + W_PLANES * W_BYTES;
+    static constexpr int STAGE = OFF_W8 + KB * W8_BLOCK;
+    static constexpr int ROUND = NT * 16;                                   // bytes one DMA wave-instruction per wave moves
+    static constexpr int RA = A_BYTES / ROUND, RW = W_BYTES / ROUND, R8B = W8_BLOCK / ROUND, R8 = KB * R8B;
+    static constexpr int NR = A_PLANES * RA + W_PLANES * RW + R8;           // DMA wave-instructions per wave and stage
+    static constexpr int NS_MAX = (144 * 1024) / STAGE;
+    static constexpr int NS = NS_MAX < 4 ? NS_MAX : 4;                      // ring slots; NS - 1 stages of look-ahead
+    static constexpr int L = NS - 1;
+    static constexpr size_t LDS_BYTES = size_t(NS) * STAGE;
+    static_assert(A_BYTES % ROUND == 0 && W_BYTES % ROUND == 0 && W8_BLOCK % ROUND == 0, "plane / workgroup mismatch");
+    static_assert(NS >= 2 && (L - 1) * NR <= 63, "ring depth against the vmcnt range");
+};
+
+// sc1 (agent-scope, write-through / L1-bypassing) 16-byte accesses for data handed from one workgroup to another inside a launch
+__device__ __forceinline__ void store_sc1_b128(float* p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 load_sc1_b128(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// ---- OUT_LN: residual + LayerNorm of a 64-row tile by ONE 256-thread workgroup (the last of the tile's ntn workgroups to arrive).
+// The fp32 rows (accumulator + bias) of the other workgroups come through memory: every producer stages its 64 x 64 tile in LDS
+// and writes it out in 1 KB wave-instructions (sc1: write-through), in the order the consumer's lanes will want it; the consumer
+// reads it back with sc1 loads (past its L1), all of them requested before the first use - one memory round trip for the tile.
+// Per row the arithmetic and the summation order are those of the stand-alone kernels (add_ln2_kernel / add_ln_kernel<2, true>):
+// the rows are bit-identical to the unfused pair.
+//
+// F16MX at d_model 512 (byte lo plane, gemm_ln2_mx.hpp's canonical order: partial(c, h) over the 32 columns 64 c + 32 j + 16 p + 8 h + e,
+// P_c = partial(c, 0) + partial(c, 1), total = ((((((P0 + P1) + P2) + P3) + P4) + P5) + P6) + P7):
+//   hand-off layout of a row tile: [c = 0..7][pass = 0..3][i = 0..7][32 lanes] x 16 B, lane = 2 (row % 16) + h, row = 16 pass + row % 16,
+//   i = 2 u + half: the four floats 64 c + 32 (u >> 1) + 16 (u & 1) + 8 h + 4 half + 0..3.  Block c (16 KB, contiguous) is exactly
+//   what the workgroup of N-tile c produces; consumer wave w owns blocks 2 w and 2 w + 1 (lanes 0-31 / 32-63) for all 64 rows, and the
+//   row totals are formed from the eight P_c in LDS, in the canonical order.
+constexpr int SM_LN_TILE_BYTES = 64 * GLN_BN * 4;          // one row tile of the hand-off buffer: 128 KB
+constexpr int SM_STG_LD = 68;                              // floats per row of the staged 64 x 64 tile (272 B: conflict-free b128)
+
+__device__ __forceinline__ void sm_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// the producer's side: the staged tile (LDS, [64][SM_STG_LD] floats) -> global, 1 KB per wave-instruction
+template <bool MXV2>
+__device__ __forceinline__ void ln_handoff_store(const float* stg, float* Y, int ldc, int m0, int n0, int tn, int tm, int M, int tid) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int idx = ps * 256 + tid;                    // 16-byte unit of the tile
+        if (MXV2) {
+            const int hi = idx & 1, r16 = (idx >> 1) & 15, i = (idx >> 5) & 7, p = idx >> 8;
+            const int u = i >> 1, half = i & 1, row = p * 16 + r16, col = (u >> 1) * 32 + (u & 1) * 16 + hi * 8 + half * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SM_STG_LD + col);
+            store_sc1_b128(Y + (size_t)tm * (SM_LN_TILE_BYTES / 4) + tn * 4096 + idx * 4, v);
+        } else {                                           // row-major [M, 512]: 256-byte row pieces
+            const int row = idx >> 4, ch = idx & 15;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SM_STG_LD + ch * 4);
+            if (m0 + row < M) store_sc1_b128(Y + (size_t)(m0 + row) * ldc + n0 + ch * 4, v);
+        }
+    }
+}
+
+__device__ __forceinline__ void ln_tail_mx(const float* Yt, const float* gamma, const float* beta, int M, float eps, half_t* Xh,
+                                           unsigned char* Xl8, int no_lo_out, int* range_flag, int row0, int tid, float* red
+#ifdef JMID_SMALL_TRACE
+                                           , unsigned long long* sm_trace_p
+#endif
+                                           ) {
+    constexpr int d = GLN_BN, NP = 4;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int c = 2 * wid + (lane >> 5), r16 = (lane >> 1) & 15, hi = lane & 1;
+    f16x8 xh[NP][4];
+    i32x2 xb[NP][4];
+    f32x4 y[NP][8];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = row0 + p * 16 + r16, rowc = row < M ? row : M - 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
+            xh[p][u] = *reinterpret_cast<const f16x8*>(Xh + blk_index(rowc, c0, d));
+            xb[p][u] = *reinterpret_cast<const i32x2*>(Xl8 + blk8_index(rowc, c0, d));
+        }
+    }
+    const float* yb = Yt + c * 4096 + (lane & 31) * 4;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[p][i] = load_sc1_b128(yb + (p * 8 + i) * 128);
+    sm_wait_loads();
+    SM_STAMP(7);
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(y[p][i]));
+    // red: [2][64 rows][8] floats - the P_c of every row, first of the sums, then of the squared deviations
+    auto row_total = [&](const float* r8p) {
+        float t = r8p[0] + r8p[1];
+#pragma unroll
+        for (int k = 2; k < 8; ++k) t += r8p[k];
+        return t;
+    };
+    float v[NP][32];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float xl[8];
+            f32_of_bf8x8(xb[p][u], xl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (float)xh[p][u][e] + xl[e];
+                const float t = a + (e < 4 ? y[p][2 * u][e] : y[p][2 * u + 1][e - 4]);
+                v[p][u * 8 + e] = t;
+                s += t;
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        if (hi == 0) red[(p * 16 + r16) * 8 + c] = s;
+    }
+    __syncthreads();
+    float mean[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        mean[p] = row_total(red + (p * 16 + r16) * 8) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const float t = v[p][e] - mean[p];
+            q += t * t;
+        }
+        q += __shfl_xor(q, 1, 64);
+        if (hi == 0) red[512 + (p * 16 + r16) * 8 + c] = q;
+    }
+    __syncthreads();
+    SM_STAMP(8);
+    bool overflow = false;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = row0 + p * 16 + r16;
+        const float rstd = rsqrtf(row_total(red + 512 + (p * 16 + r16) * 8) / (float)d + eps);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(beta + c0), t1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+            f16x8 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float o = (v[p][u * 8 + e] - mean[p]) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+                half_t hh, ll;
+                split_f32(o, hh, ll);
+                overflow |= row < M && !(fabsf(o) <= kHalfMax);
+                vh[e] = hh;
+                vl[e] = ll;
+            }
+            if (row < M) {
+                *reinterpret_cast<f16x8*>(Xh + blk_index(row, c0, d)) = vh;
+                if (!no_lo_out) *reinterpret_cast<i32x2*>(Xl8 + blk8_index(row, c0, d)) = bf8x8_of_f16(vl);
+            }
+        }
+    }
+    if (overflow) atomicOr(range_flag, 1);
+}
+
+// F16X2 / F16X3 (fp16 lo plane): one wave per row and pass, lane l the columns 4 l .. 4 l + 3 and 256 + 4 l .. (add_ln_kernel<2, true>);
+// the hand-off buffer is the row-major fp32 [M, 512] the stand-alone GEMM writes: a wave's loads are whole 1 KB half rows
+__device__ __forceinline__ void ln_tail_planes(const float* Y, const float* gamma, const float* beta, int M, float eps, half_t* Xh,
+                                               half_t* Xl, int row0, int tid) {
+    constexpr int d = GLN_BN, NP = 16;                 // 4 waves x 16 passes = 64 rows
+    const int lane = tid & 63, wid = tid >> 6;
+    f16x4 ph[NP][2], pl[NP][2];
+    f32x4 y[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = row0 + p * 4 + wid, rowc = row < M ? row : M - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t ob = blk_index(rowc, (i * 64 + lane) * 4, d);
+            ph[p][i] = *reinterpret_cast<const f16x4*>(Xh + ob);
+            pl[p][i] = *reinterpret_cast<const f16x4*>(Xl + ob);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = row0 + p * 4 + wid, rowc = row < M ? row : M - 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) y[p][i] = load_sc1_b128(Y + (size_t)rowc * d + (i * 64 + lane) * 4);
+    }
+    sm_wait_loads();
+#pragma unroll
+    for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(y[p][0]), "+v"(y[p][1]));
+    f32x4 gm[2], bt[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        gm[i] = *reinterpret_cast<const f32x4*>(gamma + (i * 64 + lane) * 4);
+        bt[i] = *reinterpret_cast<const f32x4*>(beta + (i * 64 + lane) * 4);
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = row0 + p * 4 + wid;
+        f32x4 v[2];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 a;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = (float)ph[p][i][e] + (float)pl[p][i][e];
+            v[i] = a + y[p][i];
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x4 vh, vl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
+                half_t hh, ll;
+                split_f32(o, hh, ll);
+                vh[e] = hh;
+                vl[e] = ll;
+            }
+            if (row < M) {
+                const size_t ob = blk_index(row, (i * 64 + lane) * 4, d);
+                *reinterpret_cast<f16x4*>(Xh + ob) = vh;
+                *reinterpret_cast<f16x4*>(Xl + ob) = vl;
+            }
+        }
+    }
+}
+
+template <int EPI, int OUT, int MODE, int WC>
+__global__ __launch_bounds__(128 * WC, 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags) {
+    using C = SmCfg<MODE, WC>;
+    constexpr bool X2 = MODE != SM_X3, MX = MODE == SM_MX;
+    constexpr int BM = C::BM, BN = C::BN, NS = C::NS, L = C::L, KB = C::KB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+#ifdef JMID_SMALL_TRACE
+    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;     // (loaded before the ring starts: vmcnt stays the ring's)
+    asm volatile("" : "+s"(sm_trace_p));
+    if (SM_ABL(64)) return;          // ablation: the launch alone
+#endif
+    SM_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid / WC, wc = wid % WC;
+    // XCD-contiguous ranges of the tile sequence (block b runs on XCD b % 8: for speed only); the sequence is cut into column
+    // groups of gw N-tiles, each walked M-major with the group's N-tiles fastest
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int s = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int per = ntm * gw, cg = s / per, rem = s - cg * per;
+    const int tm = rem / gw, tn = cg * gw + (rem - tm * gw);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = g.K / 32, nst = g.K / (64 * KB);
+
+    // DMA sources of stage 0, one per wave-instruction of a stage ("round"), in the fixed order A_hi [A_lo] W_hi [W_lo] [W8];
+    // round q of a plane moves bytes [q ROUND, (q + 1) ROUND) of the plane's stage image = its 2 KB k32 sub-tiles back to back
+    constexpr int IAL = C::RA, IWH = C::A_PLANES * C::RA, IWL = IWH + C::RW, I8 = IWH + C::W_PLANES * C::RW;
+    const char* src[C::NR];
+    auto plane_src = [&](const void* base, int tile, auto rows_c, int q) {
+        constexpr int ROWS = decltype(rows_c)::value, SUB = ROWS * 64;
+        const int o = q * C::ROUND + tid * 16, sub = o / SUB, within = o - sub * SUB;
+        const size_t panel = ROWS == 128 ? (size_t)tile * nk : (size_t)(tile >> 1) * nk;
+        return reinterpret_cast<const char*>(base) + (panel + sub) * 8192 + (ROWS == 128 ? 0 : (tile & 1) * 4096) + within;
+    };
+#pragma unroll
+    for (int q = 0; q < C::RA; ++q) {
+        src[q] = plane_src(g.Ahi, tm, std::integral_constant<int, 64>{}, q);
+        if (!X2) src[IAL + q] = plane_src(g.Alo, tm, std::integral_constant<int, 64>{}, q);
+    }
+#pragma unroll
+    for (int q = 0; q < C::RW; ++q) {
+        src[IWH + q] = plane_src(g.Whi, tn, std::integral_constant<int, BN>{}, q);
+        if (!MX) src[IWL + q] = plane_src(g.Wlo, tn, std::integral_constant<int, BN>{}, q);
+    }
+    const size_t w8_kstride = (size_t)(g.N / 32) * 2048;
+    if (MX) {
+#pragma unroll
+        for (int q = 0; q < C::R8; ++q)      // block q / R8B of the stage, round q % R8B of its image
+            src[I8 + q] = reinterpret_cast<const char*>(g.W8) + (size_t)(q / C::R8B) * w8_kstride + (size_t)(n0 / 32) * 2048 +
+                          (q % C::R8B) * C::ROUND + tid * 16;
+    }
+    // destination of round r inside a stage (compile-time) + this wave's 1 KB slice of the round
+    auto dst_of = [&](int r) {
+        if (r < IAL) return C::OFF_AH + r * C::ROUND;
+        if (r < IWH) return C::OFF_AL + (r - IAL) * C::ROUND;
+        if (r < IWH + C::RW) return C::OFF_WH + (r - IWH) * C::ROUND;
+        if (!MX) return C::OFF_WL + (r - IWL) * C::ROUND;
+        return C::OFF_W8 + (r - I8) * C::ROUND;
+    };
+    auto issue = [&](int st_idx, int slot) {
+        if (SM_ABL(16)) return;
+        unsigned char* st = lds_raw + slot * C::STAGE + wid * 1024;
+#pragma unroll
+        for (int r = 0; r < C::NR; ++r) {
+            const bool is8 = MX && r >= I8;
+            const char* sp = src[r] + (is8 ? (size_t)st_idx * KB * w8_kstride : (size_t)st_idx * KB * 16384);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 0);
+        }
+    };
+    f32x16 acc[1][1];
+    const int rowA = wr * 32 + l31, rowW = wc * 32 + l31;
+    int offA[2], offW[2];               // bytes inside a k32 sub-tile, per 16-deep step
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        offA[ks] = (rowA * 32 + (((ks * 2 + hi) ^ ((rowA >> 2) & 3)) * 8)) * 2;
+        offW[ks] = (rowW * 32 + (((ks * 2 + hi) ^ ((rowW >> 2) & 3)) * 8)) * 2;
+    }
+    auto kloop = [&](auto swap_c) {
+        constexpr bool SWAP = decltype(swap_c)::value;
+        f32x16 c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < L; ++t)
+            if (t < nst) issue(t, t);
+        SM_STAMP(1);
+        int slot = 0;
+        for (int si = 0; si < nst; ++si) {
+            if (si + L - 1 < nst) wait_vmcnt<(L - 1) * C::NR>();       // stage si has landed (this wave's share) ...
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                              // ... and everybody else's; the slot of stage si - 1 is free
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef JMID_SMALL_TRACE
+            if (si == 0) SM_STAMP(2);
+#endif
+            if (si + L < nst) issue(si + L, slot == 0 ? NS - 1 : slot - 1);
+            const unsigned char* st = lds_raw + slot * C::STAGE;
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {          // the k64 blocks of the stage; per block the canonical MFMA sequence of the mode
+                f16x8 ah[4], al[4], wh[4], wl[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int sub = 2 * j + (ks >> 1), step = ks & 1;
+                    ah[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_AH + sub * C::A_SUB + offA[step]);
+                    wh[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_WH + sub * C::W_SUB + offW[step]);
+                    if (!X2) al[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_AL + sub * C::A_SUB + offA[step]);
+                    if (!MX) wl[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_WL + sub * C::W_SUB + offW[step]);
+                }
+                i32x8 w8, a8;
+                if (MX) {
+                    const unsigned char* p = st + C::OFF_W8 + j * C::W8_BLOCK + wc * 2048 + lane * 16;
+                    const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
+                    const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
+                    w8 = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (!SM_ABL(32))
+                    c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah[ks], c, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], wh[ks], c, 0, 0, 0);
+                    if (MX) {
+                        // the bf8 image of this step's A fragment, in the shadow of the MFMA just issued (pinned: left to itself the
+                        // compiler sinks all eight packs in front of the fp8 instruction, onto the wave's critical path)
+                        const i32x4 d = __builtin_bit_cast(i32x4, ah[ks]);
+                        int p0 = bf8_of_f16x4(d[0], d[1]), p1 = bf8_of_f16x4(d[2], d[3]);
+                        asm volatile("" : "+v"(p0), "+v"(p1));
+                        a8[ks * 2 + 0] = p0;
+                        a8[ks * 2 + 1] = p1;
+                    } else {
+                        c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah[ks], c, 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], wl[ks], c, 0, 0, 0);
+                        if (!X2)
+                            c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al[ks], c, 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], wh[ks], c, 0, 0, 0);
+                    }
+                }
+                if (MX)      // both operands bf8, literal zero scales: the UNSCALED instruction (gemm_f16x3.hpp)
+                    c = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, c, 1, 1, 0, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, c, 1, 1, 0, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot + 1 == NS ? 0 : slot + 1;
+        }
+        acc[0][0] = c;
+        SM_STAMP(3);
+    };
+    if constexpr (OUT == OUT_LN) {
+        // Transposed product: a lane owns token row l31 of its wave's block and four runs of 4 consecutive columns.  The fp32 rows
+        // (accumulator + bias: what the stand-alone GEMM hands add_ln*) go out write-through (sc1), the workgroup's arrival is counted
+        // per row tile, and the LAST of the ntn workgroups of a tile - whoever that is, wherever it runs - reads the complete rows
+        // back (sc1: past its L1) and normalises them.  No spinning: nobody waits for anybody.
+        static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
+        kloop(std::true_type{});
+        __syncthreads();                                       // everybody is done with the operand ring: it becomes the staging tile
+        float* stg = reinterpret_cast<float*>(lds_raw);
+        {
+            float* sr = stg + (wr * 32 + l31) * SM_STG_LD + wc * 32 + 4 * hi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 32 + 8 * q + 4 * hi);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[0][0][4 * q + e], kWInv, bv[e]);
+                *reinterpret_cast<f32x4*>(sr + 8 * q) = o;
+            }
+        }
+        __syncthreads();
+        if (g.ln_xl8) ln_handoff_store<true>(stg, g.C, g.ldc, m0, n0, tn, tm, g.M, tid);
+        else ln_handoff_store<false>(stg, g.C, g.ldc, m0, n0, tn, tm, g.M, tid);
+        SM_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the tile is out ...
+        __syncthreads();                                       // ... and the workgroup's
+        __shared__ unsigned sm_last;
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(g.ln_cnt + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sm_last = (old % (unsigned)ntn) == (unsigned)(ntn - 1);
+        }
+        __syncthreads();
+        SM_STAMP(5);
+        if (!sm_last) return;
+        if (g.ln_xl8)
+            ln_tail_mx(g.C + (size_t)tm * (SM_LN_TILE_BYTES / 4), g.ln_gamma, g.ln_beta, g.M, g.ln_eps, g.ln_xh, g.ln_xl8, g.ln_no_lo,
+                       g.range_flag, m0, tid, stg
+#ifdef JMID_SMALL_TRACE
+                       , sm_trace_p
+#endif
+                       );
+        else
+            ln_tail_planes(g.C, g.ln_gamma, g.ln_beta, g.M, g.ln_eps, g.ln_xh, g.ln_xl, m0, tid);
+        SM_STAMP(6);
+        return;
+    }
+    // the ConcatSquash GEMMs (and, on request, linear1) run transposed with the row-wise epilogue, as in the large-tile kernels
+    if constexpr (csl_rowwise<EPI, OUT>() || (EPI == EPI_BIAS_RELU && OUT == OUT_SPLIT)) {
+        if (csl_rowwise<EPI, OUT>() ? (!MX || (flags & 4)) : (flags & 8)) {
+            kloop(std::true_type{});
+            csl_swapped_epilogue<1, 1, EPI, OUT, X2>(g, acc, m0 + wr * 32, n0 + wc * 32, l31, hi);
+            SM_STAMP(4);
+            return;
+        }
+    }
+    if constexpr (OUT != OUT_LN) {
+    kloop(std::false_type{});
+    gemm_h_epilogue<1, 1, EPI, OUT, X2, MX && OUT == OUT_QKV>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
+    }
+    SM_STAMP(4);
+#ifdef JMID_SMALL_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SM_STAMP(5);
+#endif
+}
+
+// bytes all eight XCDs pull from the Infinity Cache with pn column groups: every XCD its column group's share of W and the A rows
+// of its part of the M range
+inline int small_pick_groups(const GemmHArgs& g, int ntn, double w_bytes_per_el, double a_bytes_per_el) {
+    const double wb = (double)g.N * g.K * w_bytes_per_el, ab = (double)g.M * g.K * a_bytes_per_el;
+    int best = 1;
+    double best_bytes = 8.0 * wb + ab;
+    for (int pn = 2; pn <= 8; pn *= 2) {
+        if (ntn % pn != 0) break;
+        const double bytes = 8.0 * wb / pn + pn * ab;
+        if (bytes < best_bytes) {
+            best = pn;
+            best_bytes = bytes;
+        }
+    }
+    return best;
+}
+
+template <int EPI, int OUT, int MODE, int WC>
+inline hipError_t launch_gemm_small_cfg(const GemmHArgs& g, hipStream_t st) {
+    using C = SmCfg<MODE, WC>;
+    const int ntm = (g.M + C::BM - 1) / C::BM, ntn = g.N / C::BN;
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_kernel<EPI, OUT, MODE, WC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    const int pn = tune().small_pn > 0 ? (ntn % tune().small_pn == 0 ? tune().small_pn : 1)
+                                       : small_pick_groups(g, ntn, MODE == SM_MX ? 3.0 : 4.0, MODE == SM_X3 ? 4.0 : 2.0);
+    const int flags = (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0);
+    hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, MODE, WC>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
+                       ntn / pn, flags);
+    return hipGetLastError();
+}
+
+// Does this GEMM run on the small-launch kernel, and in which shape?  One workgroup per CU: at most 256 tiles.
+//   -> 0 no, 2 / 4 = WC.  (OUT_LN callers: 2 means the fused tail applies.)  "gemm_small" knob: 0 auto, 1 never.
+inline int small_gemm_shape(const GemmHArgs& g) {
+    if (tune().gemm_small == 1 || tune().gemm_h_variant != 0) return 0;
+    if (g.K % 128 != 0 || g.N % 128 != 0) return 0;       // (k128 ring stages)
+    const long ntm = (g.M + 63) / 64;
+    if (ntm * (g.N / 64) <= 256) return 2;
+    if (ntm * (g.N / 128) <= 256) return 4;
+    return 0;
+}
+
+template <int EPI, int OUT, int MODE>
+inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t st) {
+    if (wc == 2) return launch_gemm_small_cfg<EPI, OUT, MODE, 2>(g, st);
+    if constexpr (OUT == OUT_LN) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
+    else return launch_gemm_small_cfg<EPI, OUT, MODE, 4>(g, st);
+}
+
+// does out_proj / linear2 + residual + LayerNorm run as ONE small launch (OUT_LN)?  d_model 512, at most 256 tiles of 64 x 64
+inline bool small_ln_fits(int M, int K) {
+    return tune().gemm_small != 1 && tune().gemm_h_variant == 0 && tune().small_ln == 1 && K % 128 == 0 && (long)((M + 63) / 64) * (GLN_BN / 64) <= 256;
+}
+
+template <int EPI, int OUT>
+inline hipError_t launch_gemm_small(const GemmHArgs& g, int wc, hipStream_t st) {
+    if (g.x2 && g.W8) return launch_gemm_small_mode<EPI, OUT, SM_MX>(g, wc, st);
+    if (g.x2) return launch_gemm_small_mode<EPI, OUT, SM_X2>(g, wc, st);
+    return launch_gemm_small_mode<EPI, OUT, SM_X3>(g, wc, st);
+}
+
+}  // namespace jmid

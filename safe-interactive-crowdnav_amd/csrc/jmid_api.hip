@@ -20,6 +20,7 @@
 #include "gemm_f16x3.hpp"
 #include "gemm_ln_f16x3.hpp"
 #include "gemm_ln2_mx.hpp"
+#include "gemm_small.hpp"
 #include "gemm_f32.hpp"
 #include "kde.hpp"
 #include "tail_f16x3.hpp"
@@ -320,6 +321,15 @@ int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
     return 0;
 }
 
+// out_proj / linear2 + residual + LayerNorm as ONE small launch (gemm_small.hpp, OUT_LN); g carries the GEMM, the ln_* fields the tail
+int run_gemm_ln_small(jmid_ctx* h, int cls, GemmHArgs& g) {
+    g.range_flag = h->range_flag;
+    g.x2 = h->x2;
+    ProfScope ps(h, cls);
+    HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LN>(g, 2, h->stream)));
+    return 0;
+}
+
 // JMID_PREC_F16MX: hand the GEMM the fp8 image of this weight's lo plane (the kernels that have no fp8 path ignore it)
 void set_w8(jmid_ctx* h, GemmHArgs& g, const std::string& name) {
     g.W8 = nullptr;
@@ -372,7 +382,9 @@ struct StepBuffers {
     size_t vt_elems;
     int attn_nsplit;          // split-KV factor of the attention launch (1 = off)
     float *Opart, *MLpart;
+    unsigned* ln_cnt;         // arrival counters of the small-launch GEMM + LayerNorm (gemm_small.hpp, OUT_LN): kLnCounters words
 };
+constexpr size_t kLnCounters = 256;
 
 half_t* take_half(Carver& c, size_t n) { return reinterpret_cast<half_t*>(c.take((n + 1) / 2)); }
 
@@ -393,7 +405,8 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
     Carver c(base);
     StepBuffers s{};
     s.X = c.take(Mc * h->d);
-    s.Y = c.take(Mc * h->d);
+    s.Y = c.take((Mc + 63) / 64 * 64 * h->d);     // (whole 64-row tiles: the hand-off layout of gemm_small.hpp's LayerNorm tail)
+    s.ln_cnt = reinterpret_cast<unsigned*>(c.take(kLnCounters));
     s.Y4 = c.take(Mc * h->dlow);
     if (precision == JMID_PREC_F32) {
         s.QKV = c.take(Mc * 3 * h->d);
@@ -552,6 +565,10 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             // per launch: 36.8 vs 39.1 ms per 12-episode call; 5: 33.8 vs 33.5, 4: 29.6 vs 28.8)
             // (enough row tiles to occupy the chip); otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
             const bool ln_fused = d == GLN_BN && tune().ln_fuse != 2 && (tune().ln_fuse == 1 || M >= 7168);
+            // small launches (one scene ... a few): GEMM + residual + LayerNorm in one kernel, the LayerNorm by the last-arriving
+            // workgroup of each 64-row tile (gemm_small.hpp; bit-identical to the pair below it replaces, two launches per layer fewer).
+            // F16MX: only with the byte lo plane of the second-generation LayerNorm (mxv2), whose order the tail reproduces
+            const bool ln_small = d == GLN_BN && (!h->mx || mxv2);
             if (ln_fused && mxv2) {
                 GemmLn2Args g2{sb.Ah, h->w16[p + ".self_attn.out_proj.weight"].hi, h->w8[p + ".self_attn.out_proj.weight"].p,
                                W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), sb.Xh, Xl8,
@@ -573,10 +590,16 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
                 set_w8(h, g, p + ".self_attn.out_proj.weight");
                 g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+                if (ln_small && small_ln_fits(M, g.K)) {
+                    g.ln_gamma = W(h, p + ".norm1.weight"); g.ln_beta = W(h, p + ".norm1.bias"); g.ln_xh = sb.Xh; g.ln_xl = sb.Xl;
+                    g.ln_xl8 = Xl8; g.ln_cnt = sb.ln_cnt; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
+                    if (int rc = run_gemm_ln_small(h, KC_GEMM_OUT, g)) return rc;
+                } else {
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
                                         sb.Xl, mxv2, 0))
                     return rc;
+                }
             }
             const HalfPair& w1 = h->wsplit[p + ".linear1.weight"];
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w1.hi; g.Wlo = w1.lo;
@@ -605,10 +628,16 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
                 set_w8(h, g, p + ".linear2.weight");
                 g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
+                if (ln_small && small_ln_fits(M, g.K)) {
+                    g.ln_gamma = W(h, p + ".norm2.weight"); g.ln_beta = W(h, p + ".norm2.bias"); g.ln_xh = sb.Xh; g.ln_xl = sb.Xl;
+                    g.ln_xl8 = Xl8; g.ln_cnt = sb.ln_cnt; g.ln_eps = 1e-5f; g.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
+                    if (int rc = run_gemm_ln_small(h, KC_GEMM_FF2, g)) return rc;
+                } else {
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
                                         sb.Xl, mxv2, l + 1 == h->tf_layer))
                     return rc;
+                }
             }
         }
         // concat3 -> concat4 -> output layer -> sampler update -> next embedding in ONE kernel (tail_f16x3.hpp; bit-identical
@@ -825,6 +854,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     const StepBuffers& sb = sbs[0];
     if (precision != JMID_PREC_F32) {
         HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
+        for (int l = 0; l < lanes; ++l) HIPCHK(h, hipMemsetAsync(sbs[l].ln_cnt, 0, kLnCounters * sizeof(unsigned), h->stream));
         for (int l = 0; l < lanes; ++l)
             if (sbs[l].Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
                 HIPCHK(h, hipMemsetAsync(sbs[l].Vth, 0, sbs[l].vt_elems * sizeof(half_t), h->stream));
@@ -958,6 +988,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (flag) ++h->erange_calls;
+        if (flag) h->last_pos = nullptr;     // the integrated positions are poisoned too: jmid_topk(pos = NULL) must not rank them
         if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
     } else if (mem == JMID_MEM_HOST) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1319,6 +1350,7 @@ int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* n
         Carver c0(nullptr);
         c0.take(n * Th * 6); c0.take(n * 2 * Th * 6); c0.take(n * 2); c0.take(n * 2 * H);
         if (int rc = ensure_arena(h, c0.off)) return rc;
+        h->last_pos = nullptr;        // the staging buffers below overwrite the workspace the last positions live in
         Carver c(h->arena);
         float* dx = c.take(n * Th * 6);
         float* dn = c.take(n * 2 * Th * 6);
@@ -1376,6 +1408,7 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
         Carver c0(nullptr);
         c0.take(np_); c0.take(ng); c0.take((size_t)E * 4);
         if (int rc = ensure_arena(h, c0.off)) return rc;
+        h->last_pos = nullptr;        // (as in jmid_encode)
         Carver c(h->arena);
         float* a = c.take(np_);
         float* b = c.take(ng);
@@ -1411,7 +1444,9 @@ int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* p
     const int d = 2 * A;
     const size_t n_pos = (size_t)E * K * A * T * 2, n_sel = (size_t)E * A * k * T * 2, n_lw = (size_t)E * A * k;
     auto up = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t o_ll = 0, o_Y = up((size_t)E * T * K * 8), o_bw = o_Y + up((size_t)E * T * K * d * 8), o_pos = o_bw + up(T * 4),
+    // the global buffer of whitened points only when they do not fit in LDS (E = 64, T = 12, K = 1024, A = 32 would be 400 MB)
+    const size_t y_bytes = kde_y_in_lds(A, K) ? 0 : up((size_t)E * T * K * d * 8);
+    const size_t o_ll = 0, o_Y = up((size_t)E * T * K * 8), o_bw = o_Y + y_bytes, o_pos = o_bw + up(T * 4),
                  o_sel = o_pos + (pos && mem == JMID_MEM_HOST ? up(n_pos * 4) : 0), o_lw = o_sel + (mem == JMID_MEM_HOST ? up(n_sel * 4) : 0),
                  need = o_lw + (mem == JMID_MEM_HOST ? up(n_lw * 4) : 0);
     if (need > h->kde_ws_bytes) {
@@ -1492,6 +1527,9 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_pf", &Tuning::attn_pf, 0, 2},
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
+        {"gemm_small", &Tuning::gemm_small, 0, 1},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
+        {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches
+        {"small_pn", &Tuning::small_pn, 0, 8},                 // column groups of its XCD tile order: 0 auto
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
@@ -1753,7 +1791,7 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
     float* dG = (float*)dalloc(N * 4, gamma);
     float* dT = (float*)dalloc(N * 4, beta);
     float* dX = (float*)dalloc((size_t)M * N * 4, X);
-    float* dY = (float*)dalloc((size_t)M * N * 4, nullptr);
+    float* dY = (float*)dalloc((size_t)(M + 63) / 64 * 64 * N * 4, nullptr);
     const size_t pa = blk_plane_elems(M, K) * 2, pw = blk_plane_elems(N, K) * 2, px = blk_plane_elems(M, N) * 2;
     half_t* ah = (half_t*)dalloc(pa, nullptr);
     half_t* al = (half_t*)dalloc(pa, nullptr);
@@ -1780,8 +1818,15 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
     } else {
         GemmHArgs g{};
         g.Ahi = ah; g.Alo = al; g.Whi = wh; g.Wlo = wl; g.W8 = img.p; g.bias = dB; g.C = dY; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        if (fused == 2) {        // the small-launch kernel with the LayerNorm tail (gemm_small.hpp, OUT_LN)
+            unsigned* cnt = (unsigned*)dalloc(kLnCounters * sizeof(unsigned), nullptr);
+            if (!cnt || !small_ln_fits(M, K)) return fail(h, JMID_EINVAL, "jmid_dbg_gemm_ln_mx: shape does not take the small fused kernel");
+            g.ln_gamma = dG; g.ln_beta = dT; g.ln_xh = xh; g.ln_xl = nullptr; g.ln_xl8 = xl8; g.ln_cnt = cnt; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
+            rc = run_gemm_ln_small(h, KC_GEMM_OUT, g);
+        } else {
         rc = run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g);
         if (!rc) rc = run_add_ln(h, nullptr, dY, dG, dT, M, N, xh, reinterpret_cast<half_t*>(xl8), true, 0);
+        }
     }
     if (!rc) {
         hipLaunchKernelGGL(merge_planes_lo8_kernel, dim3(512), dim3(256), 0, h->stream, xh, xl8, dX, M);

@@ -311,8 +311,9 @@ class JmidEngine:
                                                  _lib.PRECISIONS[precision], C.c_void_p(out.ctypes.data)))
         return out
 
-    def dbg_gemm_ln_mx(self, A: np.ndarray, Wt: np.ndarray, bias, gamma, beta, X: np.ndarray, fused: bool) -> np.ndarray:
-        """LayerNorm(X + A Wt^T + bias) with the F16MX second-generation kernels (d_model 512): fused kernel or GEMM + add_ln2."""
+    def dbg_gemm_ln_mx(self, A: np.ndarray, Wt: np.ndarray, bias, gamma, beta, X: np.ndarray, fused) -> np.ndarray:
+        """LayerNorm(X + A Wt^T + bias) with the F16MX second-generation kernels (d_model 512): fused = 1 the row-complete kernel,
+        0 the GEMM + add_ln2 pair, 2 the small-launch GEMM whose last workgroup per row tile normalises (gemm_small.hpp)."""
         A = np.ascontiguousarray(A, np.float32)
         Wt = np.ascontiguousarray(Wt, np.float32)
         X = np.array(X, np.float32, order="C", copy=True)
@@ -321,7 +322,7 @@ class JmidEngine:
         assert Wt.shape == (512, K) and X.shape == (M, 512)
         self._check(self._lib.jmid_dbg_gemm_ln_mx(self._h, M, K, C.c_void_p(A.ctypes.data), C.c_void_p(Wt.ctypes.data),
                                                   *[C.c_void_p(t.ctypes.data) for t in v], C.c_void_p(X.ctypes.data),
-                                                  int(bool(fused))))
+                                                  int(fused)))
         return X
 
     def dbg_add_layernorm(self, X: np.ndarray, Y: np.ndarray, gamma: np.ndarray, beta: np.ndarray) -> np.ndarray:

@@ -41,9 +41,10 @@ def test_bench_json_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert c["processes"] * c["threads_per_process"] == c["cores"] <= c["hardware_threads"]
     # the headline is the throughput mode (an explicit opt-in of the drop-in class, whose own default is the fp32-class mode) ...
-    from safe_interactive_crowdnav_amd.forecaster import HumanTrajectoryForecasterSim
+    from safe_interactive_crowdnav_amd import forecaster as FC
     import inspect
-    assert inspect.signature(HumanTrajectoryForecasterSim.__init__).parameters["precision"].default == "f16x3"
+    assert inspect.signature(FC.HumanTrajectoryForecasterSim.__init__).parameters["precision"].default is None     # -> DEFAULTS
+    assert FC.DEFAULTS["precision"] == "f16x3"
     assert j["config"]["precision"] == "f16mx" and j["parity"]["precision"] == "f16mx"
     assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
     # ... and all split modes are measured the same way and reported under the same keys

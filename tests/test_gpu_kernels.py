@@ -138,3 +138,29 @@ def test_f16mx_fused_gemm_layernorm_gen2_matches_float64_and_its_unfused_pair(M,
     # inputs enter as fp16 (A_hi, X as hi + bf8(lo)): 2^-11 relative per operand, outputs leave as hi + bf8(lo)
     assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
     np.testing.assert_array_equal(fused, pair)
+
+
+@pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128)])
+def test_small_launch_gemm_with_layernorm_tail_equals_its_unfused_pair(M, K):
+    """gemm_small_kernel<.., OUT_LN> (one scene: out_proj / linear2 + residual + LayerNorm in ONE launch, the rows normalised by
+    the last-arriving workgroup of each 64-row tile after an sc1 hand-off) against float64 and bit for bit against the GEMM +
+    add_ln2 pair - repeated, so that an unlucky arrival order or a stale line would show (every word is compared)."""
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
+    try:
+        rng = np.random.default_rng(M + K)
+        A = rng.standard_normal((M, K)).astype(np.float32) * np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
+        W = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32) * np.linspace(1.5, 0.5, 512, dtype=np.float32)[:, None]
+        b, g, t = (rng.standard_normal(512).astype(np.float32) for _ in range(3))
+        X = rng.standard_normal((M, 512)).astype(np.float32) * 2.0
+        eng.set_tuning("gemm_small", 1)
+        pair = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=0)          # round-3 tile shapes + add_ln2
+        eng.set_tuning("gemm_small", 0)
+        eng.set_tuning("small_ln", 1)                                 # (opt-in: measured slower than the pair for one scene)
+        for _ in range(5):
+            fused = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=2)
+            np.testing.assert_array_equal(fused, pair)
+    finally:
+        eng.close()
+    v = X.astype(np.float64) + A.astype(np.float64) @ W.astype(np.float64).T + b
+    ref = (v - v.mean(1, keepdims=True)) / np.sqrt(v.var(1, keepdims=True) + 1e-5) * g + t
+    assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
