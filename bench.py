@@ -150,6 +150,24 @@ def cpu_worker(job):
 _CPU_READY = None
 
 
+def physical_cores():
+    """Physical cores of the host (unique (socket, core) pairs of /proc/cpuinfo); None when it cannot be told."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
 def cpu_init(ready, seed, threads, joint, K, eps1):
     """Start-up of one CPU-baseline worker (imports, weights from the seed, a 2-step oracle run), kept out of the timed
     region: the parent waits until every worker has counted itself ready."""
@@ -255,6 +273,14 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (one rank per GPU); gloo = host gather (lets several ranks share one GPU)")
     ap.add_argument("--device", type=int, default=-1, help="HIP device of this rank (-1 = LOCAL_RANK)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="weak = --episodes-per-gpu (workload default) on every GPU; strong = a FIXED total (--total-episodes, default "
+                         "4096 = BASELINE configs[4]) block-partitioned over the ranks (sweep.shard_range); auto = weak on one GPU, "
+                         "strong on several - per-N values then divide into a speed-up")
+    ap.add_argument("--total-episodes", type=int, default=4096, help="episodes of the whole job with --scaling strong")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not re-run one 51-episode call under rocprofv3 --pmc after the timed region (roofline.traffic / mfma_busy "
+                         "then come from the committed profiles/ summary, labelled as such)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run every collective even with one rank (exercises the RCCL calls "
                          "of the N > 1 path on a one-GPU box)")
@@ -285,6 +311,15 @@ def main():
     E, N, K, H, steps50 = WORKLOADS[args.workload]
     if args.episodes_per_gpu > 0:
         E = args.episodes_per_gpu
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 and args.episodes_per_gpu <= 0 else "weak")
+    ep_lo = rank * E                       # first episode (global index) of this rank
+    if scaling == "strong":                # fixed total, block partition: rank g owns [g T / G, (g + 1) T / G)  
+        from safe_interactive_crowdnav_amd.sweep import shard_range
+        ep_lo, ep_hi = shard_range(args.total_episodes, rank, world)
+        E = ep_hi - ep_lo
+        if E <= 0:
+            raise SystemExit(f"--total-episodes {args.total_episodes} leaves rank {rank} of {world} without work")
+    total_eps = args.total_episodes if scaling == "strong" else E * world
     joint = args.net == "jmid"
     dims = NetDims(ctx_dim=256)
     weights = JMIDWeights.from_seed(dims, args.seed)
@@ -313,7 +348,7 @@ def main():
     p0 = torch.from_numpy(syn["p0"]).to(dev)
     gt = torch.from_numpy(syn["gt"]).to(dev)
     x_T_host = torch.stack([torch.randn([K * A, H, 2], generator=torch.Generator().manual_seed(
-        args.seed + rank * E + e)) for e in range(E)])
+        args.seed + ep_lo + e)) for e in range(E)])      # per GLOBAL episode: results do not depend on the partition
     x_T = x_T_host.to(dev)
 
     def one_step(precision):
@@ -321,8 +356,7 @@ def main():
         vel, pos = eng.denoise(x_T, ctx.view(E, A, -1), p0, dt=0.25, precision=precision, want_vel=False)
         met = eng.episode_metrics(pos, gt)
         eng.synchronize()            # the library runs on its own stream
-        allm = gather_metrics(met, E * world, force=args.force_dist)
-        return pos, met, allm
+        return pos, met
 
     def barrier():
         torch.cuda.synchronize()
@@ -331,7 +365,37 @@ def main():
             torch.cuda.synchronize()
 
     fl = algorithmic_flops(dims, joint, E, A, K, H)
-    traj = world * E * A * K
+    traj = total_eps * A * K               # the whole job's trajectories per step
+
+    def fill_pmc(res, precision, pmc, src):
+        """roofline.traffic / mfma_busy / hbm of a mode from a per-call PMC summary: the one measured in this run
+        (tools/pmc_summary.py re-runs one 51-episode call under rocprofv3 --pmc after the timed region) or, failing that, the
+        newest committed profiles/rNN_pmc_call_<mode>.json - `source` says which, with the file's git blob hash."""
+        ctx, roof = res.pop("_pmc_ctx", None), res.get("roofline")
+        if not (ctx and roof and pmc and joint and (N, K, H, steps50) == (5, 20, 12, 50)):
+            return
+        dom = ctx["dom"]
+        kname = PMC_KERNEL_OF_CLASS.get(dom)
+        knames = (kname,) if isinstance(kname, str) else (kname or ())
+        rows = [v for k, v in pmc.get("kernels", {}).items() if any(n in k for n in knames) and v.get("launches", 0) >= 50]
+        if rows:
+            r = max(rows, key=lambda v: v["hbm_bytes_per_launch"])
+            # per launch of the SAME launches `achieved` is quoted on (the exclusive pass runs the one-lane chunk plan)
+            chunks_per_step = ctx["launches"] / (steps50 * ctx["passes"] * dims.tf_layer)
+            tokens_per_launch = E * A * K * H / chunks_per_step
+            roof["traffic"] = r["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
+            roof["traffic_source"] = dict(src, kernel=r.get("name"), measured_at_tokens=pmc["tokens"],
+                                          note="HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of the production "
+                                               "kernel inside one whole predictor call, scaled to this run's tokens per launch")
+            if "mfma_busy" in r:
+                roof["mfma_busy"] = {"dominant_kernel": r["mfma_busy"], "whole_call": pmc.get("whole_call_mfma_busy"),
+                                     "source": src}
+        bpt = pmc["call"]["hbm_bytes_per_trajectory"]
+        res["hbm"] = {"bytes_per_trajectory": bpt, "GBps": round(bpt * res["value"] / world / 1e9, 1),
+                      "peak_GBps": 8000.0, "frac": round(bpt * res["value"] / world / 8e12, 4), "source": src,
+                      "note": "PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of one whole predictor call on one chunk, "
+                              "per trajectory, times this run's per-GPU traj/s",
+                      "model_bytes_per_trajectory": {"layer_streamed_bf16": 34.9e6, "minimal": 9600}}
 
     def measure(precision):
         """W warm-up steps, one untimed profiling step, K timed steps between barriers: identical for every mode."""
@@ -356,18 +420,33 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            pos, met, allm = one_step(precision)
+            pos, met = one_step(precision)
+        own = time.perf_counter() - t0         # this rank's own K steps (no collective inside: episodes are independent)
         barrier()
         elapsed = time.perf_counter() - t0
+        rank_ms = [1e3 * own / args.steps]
         if use_dist:
             tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             elapsed = float(tt.item())
+            mine = torch.tensor([own], dtype=torch.float64, device=coll_dev)
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            rank_ms = [1e3 * float(v.item()) / args.steps for v in every]
+        # the sweep's ONE collective: the per-episode metric rows of the last step, gathered to rank 0 after the timed steps
+        #  and timed on its own - it is off the data path and says nothing about the kernels
+        tg = time.perf_counter()
+        allm = gather_metrics(met, total_eps, force=args.force_dist)
+        gather_ms = 1e3 * (time.perf_counter() - tg)
         prof = eng.profile_get() if not args.no_profile else {}
         eng.profile_disable()
         log(f"[{precision}] timed region: {elapsed:.3f}s for {args.steps} steps")
         res = {"value": round(traj * args.steps / elapsed, 2), "unit": "traj/s", "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "dtype": DTYPE_TEXT[precision]}
+               "ms_per_step": round(1e3 * elapsed / args.steps, 3), "dtype": DTYPE_TEXT[precision],
+               "ranks_seen": int(dist.get_world_size()) if use_dist else 1,
+               "per_rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3),
+                                        "all": [round(v, 3) for v in rank_ms]},
+               "gather_ms": round(gather_ms, 3)}
         if prof and rank == 0:
             per = {}
             for cls in PROF_CLASSES:       # untimed profiling step (one pass over the batch)
@@ -408,31 +487,8 @@ def main():
                             "sustains 1.66 PFLOP/s at the 1.4 kW power cap (tools/mfma_peak.hip, warm clocks); this mode "
                             f"spends {passes} MFMA FLOPs per algorithmic FLOP of this kernel; path_achieved = algorithmic "
                             "FLOPs of all MFMA kernel classes / wall time of the timed region"}
-            # PMC-derived fields are NOT measured in this run: they come from the newest committed per-call PMC summary of
-            # this mode (separate rocprofv3 --pmc passes, tools/pmc_call.sh) and say so, with the file's git blob hash
-            pmc, src = pmc_summary(precision)
-            if pmc and joint and (N, K, H, steps50) == (5, 20, 12, 50):
-                kname = PMC_KERNEL_OF_CLASS.get(dom)
-                knames = (kname,) if isinstance(kname, str) else (kname or ())
-                rows = [v for k, v in pmc.get("kernels", {}).items() if any(n in k for n in knames) and v.get("launches", 0) >= 50]
-                if rows:
-                    r = max(rows, key=lambda v: v["hbm_bytes_per_launch"])
-                    # per launch of the SAME launches `achieved` is quoted on (the exclusive pass runs the one-lane chunk plan)
-                    chunks_per_step = dom_x["launches"] / (steps50 * (args.steps if args.lanes == 1 else 1) * dims.tf_layer)
-                    tokens_per_launch = E * A * K * H / chunks_per_step
-                    roof["traffic"] = r["hbm_bytes_per_launch"] * tokens_per_launch / pmc["tokens"]
-                    roof["traffic_source"] = dict(src, kernel=r.get("name"), measured_at_tokens=pmc["tokens"],
-                                                  note="HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE of the production "
-                                                       "kernel inside one whole predictor call, scaled to this run's tokens per launch")
-                    if "mfma_busy" in r:
-                        roof["mfma_busy"] = {"dominant_kernel": r["mfma_busy"], "whole_call": pmc.get("whole_call_mfma_busy"),
-                                             "source": src}
-                bpt = pmc["call"]["hbm_bytes_per_trajectory"]
-                res["hbm"] = {"bytes_per_trajectory": bpt, "GBps": round(bpt * res["value"] / world / 1e9, 1),
-                              "peak_GBps": 8000.0, "frac": round(bpt * res["value"] / world / 8e12, 4), "source": src,
-                              "note": "PMC bytes (2 x FETCH_SIZE + WRITE_SIZE) of one whole predictor call on one chunk, "
-                                      "per trajectory, times this run's per-GPU traj/s",
-                              "model_bytes_per_trajectory": {"layer_streamed_bf16": 34.9e6, "minimal": 9600}}
+            # what fill_pmc() needs to scale a per-call PMC summary to this run's launches
+            res["_pmc_ctx"] = {"dom": dom, "launches": dom_x["launches"], "passes": (args.steps if args.lanes == 1 else 1)}
             res["roofline"] = roof
             res["kernels"] = {c: {"launches": v["launches"], "avg_ms": round(v["avg_ms"], 4),
                                   "total_ms": round(v["total_ms"], 2), "tflops": round(v["tflops"], 2)}
@@ -454,15 +510,41 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- PMC counters of THIS run's build on THIS box (headline mode): one whole 51-episode call re-run under rocprofv3,
+    # one counter group per pass (kernel-trace + pmc only), after the timed region; the other modes - and this one if
+    # rocprofv3 is missing or a pass fails - fall back to the committed profiles/ summary of the mode
+    for m in modes:
+        pmc, src = None, None
+        if m == args.precision and world == 1 and not args.no_pmc and joint and (N, K, H, steps50) == (5, 20, 12, 50):
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import pmc_summary as PS
+                tp = time.perf_counter()
+                pmc = PS.collect(m, episodes=51, timeout_s=150)
+                if pmc:
+                    src = {"measured_in_run": True, "command": pmc.pop("_command"), "seconds": round(time.perf_counter() - tp, 1)}
+                    log(f"[{m}] PMC passes in this run: {src['seconds']} s, {pmc['call']['hbm_bytes_per_trajectory']} B / trajectory")
+            except Exception as ex:          # never let a profiler problem take the bench line down
+                log(f"[{m}] in-run PMC failed ({type(ex).__name__}: {ex}); falling back to the committed summary")
+                pmc = None
+        if pmc is None:
+            pmc, src = pmc_summary(m)
+            if src:
+                src = dict(src, measured_in_run=False)
+        fill_pmc(results[m], m, pmc, src)
+
     head = results[args.precision]
     out = {
         "metric": "sampled trajectories/sec (N x K, 50 denoise steps)",
         "value": head["value"], "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": scaling,
+        "ranks_seen": head["ranks_seen"], "per_rank_ms_per_step": head["per_rank_ms_per_step"], "gather_ms": head["gather_ms"],
         "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {E} episodes/GPU x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
+        "config": {"workload": (f"{args.workload}: {E} episodes/GPU" if scaling == "weak" else
+                                f"cfg5-style strong scaling: {total_eps} episodes in total, block-partitioned over {world} GPU(s) "
+                                f"({E} on rank 0)") + f" x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
-                   "episodes_per_gpu": E, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
+                   "episodes_per_gpu": E, "total_episodes": total_eps, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
                    "net": args.net, "precision": args.precision, "lanes": args.lanes, "scenes": args.scenes,
                    "dist_backend": args.dist_backend if use_dist else None},
     }
@@ -544,8 +626,11 @@ def main():
             for k, v in env_keep.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         with pool:
+            t_wait = time.perf_counter()
             while ready.value < nproc_max:                   # every worker warm before any clock starts
                 time.sleep(0.05)
+                if time.perf_counter() - t_wait > 600:       # (a worker whose start-up raises is respawned for ever: do not wait for it)
+                    raise RuntimeError(f"cpu_baseline: only {ready.value} of {nproc_max} worker processes came up in 600 s")
             # how many workers side by side the host really carries (the affinity mask says `avail`, a CPU quota or shared
             # memory bandwidth may say less - and oversubscribed OpenMP teams collapse): a 2-step job on n workers at once,
             # n = max, max/2, ...; the sample then runs on the n with the best aggregate rate
@@ -577,7 +662,10 @@ def main():
         pos_ref = np.stack([got[e] for e in pick])
         out["cpu_baseline"] = {"value": round(ne * A * K / cpu_s, 2), "unit": "traj/s", "cores": nproc * threads,
                                "kind": "port", "processes": nproc, "threads_per_process": threads,
-                               "hardware_threads": avail, "worker_scaling_jobs_per_s": {str(k): v for k, v in scaling.items()},
+                               "hardware_threads": avail, "host_physical_cores": physical_cores(),
+                               "cores_note": "cores = processes x threads_per_process actually used by the timed sample (the best "
+                                             "of the measured splits); host_physical_cores / hardware_threads = what the host has",
+                               "worker_scaling_jobs_per_s": {str(k): v for k, v in scaling.items()},
                                "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, {cpu_s:.1f} s wall; "
                                          f"oracle/jmid_oracle.py, torch-CPU fp32, {nproc} processes x {threads} threads)"}
         for m in modes:

@@ -39,8 +39,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+typedef struct jmid_ctx* jmid_handle_t;      /* opaque */
 
-typedef struct jmid_ctx* jmid_handle_t;
+/* The library is built with -fvisibility=hidden: the entry points below are all the C++ host code it exports (next to the
+ * kernel handles the HIP runtime needs). */
+#pragma GCC visibility push(default)
 
 enum { JMID_NET_IMID = 0, JMID_NET_JMID = 1 };
 enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
@@ -240,6 +243,7 @@ int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float*
                            const float* beta);
 #endif /* JMID_DIAGNOSTICS */
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -69,19 +69,20 @@ class JmidError(RuntimeError):
         self.code = code
 
 
-_LIB = None
+_LIBS = {}
 
 
-def load_library() -> C.CDLL:
-    """Load (once) the in-tree HIP library.  Raises if it has not been built."""
-    global _LIB
-    if _LIB is not None:
-        return _LIB
+def load_library(path: str = None) -> C.CDLL:
+    """Load (once per path) the in-tree HIP library - ``path`` = None: the product's (``build.library_path()``: csrc/libjmid_hip.so
+    unless JMID_LIB names another build).  Raises if it has not been built.  (Tests load both flavours side by side.)"""
+    key = os.path.abspath(path or library_path())
+    if key in _LIBS:
+        return _LIBS[key]
     # torch first: it bundles its own HIP runtime (libamdhip64) and must be the one instance in the process,
     # otherwise a second runtime loaded from /opt/rocm sees no device and device pointers cannot be shared
     import torch  # noqa: F401
 
-    path = library_path()
+    path = key
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -97,5 +98,5 @@ def load_library() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-    _LIB = lib
+    _LIBS[key] = lib
     return lib

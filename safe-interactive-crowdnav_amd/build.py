@@ -17,9 +17,9 @@ def _newest_source_mtime() -> float:
     m = 0.0
     for root in (CSRC, os.path.join(os.path.dirname(CSRC), "..", "include")):
         for f in os.listdir(root):
-            if f.endswith((".hip", ".hpp", ".h")):
+            if f.endswith((".hip", ".hpp", ".h", ".map")):
                 m = max(m, os.path.getmtime(os.path.join(root, f)))
-    return m
+    return max(m, os.path.getmtime(os.path.abspath(__file__)))       # (the command line lives in this file)
 
 
 def library_path() -> str:
@@ -43,9 +43,9 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
     # 400 overlaps, 0 with straight selects or other co-runners) - the cause of the run-to-run variation with several
     # chunks in flight (docs/NOTEBOOK.md section 3).  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
     # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-ffp-contract=off",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-ffp-contract=off",
            "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else []) + \
-          ["-o", LIB] + SOURCES
+          ["-Wl,--version-script=libjmid.map", "-o", LIB] + SOURCES
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

@@ -1331,8 +1331,11 @@ template <int EPI, int OUT>
 inline hipError_t launch_gemm_mx(const GemmHArgs& g, hipStream_t st) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     const int v = tune().gemm_h_variant;
+    // the 256 x 128 shape with the ConcatSquash epilogue into fp32 (concat4: N = 128, never enough tiles for it) spills: not instantiated
+    constexpr bool has_256x128 = !(EPI == EPI_CSL && OUT == OUT_F32);
     if (v == 3) return launch_gemm_mx_128<EPI, OUT>(g, st);
-    if (v == 4) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
+    if constexpr (has_256x128)
+        if (v == 4) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
     if (v == 5) return launch_gemm_mx_64<EPI, OUT>(g, st);
     if constexpr (EPI != EPI_CSL)
         if (v == 6 && g.N % 256 == 0) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
@@ -1347,7 +1350,8 @@ inline hipError_t launch_gemm_mx(const GemmHArgs& g, hipStream_t st) {
             const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);
             if ((nbq >= 256 && 1.2 * eff(nbq) >= eff(nb256)) || (nbq < 256 && g.M >= 7168)) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
         }
-    if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
+    if constexpr (has_256x128)
+        if (nb256 >= 256 && 1.2 * eff(nb256) >= eff(big)) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
     return launch_gemm_mx_128<EPI, OUT>(g, st);
 }
 
@@ -1452,14 +1456,16 @@ inline hipError_t launch_gemm_h_mode(const GemmHArgs& g, hipStream_t st) {
     if (v == 3) return launch_gemm_h_dma<EPI, OUT, X2>(g, st);
     if (v == 4) return launch_gemm_h_dma256<EPI, OUT, X2>(g, st);
     if (v == 5) return launch_gemm_h_dma64<EPI, OUT, X2>(g, st);
-    if (v == 6 && g.N % 256 == 0) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
+    // (the ConcatSquash epilogue next to 128 accumulators spills: that shape is not instantiated for it)
+    if constexpr (EPI != EPI_CSL)
+        if (v == 6 && g.N % 256 == 0) return launch_gemm_h_dma256x256<EPI, OUT, X2>(g, st);
     if (big < 256) return launch_gemm_h_dma64<EPI, OUT, X2>(g, st);
     // auto: 256x128 unless the coarser grid quantises badly onto the 256 CUs (one workgroup per CU)
     const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };
     // 256x256 when N allows it (in_proj, linear1) and the grid still fills the chip; the ConcatSquash epilogue needs
     // too many registers next to the 128 accumulators
-    if (EPI != EPI_CSL && g.N % 256 == 0) {
+    if constexpr (EPI != EPI_CSL) if (g.N % 256 == 0) {
         // (below one workgroup per CU too from 12288 rows - two chunks are in flight: 2 x 12 episodes per call 76.0 vs 79.7 ms
         // in F16X2, 102.2 vs 107.5 in F16X3; 2 x 8: within 1 %)
         const long nbq = (long)((g.M + 255) / 256) * (g.N / 256);

@@ -360,13 +360,15 @@ inline void launch_gemm_ln2_cfg(const GemmLn2Args& g, hipStream_t st) {
     hipLaunchKernelGGL((gemm_ln2_mx_kernel<WM, WN>), dim3((g.M + C::BM - 1) / C::BM), dim3(C::NT), C::LDS_BYTES, st, g);
 }
 inline hipError_t launch_gemm_ln2_mx(const GemmLn2Args& g, hipStream_t st) {
-    // the row tile by how well the grid fills whole rounds of the resident slots (one 128-row workgroup or two 64-row ones per
-    // CU); at equal fill the 128-row kernel wins (W streams through L2 -> LDS half as often)
-    auto fill = [](long n, long slots) { return (double)n / (double)(((n + slots - 1) / slots) * slots); };
-    const long n128 = (g.M + 127) / 128, n64 = (g.M + 63) / 64;
-    const int rows = tune().ln_rows;
-    if (rows == 128 || (rows == 0 && 1.1 * fill(n128, 256) >= fill(n64, 512))) launch_gemm_ln2_cfg<4, 2>(g, st);
-    else launch_gemm_ln2_cfg<2, 4>(g, st);
+#ifdef JMID_DIAGNOSTICS
+    // the 64-row shape (two workgroups per CU; measured 10 % slower on full launches, and hipcc spills 48 registers in it) exists
+    // in the diagnostics flavour only, behind the "ln_rows" knob: the production library always runs the 128-row shape
+    if (tune().ln_rows == 64) {
+        launch_gemm_ln2_cfg<2, 4>(g, st);
+        return hipGetLastError();
+    }
+#endif
+    launch_gemm_ln2_cfg<4, 2>(g, st);
     return hipGetLastError();
 }
 

@@ -52,8 +52,8 @@ class JmidEngine:
     """One predictor engine (weights resident on one GPU, one HIP stream)."""
 
     def __init__(self, weights: JMIDWeights, joint: bool, device_id: int = 0, hist_len: int = 6,
-                 step: int = 50, schedule: Optional[VarianceSchedule] = None):
-        self._lib = _lib.load_library()
+                 step: int = 50, schedule: Optional[VarianceSchedule] = None, lib_path: Optional[str] = None):
+        self._lib = _lib.load_library(lib_path)      # lib_path: another build of the library (tests: both flavours in one process)
         self._h = _lib.Handle()
         self.dims = weights.dims
         self.joint = bool(joint)

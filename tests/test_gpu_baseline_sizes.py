@@ -25,6 +25,12 @@ from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 ADE_GATE = 1e-4
 SPLIT_MODES = ["f16x3", "f16x2", "f16mx"]
+# The session runs on the diagnostics flavour of the library (tests/conftest.py).  The BASELINE-size checks below run a second
+# time on the library that SHIPS (csrc/libjmid_hip.so, loaded next to it in the same process), in the mode bench.py quotes and in
+# the class default, and hold it to the oracle / the reference fixture AND to the diagnostics flavour's bits.
+PROD_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc",
+                        "libjmid_hip.so")
+PROD_MODES = ["f16mx", "f16x3"]
 
 
 def ade(a, b):
@@ -59,8 +65,10 @@ def cfg3():
             assert np.abs(c.numpy() - ctx[e].cpu().numpy()).max() < 1e-5
             v = O.denoise(w.tensors, c, x_T[e], sample=K, step=50, joint=True)
             ref[e] = O.integrate(v, p0[e], 0.25).numpy()
-    yield dict(eng=eng, ctx=ctx, x_T=x_T.cuda(), p0=p0.cuda(), ref=ref, picks=picks, dims=(E, A, K, T))
+    eng_prod = JmidEngine(w, joint=True, step=50, lib_path=PROD_LIB)
+    yield dict(eng=eng, eng_prod=eng_prod, ctx=ctx, x_T=x_T.cuda(), p0=p0.cuda(), ref=ref, picks=picks, dims=(E, A, K, T))
     eng.close()
+    eng_prod.close()
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)
@@ -168,8 +176,10 @@ def cfg5():
             c = O.encode_context(w.tensors, x_st[e * A:(e + 1) * A], nbr[e * A:(e + 1) * A], em[e * A:(e + 1) * A])
             v = O.denoise(w.tensors, c, x_T[e], sample=K, step=50, joint=True)
             ref[e] = O.integrate(v, p0[e], 0.25).numpy()
-    yield dict(eng=eng, ctx=ctx, x_T=x_T.cuda(), p0=p0.cuda(), gt=gt, ref=ref, picks=picks)
+    eng_prod = JmidEngine(w, joint=True, step=50, lib_path=PROD_LIB)
+    yield dict(eng=eng, eng_prod=eng_prod, ctx=ctx, x_T=x_T.cuda(), p0=p0.cuda(), gt=gt, ref=ref, picks=picks)
     eng.close()
+    eng_prod.close()
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)
@@ -209,3 +219,65 @@ def test_cfg3_chunks_in_flight_do_not_change_a_bit(cfg3, precision):
         eng.set_tuning("lanes", 2)
     per = {e: ade(ref[e].cpu().numpy(), cfg3["ref"][e]) for e in cfg3["picks"]}
     assert max(per.values()) <= ADE_GATE
+
+
+# ------------------------------------------------------------------------------------------- the library that ships
+def _is_production(eng):
+    return not eng._lib.has_diagnostics and b"diagnostics" not in eng._lib.jmid_version()
+
+
+@pytest.mark.parametrize("precision", PROD_MODES)
+def test_production_library_cfg3_chunk_boundaries(cfg3, precision):
+    """cfg3 on csrc/libjmid_hip.so: both sides of every chunk boundary of the automatic plan and of 5 x 51 + 1 against the oracle,
+    the two plans bit-identical, and bit-identical to the diagnostics flavour (same kernels, now measured rather than assumed)."""
+    eng, diag, picks = cfg3["eng_prod"], cfg3["eng"], cfg3["picks"]
+    assert _is_production(eng) and not _is_production(diag)
+    outs = {}
+    try:
+        for chunk in (0, 51):
+            eng.set_chunk_episodes(chunk)
+            outs[chunk] = eng.denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision=precision, want_vel=False)[1]
+    finally:
+        eng.set_chunk_episodes(0)
+    ref_diag = diag.denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision=precision, want_vel=False)[1]
+    assert torch.equal(outs[0], outs[51]) and torch.equal(outs[0], ref_diag)
+    pos = outs[0].cpu().numpy()
+    per = {e: ade(pos[e], cfg3["ref"][e]) for e in picks}
+    print(f"cfg3 on the production library [{precision}]: worst episode ADE vs oracle = {max(per.values()):.3e}")
+    assert max(per.values()) <= ADE_GATE, per
+    assert eng.erange_count() == 0
+
+
+@pytest.mark.parametrize("precision", PROD_MODES)
+def test_production_library_cfg4_at_its_real_step_count(precision):
+    """BASELINE configs[3] (N=25, K=64: one 19 200-key sequence, 50 steps) on the production library against the REFERENCE's
+    own output (tests/golden/net_jmid_w256_a25k64t12_s50.npz)."""
+    z = np.load(os.path.join(GOLDEN, "net_jmid_w256_a25k64t12_s50.npz"))
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=int(z["ctx_dim"])), int(z["wseed"]))
+    eng = JmidEngine(w, joint=True, step=int(z["step"]), lib_path=PROD_LIB)
+    try:
+        assert _is_production(eng)
+        x_T = torch.from_numpy(z["x_T"])[None].cuda()
+        ctx = torch.from_numpy(z["ctx"])[None].cuda()
+        vel, _ = eng.denoise(x_T, ctx, precision=precision, want_pos=False)
+        assert eng.erange_count() == 0
+    finally:
+        eng.close()
+    a = ade(vel.cpu().numpy()[0], z["vel"])
+    print(f"cfg4, 50 steps, production library [{precision}]: mean L2(velocity) vs the reference = {a:.3e}")
+    assert a <= ADE_GATE
+
+
+@pytest.mark.parametrize("precision", PROD_MODES)
+def test_production_library_cfg5_shard(cfg5, precision):
+    """The 512-episode shard of rank 3 on the production library: one episode of every chunk against the oracle, and the whole
+    shard bit-identical to the diagnostics flavour."""
+    eng, diag = cfg5["eng_prod"], cfg5["eng"]
+    assert _is_production(eng)
+    pos = eng.denoise(cfg5["x_T"], cfg5["ctx"], cfg5["p0"], dt=0.25, precision=precision, want_vel=False)[1]
+    ref_diag = diag.denoise(cfg5["x_T"], cfg5["ctx"], cfg5["p0"], dt=0.25, precision=precision, want_vel=False)[1]
+    assert torch.equal(pos, ref_diag)
+    pos = pos.cpu().numpy()
+    worst = max(ade(pos[e], cfg5["ref"][e]) for e in cfg5["picks"])
+    print(f"cfg5 shard on the production library [{precision}]: worst sampled episode ADE vs oracle = {worst:.3e}")
+    assert worst <= ADE_GATE and eng.erange_count() == 0

@@ -72,11 +72,19 @@ def test_bench_json_contract():
             assert t["ms_per_call"] > 0 and t["erange_fallbacks"] == 0
             assert abs(t["host_scene_ms"] + t["device_ms"] + t["topk_ms"] + t["host_assemble_ms"] - t["ms_per_call"]) < 0.5 * t["ms_per_call"]
     assert "jmid_topk" in fe["shipped"]["topk"]
-    # PMC-derived fields name the committed profile they were read from
+    # PMC-derived fields say where they come from: counters collected in this run (one 51-episode call re-run under
+    # rocprofv3 --pmc after the timed region) or, failing that, the committed profile they were read from
     for k in ("traffic_source", "mfma_busy"):
         if k in r:
             src = r[k]["source"] if k == "mfma_busy" else r[k]
-            assert src["file"].startswith("profiles/") and len(src["git_blob_sha1"]) == 40
+            assert src["measured_in_run"] is True or (src["file"].startswith("profiles/") and len(src["git_blob_sha1"]) == 40)
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert r["traffic_source"]["measured_in_run"] is True and r["traffic"] > 0, r.get("traffic_source")
+        assert j["hbm"]["source"]["measured_in_run"] is True and 0 < j["hbm"]["frac"] < 1
+    # one rank: the per-rank fields are there and trivial; the metric gather is timed outside the steps
+    assert j["ranks_seen"] == 1 and j["per_rank_ms_per_step"]["min"] == j["per_rank_ms_per_step"]["max"] and j["gather_ms"] >= 0
+    assert j["cpu_baseline"]["host_physical_cores"] is None or j["cpu_baseline"]["host_physical_cores"] >= 1
 
 
 def test_bench_two_ranks_share_one_gpu_over_gloo():
@@ -102,6 +110,25 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
     assert sm["mean_ADE_m"] > 0 and sm["mean_ADE_m"] == sm["mean_ADE_m"]     # no NaN padding rows leaked through
     # whole-job rate: 2 ranks x 5 episodes x 5 humans x 20 samples per step
     assert abs(j["value"] - 2 * 5 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+
+
+def test_bench_strong_scaling_two_ranks_share_one_gpu_over_gloo():
+    """`--gpus 2` defaults to STRONG scaling: a fixed total (here 7 episodes instead of configs[4]'s 4096) block-partitioned over
+    the ranks (sweep.shard_range: 4 + 3), no collective inside the timed steps, ONE gather of the metric rows after them,
+    per-rank step times and the ranks the process group saw in the JSON line.  Plain launch (bench.py spawns its ranks)."""
+    env = {k: v for k, v in PROD_ENV.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--total-episodes", "7", "--dist-backend", "gloo", "--device", "0", "--modes", "f16mx",
+                          "--cpu-episodes", "0", "--no-profile"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    j = _one_json_line(out)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["ranks_seen"] == 2
+    assert j["config"]["total_episodes"] == 7 and j["config"]["episodes_per_gpu"] == 4          # rank 0's block
+    assert j["sweep_metrics"]["episodes"] == 7
+    pr = j["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"] <= j["ms_per_step"] * 1.05 and j["gather_ms"] >= 0
+    # whole-job rate: the FIXED total per step
+    assert abs(j["value"] - 7 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
 
 
 def test_bench_launched_plainly_spawns_its_own_ranks():

@@ -1,0 +1,176 @@
+"""Where does each arithmetic mode leave the 1e-4 m gate?  Every ADE figure in this repository is on seeded random-init weights
+(the reference's trained blobs are absent), whose softmax logits are O(0.1) and whose activations are tame.  This sweep stresses
+the net the way a trained checkpoint might - weight scale, LayerNorm gain, heavy-tailed weights, peaked attention - on the two
+shapes the MPC issues (BASELINE cfg2: N=5, K=20, H=12, 50 steps; the reference's shipped point: N=3, K=100, H=8, 2 steps) and
+holds all four modes against the oracle evaluated in float64 (oracle/jmid_oracle.py, dtype-generic; pinned to the reference:
+sample_sicnav_inference, sicnav_diffusion/JMID/MID/models/diffusion.py:478-541).
+
+    python tools/robustness_sweep.py [--out profiles/r04_robustness.json] [--cells default,w_x4,...] [--markdown]
+
+Per (cell, shape, mode): mean position ADE against the fp64 truth, or "ERANGE" when the library reports an fp16-range
+overflow (the class then repeats the call in exact fp32), and the mean displacement against the f16x3 result of the same call
+(what ``self_check=True`` of the drop-in class measures).  tests/test_gpu_robustness.py asserts the claims INTEGRATION.md makes
+from this table.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import jmid_oracle as O                                        # noqa: E402  (test infrastructure: this is a checker)
+from safe_interactive_crowdnav_amd.engine import JmidEngine, JmidError     # noqa: E402
+from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims     # noqa: E402
+
+MODES = ("f32", "f16x3", "f16x2", "f16mx")
+SHAPES = {"cfg2": dict(A=5, K=20, T=12, step=50), "shipped": dict(A=3, K=100, T=8, step=2)}
+LAYER_KEYS = ("self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight")
+
+
+def _layer_weights(w):
+    return [k for k in w.tensors if k.startswith("transformer_encoder.layers.") and k.endswith(LAYER_KEYS)]
+
+
+def make_cell(name, seed=0):
+    """-> (JMIDWeights, description).  All cells start from JMIDWeights.from_seed(seed) (PyTorch default inits)."""
+    w = JMIDWeights.from_seed(NetDims(ctx_dim=256), seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    t = w.tensors
+    if name == "default":
+        return w, "seeded default init (what every other test runs on)"
+    if name.startswith("w_x"):
+        s = float(name[3:])
+        for k in _layer_weights(w):
+            t[k] *= s
+        return w, f"in_proj / out_proj / linear1 / linear2 weights of all three encoder layers x {s:g} (logits x {s * s:g}, sub-layer outputs x {s:g} before the LayerNorm)"
+    if name == "ln_gain":
+        for k in t:
+            if ".norm1.weight" in k or ".norm2.weight" in k:
+                t[k].copy_(0.5 + 2.5 * torch.rand(t[k].shape, generator=g))
+            if ".norm1.bias" in k or ".norm2.bias" in k:
+                t[k].copy_(torch.rand(t[k].shape, generator=g) - 0.5)
+        return w, "LayerNorm gain ~ U(0.5, 3), bias ~ U(-0.5, 0.5)"
+    if name == "ln_gain_w_x2":
+        w, _ = make_cell("ln_gain", seed)
+        for k in _layer_weights(w):
+            w.tensors[k] *= 2.0
+        return w, "LayerNorm gain ~ U(0.5, 3) and encoder-layer weights x 2"
+    if name == "student_t":
+        dist = torch.distributions.StudentT(3.0)
+        for k in _layer_weights(w):
+            std = float(t[k].std())
+            torch.manual_seed(2000 + seed + len(k))
+            s = dist.sample(t[k].shape)
+            t[k].copy_(s * (std / float(s.std())))
+        return w, "encoder-layer weights re-drawn from Student-t (nu = 3) at the default init's per-tensor standard deviation (heavy tails)"
+    if name.startswith("qk_x"):
+        s = float(name[4:])
+        for k in t:
+            if "in_proj_weight" in k or "in_proj_bias" in k:
+                t[k][: 2 * t[k].shape[0] // 3] *= s
+        return w, f"Q and K rows of every in_proj x {s:g} (softmax logits x {s * s:g})"
+    raise ValueError(name)
+
+
+CELLS = ("default", "w_x2", "w_x4", "w_x8", "ln_gain", "ln_gain_w_x2", "student_t", "qk_x4", "qk_x8", "qk_x16")
+
+
+def logit_spread(w, ctx, x_T, K):
+    """Mean over queries of (max - min) of the layer-0 softmax logits at the first DDIM step, in nats (fp64)."""
+    w64 = O.to_dtype(w.tensors, torch.float64)
+    B, T, _ = x_T.shape
+    sched = O.variance_schedule()
+    beta = sched["betas"][100].to(torch.float64).repeat(B).view(B, 1, 1)
+    c = ctx.to(torch.float64).repeat(K, 1).view(B, 1, -1)
+    emb = torch.cat([torch.cat([beta, torch.sin(beta), torch.cos(beta)], dim=-1), c], dim=-1)
+    h = O.concat_squash_linear(w64, "concat1", emb, x_T.to(torch.float64)).permute(1, 0, 2) + O.positional_encoding(24, 512, torch.float64)[:T]
+    seq = h.reshape(T * B, 512)
+    Wi, bi = w64["transformer_encoder.layers.0.self_attn.in_proj_weight"], w64["transformer_encoder.layers.0.self_attn.in_proj_bias"]
+    q = (seq @ Wi[:512].T + bi[:512]).view(-1, 4, 128)
+    k = (seq @ Wi[512:1024].T + bi[512:1024]).view(-1, 4, 128)
+    lg = torch.einsum("qhd,khd->hqk", q, k) / math.sqrt(128.0)
+    return float((lg.max(dim=-1).values - lg.min(dim=-1).values).mean())
+
+
+def ade(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - np.asarray(b, np.float64), axis=-1).mean())
+
+
+def run_cell(name, shapes=("cfg2", "shipped"), seed=0, threads=None):
+    w, desc = make_cell(name, seed)
+    out = {"cell": name, "what": desc, "shapes": {}}
+    torch.set_num_threads(threads or max(1, min(32, len(os.sched_getaffinity(0)))))
+    for sname in shapes:
+        sh = SHAPES[sname]
+        A, K, T, step = sh["A"], sh["K"], sh["T"], sh["step"]
+        g = torch.Generator().manual_seed(7 + seed)
+        ctx = torch.randn([A, 256], generator=g)
+        x_T = torch.randn([K * A, T, 2], generator=g)
+        p0 = 2.0 * torch.randn([A, 2], generator=g)
+        with torch.no_grad():
+            v64 = O.denoise(O.to_dtype(w.tensors, torch.float64), ctx.double(), x_T.double(), sample=K, step=step, joint=True)
+            truth = O.integrate(v64, p0.double(), 0.25).numpy()
+            spread = logit_spread(w, ctx, x_T, K)
+        eng = JmidEngine(w, joint=True, step=step)
+        res, pos = {}, {}
+        try:
+            for m in MODES:
+                try:
+                    pos[m] = eng.denoise(x_T.numpy()[None], ctx.numpy()[None], p0.numpy()[None], dt=0.25, precision=m, want_vel=False)[1][0]
+                    res[m] = {"ade_vs_fp64_m": ade(pos[m], truth)}
+                except JmidError as e:
+                    if e.code != -5:
+                        raise
+                    res[m] = {"ade_vs_fp64_m": None, "erange": True}
+        finally:
+            eng.close()
+        for m in ("f16x2", "f16mx"):
+            if m in pos and "f16x3" in pos:
+                res[m]["delta_vs_f16x3_m"] = ade(pos[m], pos["f16x3"])
+        out["shapes"][sname] = {"layer0_logit_spread_nats": round(spread, 2), "truth_mean_abs_pos_m": float(np.abs(truth).mean()),
+                                "modes": res, "inputs": {"ctx": ctx.numpy(), "x_T": x_T.numpy(), "p0": p0.numpy()}, "pos": pos}
+    return out, w
+
+
+def strip(rec):
+    """The JSON-able part of a run_cell record."""
+    return {"cell": rec["cell"], "what": rec["what"],
+            "shapes": {s: {k: v for k, v in d.items() if k not in ("inputs", "pos")} for s, d in rec["shapes"].items()}}
+
+
+def markdown(recs):
+    lines = ["| cell | shape | layer-0 logit spread (nats) | f32 | f16x3 | f16x2 | f16mx |", "|---|---|---|---|---|---|---|"]
+    for r in recs:
+        for s, d in r["shapes"].items():
+            cells = []
+            for m in MODES:
+                v = d["modes"][m]
+                cells.append("ERANGE -> f32" if v.get("erange") else f"{v['ade_vs_fp64_m']:.1e}")
+            lines.append(f"| `{r['cell']}` | {s} | {d['layer0_logit_spread_nats']:.1f} | " + " | ".join(cells) + " |")
+    return "\n".join(lines)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--cells", default=",".join(CELLS))
+    ap.add_argument("--shapes", default="cfg2,shipped")
+    ap.add_argument("--markdown", action="store_true")
+    a = ap.parse_args()
+    recs = []
+    for c in a.cells.split(","):
+        rec, _ = run_cell(c, tuple(a.shapes.split(",")))
+        recs.append(strip(rec))
+        for s, d in recs[-1]["shapes"].items():
+            print(c, s, "spread %.1f" % d["layer0_logit_spread_nats"],
+                  {m: ("ERANGE" if v.get("erange") else "%.2e" % v["ade_vs_fp64_m"]) for m, v in d["modes"].items()}, flush=True)
+    if a.markdown:
+        print(markdown(recs))
+    if a.out:
+        json.dump({"_comment": "tools/robustness_sweep.py: mean position ADE (m) of every arithmetic mode against the oracle in float64, "
+                               "per stress cell and shape; gate 1e-4 m", "cells": recs}, open(a.out, "w"), indent=1)
