@@ -183,6 +183,20 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
 int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* pos, const float* bw, float* sel, float* logw,
               int mem);
 
+/* One predictor call end to end, host buffers in, host buffers out: what HumanTrajectoryForecasterSim.predict_ret_best issues per
+ * MPC step (sicnav_diffusion/JMID/mid_sim_wrapper.py:482-510 -> MID.eval_sicnav, MID/mid.py:298-349) - jmid_encode, jmid_denoise
+ * and, when k < K, jmid_topk chained on the handle's stream with ONE upload (a pinned staging buffer), no host round trip between
+ * the stages (the context and the K sampled futures never leave the GPU) and ONE download + synchronisation at the end.
+ *   x_st [E*A, hist_len, 6], nbr_sum [E*A, 2, hist_len, 6], edge_mask [E*A, 2]   as jmid_encode
+ *   x_T [E, K*A, T, 2], p0 [E, A, 2], dt, precision                              as jmid_denoise
+ *   k < K:  bw [T] as jmid_topk (or NULL); sel [E, A, k, T, 2] and logw [E, A, k] receive the k most likely futures; pos_out may
+ *           be NULL
+ *   k == K: no ranking (the reference skips it, mid_sim_wrapper.py:487-492); pos_out [E, K, A, T, 2] receives all futures, sel /
+ *           logw / bw are ignored
+ * Returns JMID_ERANGE like jmid_denoise (the outputs are then undefined: repeat the stages in JMID_PREC_F32). */
+int jmid_predict(jmid_handle_t h, int E, int A, int K, int T, int k, const float* x_st, const float* nbr_sum, const float* edge_mask,
+                 const float* x_T, const float* p0, float dt, int precision, const float* bw, float* sel, float* logw, float* pos_out);
+
 /* The stream (a hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream; NULL = the legacy default
  * stream) that produces the inputs and consumes the outputs of this handle's JMID_MEM_DEVICE calls - see Conventions. */
 int jmid_set_caller_stream(jmid_handle_t h, void* stream);

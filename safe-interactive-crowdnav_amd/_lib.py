@@ -39,6 +39,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_int]),
     "jmid_topk": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_int]),
+    "jmid_predict": (C.c_int, [Handle, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jmid_set_chunk_episodes": (C.c_int, [Handle, C.c_int]),
     "jmid_set_tuning": (C.c_int, [Handle, C.c_char_p, C.c_int]),
     "jmid_set_caller_stream": (C.c_int, [Handle, C.c_void_p]),

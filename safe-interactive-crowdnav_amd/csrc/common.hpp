@@ -92,8 +92,10 @@ struct Tuning {
     int attn_mx = 0;         // head_dim 128: F16MX 0 = bf8 logit corrections + one fp16 plane of P, 1 = P_hi + P_lo (F16X2 too), 2 = F16X2's attention, 3 = as 0 with Q_lo as an fp16 plane (A/B; same bits)
     int mx_ln = 0;           // F16MX at d_model 512: 0 = second-generation GEMM + LayerNorm (gemm_ln2_mx.hpp: byte lo plane of the residual stream, two workgroups per CU), 2 = the first generation
     int attn_pf = 0;         // F16MX / F16X2 attention with one plane of P: 2 = fragment reads one step ahead instead of three (A/B; same bits)
-    int gemm_small = 0;      // launches of at most one workgroup per CU (gemm_small.hpp): 0 = the deep-ring k64 kernel, 1 = the round-3 tile shapes
+    int gemm_small = 0;      // launches of at most one workgroup per CU (gemm_small.hpp): 0 = the deep-ring k64 kernel, 1 = the round-3 tile shapes, 2 = the deep-ring kernel only up to one workgroup per CU
     int small_ln = 0;        // out_proj / linear2 + residual + LayerNorm of a small launch in ONE kernel (last-arriver tail): 1 on (measured slower: the tail's VALU work lands on 19 workgroups), 0 / 2 off (GEMM + add_ln*)
+    int small_now = 1;       // set per call by run_network: the small-launch kernels only while ONE chunk is in flight (with two lanes their
+                             // one-workgroup-per-CU launches collide: 4 episodes as 2 x 2 measured 4 % slower with them)
     int small_pn = 0;        // its column groups per launch (two-dimensional XCD tile order): 0 = fewest Infinity-Cache bytes, 1 / 2 / 4 / 8 forced
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS
     int gemm_abl = 0;

@@ -77,6 +77,17 @@ __device__ __forceinline__ bool split_range_exceeded(unsigned amax16) {
     return (amax16 & 0xffffu) > kHalfMaxBits || (amax16 >> 16) > kHalfMaxBits;
 }
 
+// epilogue stores of streamed outputs (Q / K / V^T planes: written once, read by another kernel): with -DJMID_NT_STORES they
+// carry the non-temporal hint, so that they do not push the launch's operand panels out of the XCD's L2 (A/B: tools/ab_builds.py)
+template <typename T>
+__device__ __forceinline__ void store_stream(T* p, const T& v) {
+#ifdef JMID_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
 enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2, OUT_LN = 3 };     // OUT_LN: gemm_small.hpp only (fp32 tile + residual + LayerNorm by the last workgroup of the row tile)
 
 
@@ -771,7 +782,7 @@ __device__ __forceinline__ bool vt_staged_store(const GemmHArgs& g, f32x16 (&acc
             for (int t = 8 * jh; t < 8 * jh + 8; ++t) {
                 const int row = t * 8 + (lane >> 3), c = lane & 7;
                 const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 64 + ((c ^ (row & 7)) << 3));
-                *reinterpret_cast<f16x8*>(dst + (size_t)row * g.Spad + c * 8) = v8;
+                store_stream(reinterpret_cast<f16x8*>(dst + (size_t)row * g.Spad + c * 8), v8);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -860,13 +871,13 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
                 const int row = t * 4 + (lane >> 4), u = lane & 15;
                 const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
                 if (mw0 + row < g.M) {
-                    if (!((k8 || q8) && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8) = v8;
+                    if (!((k8 || q8) && plane == 1)) store_stream(reinterpret_cast<f16x8*>(dst + (size_t)row * g.d + u * 8), v8);
                     if (img) {
                         const i32x4_e dw = __builtin_bit_cast(i32x4_e, v8);
                         i32x2_e b8;
                         b8[0] = bf8_of_f16x4_e(dw[0], dw[1]);
                         b8[1] = bf8_of_f16x4_e(dw[2], dw[3]);
-                        *reinterpret_cast<i32x2_e*>(dst8 + (size_t)row * g.d + u * 8) = b8;
+                        store_stream(reinterpret_cast<i32x2_e*>(dst8 + (size_t)row * g.d + u * 8), b8);
                     }
                 }
             }

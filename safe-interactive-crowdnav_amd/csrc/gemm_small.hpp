@@ -42,7 +42,7 @@ __device__ unsigned long long* g_small_trace;
 #endif
 
 
-template <int MODE, int WC>
+template <int MODE, int WC, bool TWO = false>     // TWO: two workgroups per CU (launches of 257 ... 512 tiles): half the LDS budget each
 struct SmCfg {
     static constexpr int NW = 2 * WC, NT = 64 * NW, BM = 64, BN = 32 * WC;
     static constexpr int A_SUB = BM * 64, W_SUB = BN * 64;                  // bytes of one k32 sub-tile of a plane
@@ -50,7 +50,8 @@ struct SmCfg {
     static constexpr int BLK = 2 * (A_PLANES * A_SUB + W_PLANES * W_SUB) + (MODE == SM_MX ? BN * 64 : 0);     // one k64 block, all planes
     // k64 blocks per ring stage: a stage costs a wave one wait + barrier + LDS round trip however deep it is (the wave is alone
     // on its SIMD: nothing hides them), so stages are k128 wherever three of them fit the CU's LDS
-    static constexpr int KB = 3 * 2 * BLK <= 144 * 1024 ? 2 : 1;
+    static constexpr int BUDGET = TWO ? 80 * 1024 : 144 * 1024;
+    static constexpr int KB = (TWO ? 2 : 3) * 2 * BLK <= BUDGET ? 2 : 1;
     static constexpr int A_BYTES = KB * 2 * A_SUB, W_BYTES = KB * 2 * W_SUB;          // one plane of a stage
     static constexpr int W8_BLOCK = MODE == SM_MX ? BN * 64 : 0;                    // bf8(W_lo) of one k64 block
     static constexpr int OFF_AH = 0, OFF_AL = A_BYTES, OFF_WH = A_PLANES * A_BYTES, OFF_WL = OFF_WH + W_BYTES;
@@ -59,7 +60,7 @@ struct SmCfg {
     static constexpr int ROUND = NT * 16;                                   // bytes one DMA wave-instruction per wave moves
     static constexpr int RA = A_BYTES / ROUND, RW = W_BYTES / ROUND, R8B = W8_BLOCK / ROUND, R8 = KB * R8B;
     static constexpr int NR = A_PLANES * RA + W_PLANES * RW + R8;           // DMA wave-instructions per wave and stage
-    static constexpr int NS_MAX = (144 * 1024) / STAGE;
+    static constexpr int NS_MAX = BUDGET / STAGE;
     static constexpr int NS = NS_MAX < 4 ? NS_MAX : 4;                      // ring slots; NS - 1 stages of look-ahead
     static constexpr int L = NS - 1;
     static constexpr size_t LDS_BYTES = size_t(NS) * STAGE;
@@ -294,9 +295,9 @@ __device__ __forceinline__ void ln_tail_planes(const float* Y, const float* gamm
     }
 }
 
-template <int EPI, int OUT, int MODE, int WC>
-__global__ __launch_bounds__(128 * WC, 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags) {
-    using C = SmCfg<MODE, WC>;
+template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
+__global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags) {
+    using C = SmCfg<MODE, WC, TWO>;
     constexpr bool X2 = MODE != SM_X3, MX = MODE == SM_MX;
     constexpr int BM = C::BM, BN = C::BN, NS = C::NS, L = C::L, KB = C::KB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -525,30 +526,33 @@ inline int small_pick_groups(const GemmHArgs& g, int ntn, double w_bytes_per_el,
     return best;
 }
 
-template <int EPI, int OUT, int MODE, int WC>
+template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
 inline hipError_t launch_gemm_small_cfg(const GemmHArgs& g, hipStream_t st) {
-    using C = SmCfg<MODE, WC>;
+    using C = SmCfg<MODE, WC, TWO>;
     const int ntm = (g.M + C::BM - 1) / C::BM, ntn = g.N / C::BN;
     static DevSeen attr_seen;
     if (auto once_ = first_use_on_device(attr_seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_kernel<EPI, OUT, MODE, WC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_kernel<EPI, OUT, MODE, WC, TWO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     const int pn = tune().small_pn > 0 ? (ntn % tune().small_pn == 0 ? tune().small_pn : 1)
                                        : small_pick_groups(g, ntn, MODE == SM_MX ? 3.0 : 4.0, MODE == SM_X3 ? 4.0 : 2.0);
     const int flags = (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0);
-    hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, MODE, WC>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
+    hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, MODE, WC, TWO>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
                        ntn / pn, flags);
     return hipGetLastError();
 }
 
 // Does this GEMM run on the small-launch kernel, and in which shape?  One workgroup per CU: at most 256 tiles.
-//   -> 0 no, 2 / 4 = WC.  (OUT_LN callers: 2 means the fused tail applies.)  "gemm_small" knob: 0 auto, 1 never.
+//   -> 0 no, 2 / 4 = WC, 8 = WC 4 with two workgroups per CU.  (OUT_LN callers: 2 means the fused tail applies.)  "gemm_small" knob: 0 auto, 1 never.
 inline int small_gemm_shape(const GemmHArgs& g) {
-    if (tune().gemm_small == 1 || tune().gemm_h_variant != 0) return 0;
+    if (tune().gemm_small == 1 || tune().gemm_h_variant != 0 || !tune().small_now) return 0;
     if (g.K % 128 != 0 || g.N % 128 != 0) return 0;       // (k128 ring stages)
     const long ntm = (g.M + 63) / 64;
     if (ntm * (g.N / 64) <= 256) return 2;
     if (ntm * (g.N / 128) <= 256) return 4;
+    // 257 ... 512 tiles of 64 x 128 (two scenes; the reference's shipped K = 100): the same kernel, two workgroups per CU
+    // (not F16X3: two k64 stages of its four operand planes do not fit half a CU's LDS)
+    if (g.x2 && tune().gemm_small != 2 && ntm * (g.N / 128) <= 512) return 8;
     return 0;
 }
 
@@ -556,7 +560,11 @@ template <int EPI, int OUT, int MODE>
 inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t st) {
     if (wc == 2) return launch_gemm_small_cfg<EPI, OUT, MODE, 2>(g, st);
     if constexpr (OUT == OUT_LN) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
-    else return launch_gemm_small_cfg<EPI, OUT, MODE, 4>(g, st);
+    else {
+        if constexpr (MODE != SM_X3)
+            if (wc == 8) return launch_gemm_small_cfg<EPI, OUT, MODE, 4, true>(g, st);
+        return launch_gemm_small_cfg<EPI, OUT, MODE, 4>(g, st);
+    }
 }
 
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch (OUT_LN)?  d_model 512, at most 256 tiles of 64 x 64

@@ -96,6 +96,12 @@ struct jmid_ctx {
     int last_pos_dims[4] = {0, 0, 0, 0};     // E, A, K, T
     char* kde_ws = nullptr;                  // jmid_topk's own workspace (it must not move the arena last_pos points into)
     size_t kde_ws_bytes = 0;
+    // jmid_predict: pinned host staging + device I/O buffers of the chained call, grown on demand
+    char* pin = nullptr;
+    size_t pin_bytes = 0;
+    char* io_dev = nullptr;
+    size_t io_dev_bytes = 0;
+    bool chained = false;       // the running run_network is a stage of jmid_predict: no caller-stream ordering, no flag round trip
     int64_t erange_calls = 0;   // calls on this handle that ended with JMID_ERANGE (jmid_erange_count)
     int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
@@ -759,13 +765,13 @@ std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
 // for everything the caller enqueued before the call, and the caller's stream waits for the call's last kernel, so
 // neither a producer kernel of an input nor a consumer (or the allocator's reuse) of an output can race with it.
 int order_in(jmid_ctx* h, int mem) {
-    if (mem != JMID_MEM_DEVICE) return 0;
+    if (mem != JMID_MEM_DEVICE || h->chained) return 0;
     HIPCHK(h, hipEventRecord(h->ev_in, h->caller_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_in, 0));
     return 0;
 }
 int order_out(jmid_ctx* h, int mem) {
-    if (mem != JMID_MEM_DEVICE) return 0;
+    if (mem != JMID_MEM_DEVICE || h->chained) return 0;
     HIPCHK(h, hipEventRecord(h->ev_out, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->caller_stream, h->ev_out, 0));
     return 0;
@@ -834,6 +840,12 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     // workspace; results do not depend on the number of lanes.
     const int nchunks = (int)chunk_sizes.size();
     const int lanes = single_step < 0 ? std::max(1, std::min(h->lanes, nchunks)) : 1;
+    // the small-launch GEMMs (gemm_small.hpp: one workgroup per CU, most of its LDS) only while one chunk is in flight
+    struct SmallNow {
+        Tuning& t;
+        SmallNow(Tuning& t_, int v) : t(t_) { t.small_now = v; }
+        ~SmallNow() { t.small_now = 1; }
+    } small_now_scope(h->tune, lanes == 1 ? 1 : 0);
     const size_t lane_floats = step_ws_floats(h, Mc, precision, sg_full, ns_call, nullptr, nullptr);
     const size_t need = io_off + lanes * lane_floats;
     if (int rc = ensure_arena(h, need)) return rc;
@@ -982,6 +994,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         }
     }
     if (int rc = order_out(h, mem)) return rc;
+    if (h->chained) return 0;          // (jmid_predict reads the range flag with its one download)
     if (precision != JMID_PREC_F32) {
         // an activation outside the fp16 range poisons the split operands: report it instead of returning garbage
         int flag = 0;
@@ -1064,6 +1077,11 @@ int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, in
 }
 
 int jmid_destroy(jmid_handle_t h) {
+    if (h) {
+        if (h->pin) (void)hipHostFree(h->pin);
+        if (h->io_dev) (void)hipFree(h->io_dev);
+        h->pin = h->io_dev = nullptr;
+    }
     if (!h) return JMID_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
@@ -1370,8 +1388,7 @@ int jmid_encode(jmid_handle_t h, int n_agents, const float* x_st, const float* n
         ea.edge[1] = LstmW{h->lstmT[2][0], h->lstmT[2][1], h->lstmT[2][2]};
         ea.W1T = h->attW1T; ea.W2T = h->attW2T; ea.v = W(h, "PEDESTRIAN/edge_influence_encoder.v.weight");
         ea.ctx = co; ea.n = n_agents; ea.Th = Th; ea.H = H;
-        hipLaunchKernelGGL(encoder_kernel, dim3(n_agents), dim3(4 * H), 0, h->stream, ea);
-        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, launch_encoder(ea, h->stream));
     }
     if (mem == JMID_MEM_HOST) {
         HIPCHK(h, hipMemcpyAsync(ctx_out, co, n * 2 * H * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1428,6 +1445,38 @@ int jmid_episode_metrics(jmid_handle_t h, int E, int A, int K, int T, const floa
     }
     return order_out(h, mem);
 }
+
+}  // extern "C"
+
+namespace {
+// the two KDE launches on device buffers (pos [E, K, A, T, 2], bw [T] or null -> sel, logw); the ll / Y workspace is the handle's
+int topk_on_device(jmid_ctx* h, int E, int A, int K, int T, int k, const float* pos, const float* bw, float* sel, float* logw) {
+    const int d = 2 * A;
+    auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t y_bytes = kde_y_in_lds(A, K) ? 0 : up((size_t)E * T * K * d * 8);
+    const size_t o_Y = up((size_t)E * T * K * 8), need = o_Y + y_bytes;
+    if (need > h->kde_ws_bytes) {
+        if (h->kde_ws) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            HIPCHK(h, hipFree(h->kde_ws));
+            h->kde_ws = nullptr;
+            h->kde_ws_bytes = 0;
+        }
+        if (hipMalloc((void**)&h->kde_ws, need) != hipSuccess) return fail(h, JMID_ENOMEM, "jmid_topk workspace allocation failed");
+        h->kde_ws_bytes = need;
+    }
+    KdeArgs g{};
+    g.E = E; g.A = A; g.K = K; g.T = T; g.k = k;
+    g.ll = reinterpret_cast<double*>(h->kde_ws);
+    g.Y = reinterpret_cast<double*>(h->kde_ws + o_Y);
+    g.pos = pos; g.bw = bw; g.sel = sel; g.logw = logw;
+    ProfScope ps(h, KC_TOPK);
+    HIPCHK(h, launch_kde(g, h->stream));
+    return 0;
+}
+}  // namespace
+
+extern "C" {
 
 int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* pos, const float* bw, float* sel, float* logw,
               int mem) {
@@ -1491,6 +1540,90 @@ int jmid_topk(jmid_handle_t h, int E, int A, int K, int T, int k, const float* p
     return order_out(h, mem);
 }
 
+int jmid_predict(jmid_handle_t h, int E, int A, int K, int T, int k, const float* x_st, const float* nbr_sum, const float* edge_mask,
+                 const float* x_T, const float* p0, float dt, int precision, const float* bw, float* sel, float* logw, float* pos_out) {
+    if (!h) return JMID_EINVAL;
+    if (int rc = check_ready(h)) return rc;
+    if (E <= 0 || A <= 0 || K <= 0 || T <= 0 || k < 1 || k > K) return fail(h, JMID_EINVAL, "jmid_predict: bad dimensions");
+    if (!x_st || !nbr_sum || !edge_mask || !x_T || !p0) return fail(h, JMID_EINVAL, "jmid_predict: null input");
+    const bool rank = k < K;
+    if (rank && (!sel || !logw)) return fail(h, JMID_EINVAL, "jmid_predict: k < K needs sel and logw");
+    if (!rank && !pos_out) return fail(h, JMID_EINVAL, "jmid_predict: k == K needs pos_out");
+    if (rank && (A > 32 || K > 1024 || T > 24)) return fail(h, JMID_EINVAL, "jmid_predict: the device top-k supports A <= 32, K <= 1024, T <= 24");
+    if (h->ddpm) return fail(h, JMID_EINVAL, "jmid_predict samples with DDIM (MID.eval_sicnav: sampling=\"ddim\", MID/mid.py:333)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t Th = h->hist_len, n = (size_t)E * A, H2 = 2 * (size_t)h->H;
+    const size_t n_xs = n * Th * 6, n_nb = n * 2 * Th * 6, n_em = n * 2, n_xT = (size_t)E * K * A * T * 2, n_p0 = n * 2, n_bw = rank && bw ? T : 0;
+    const size_t n_sel = rank ? n * k * T * 2 : 0, n_lw = rank ? n * k : 0, n_pos = pos_out ? n_xT : 0;
+    auto up = [](size_t floats) { return (floats + 63) / 64 * 64; };
+    // upload block | ctx | download block (flag, sel, logw, pos)
+    const size_t o_xs = 0, o_nb = o_xs + up(n_xs), o_em = o_nb + up(n_nb), o_xT = o_em + up(n_em), o_p0 = o_xT + up(n_xT), o_bw = o_p0 + up(n_p0),
+                 in_floats = o_bw + up(n_bw), o_ctx = in_floats, o_out = o_ctx + up(n * H2), o_flag = o_out, o_sel = o_flag + 64, o_lw = o_sel + up(n_sel),
+                 o_pos = o_lw + up(n_lw), total = o_pos + up(n_pos), out_floats = total - o_out;
+    if (total * 4 > h->io_dev_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->io_dev) HIPCHK(h, hipFree(h->io_dev));
+        h->io_dev = nullptr;
+        if (hipMalloc((void**)&h->io_dev, total * 4) != hipSuccess) return fail(h, JMID_ENOMEM, "jmid_predict: device staging allocation failed");
+        h->io_dev_bytes = total * 4;
+    }
+    const size_t pin_need = (in_floats + out_floats) * 4;
+    if (pin_need > h->pin_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->pin) HIPCHK(h, hipHostFree(h->pin));
+        h->pin = nullptr;
+        if (hipHostMalloc((void**)&h->pin, pin_need, hipHostMallocDefault) != hipSuccess) return fail(h, JMID_ENOMEM, "jmid_predict: pinned staging allocation failed");
+        h->pin_bytes = pin_need;
+    }
+    float* pin = reinterpret_cast<float*>(h->pin);
+    float* dev = reinterpret_cast<float*>(h->io_dev);
+    std::memcpy(pin + o_xs, x_st, n_xs * 4);
+    std::memcpy(pin + o_nb, nbr_sum, n_nb * 4);
+    std::memcpy(pin + o_em, edge_mask, n_em * 4);
+    std::memcpy(pin + o_xT, x_T, n_xT * 4);
+    std::memcpy(pin + o_p0, p0, n_p0 * 4);
+    if (n_bw) std::memcpy(pin + o_bw, bw, n_bw * 4);
+    HIPCHK(h, hipMemcpyAsync(dev, pin, in_floats * 4, hipMemcpyHostToDevice, h->stream));
+    int rc = 0;
+    h->chained = true;
+    {
+        TuneScope tune_scope(&h->tune);
+        ProfScope ps(h, KC_ENCODER);
+        EncArgs ea{};
+        ea.x_st = dev + o_xs; ea.nbr_sum = dev + o_nb; ea.edge_mask = dev + o_em;
+        ea.hist = LstmW{h->lstmT[0][0], h->lstmT[0][1], h->lstmT[0][2]};
+        ea.edge[0] = LstmW{h->lstmT[1][0], h->lstmT[1][1], h->lstmT[1][2]};
+        ea.edge[1] = LstmW{h->lstmT[2][0], h->lstmT[2][1], h->lstmT[2][2]};
+        ea.W1T = h->attW1T; ea.W2T = h->attW2T; ea.v = W(h, "PEDESTRIAN/edge_influence_encoder.v.weight");
+        ea.ctx = dev + o_ctx; ea.n = (int)n; ea.Th = (int)Th; ea.H = h->H;
+        if (launch_encoder(ea, h->stream) != hipSuccess) rc = fail(h, JMID_EHIP, "jmid_predict: encoder launch failed");
+    }
+    if (!rc) rc = run_network(h, E, A, K, T, dev + o_xT, dev + o_ctx, dev + o_p0, dt, precision, -1, nullptr, pos_out ? dev + o_pos : nullptr,
+                              nullptr, JMID_MEM_DEVICE);
+    if (!rc && rank) {
+        TuneScope tune_scope(&h->tune);
+        rc = topk_on_device(h, E, A, K, T, k, h->last_pos, n_bw ? dev + o_bw : nullptr, dev + o_sel, dev + o_lw);
+    }
+    h->chained = false;
+    if (rc) return rc;
+    const bool flagged = precision != JMID_PREC_F32;
+    if (flagged) HIPCHK(h, hipMemcpyAsync(dev + o_flag, h->range_flag, sizeof(int), hipMemcpyDeviceToDevice, h->stream));
+    float* pout = pin + in_floats;
+    HIPCHK(h, hipMemcpyAsync(pout, dev + o_out, out_floats * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (flagged && *reinterpret_cast<const int*>(pout + (o_flag - o_out))) {
+        ++h->erange_calls;
+        h->last_pos = nullptr;
+        return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
+    }
+    if (rank) {
+        std::memcpy(sel, pout + (o_sel - o_out), n_sel * 4);
+        std::memcpy(logw, pout + (o_lw - o_out), n_lw * 4);
+    }
+    if (pos_out) std::memcpy(pos_out, pout + (o_pos - o_out), n_pos * 4);
+    return JMID_OK;
+}
+
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes) {
     if (!h || episodes < 0) return JMID_EINVAL;
     h->chunk_eps = episodes;
@@ -1527,7 +1660,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_pf", &Tuning::attn_pf, 0, 2},
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
-        {"gemm_small", &Tuning::gemm_small, 0, 1},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
+        {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches
         {"small_pn", &Tuning::small_pn, 0, 8},                 // column groups of its XCD tile order: 0 auto
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced

@@ -27,11 +27,12 @@ struct KdeArgs {
     float* logw;          // [E, A, k] their renormalised log-weights (the same row for every agent, :139-151)
     int E, A, K, T, k;
     int y_in_lds;
+    int p_in_lds;         // the K x d points of the (episode, horizon step) staged in LDS as doubles (they are read ~2 d + 3 times each)
 };
 
 constexpr int KDE_THREADS = 256;
-inline size_t kde_lds_bytes(int d, int K, bool y_in_lds) {
-    return sizeof(double) * (size_t(2) * d * d + d + KDE_THREADS + K + (y_in_lds ? size_t(K) * d : 0));
+inline size_t kde_lds_bytes(int d, int K, bool y_in_lds, bool p_in_lds = false) {
+    return sizeof(double) * (size_t(2) * d * d + d + KDE_THREADS + K + (y_in_lds ? size_t(K) * d : 0) + (p_in_lds ? size_t(K) * d : 0));
 }
 
 // in-place lower Cholesky factor of the SPD matrix M [d, d] (row-major; the strict upper triangle is left as it was)
@@ -75,8 +76,18 @@ __global__ __launch_bounds__(KDE_THREADS) void kde_step_kernel(KdeArgs g) {
     double* red = mean + d;
     double* llv = red + KDE_THREADS;
     double* Yp = g.y_in_lds ? llv + K : g.Y + (size_t)blk * K * d;
+    double* Pp = g.p_in_lds ? llv + K + (g.y_in_lds ? K * d : 0) : nullptr;
     const float* pe = g.pos + (size_t)e * K * A * T * 2;
-    auto pt = [&](int s, int c) { return (double)pe[(((size_t)s * A + (c >> 1)) * T + h) * 2 + (c & 1)]; };
+    // the points of this (episode, horizon step): staged once (one pass over global memory instead of a dependent load per use -
+    // K = 100, d = 6: 91 -> ~20 us per launch at the reference's shipped operating point), or read in place when they do not fit
+    if (Pp) {
+        for (int idx = tid; idx < K * d; idx += KDE_THREADS) {
+            const int s = idx / d, c = idx - s * d;
+            Pp[idx] = (double)pe[(((size_t)s * A + (c >> 1)) * T + h) * 2 + (c & 1)];
+        }
+        __syncthreads();
+    }
+    auto pt = [&](int s, int c) { return Pp ? Pp[s * d + c] : (double)pe[(((size_t)s * A + (c >> 1)) * T + h) * 2 + (c & 1)]; };
     double bw;
     if (g.bw) bw = (double)g.bw[h];
     else bw = exp(log(0.01) + (T > 1 ? (double)h * (log(0.1) - log(0.01)) / (double)(T - 1) : 0.0));
@@ -120,17 +131,46 @@ __global__ __launch_bounds__(KDE_THREADS) void kde_step_kernel(KdeArgs g) {
     }
     __syncthreads();
     const double Z = 0.5 * (double)d * log(2.0 * 3.14159265358979323846) + 0.5 * log_det + log((double)K);
-    for (int i = tid; i < K; i += KDE_THREADS) {
+    // pairwise sums: the K x K exponentials are the kernel's time (fp64 exp), so every sample gets TPS = 2^n <= 256 / K threads,
+    // each summing a contiguous slice of j; the slices are added in j order (red[] is free until the normalisation below)
+    int tps = 1;
+    while (tps * 2 * K <= KDE_THREADS) tps *= 2;
+    {
+        const int i = tid / tps, sl = tid - i * tps;
         double acc = 0.0;                              // max_j e_ij = e_ii = 0: no shift needed
-        for (int j = 0; j < K; ++j) {
-            double q = 0.0;
-            for (int c = 0; c < d; ++c) {
-                const double t = Yp[i * d + c] - Yp[j * d + c];
-                q += t * t;
+        if (tps > 1 && i < K) {
+            const int j0 = (int)((long)sl * K / tps), j1 = (int)((long)(sl + 1) * K / tps);
+            for (int j = j0; j < j1; ++j) {
+                double q = 0.0;
+                for (int c = 0; c < d; ++c) {
+                    const double t = Yp[i * d + c] - Yp[j * d + c];
+                    q += t * t;
+                }
+                acc += exp(-0.5 * q);
             }
-            acc += exp(-0.5 * q);
         }
-        llv[i] = log(acc) - Z;
+        if (tps > 1) {
+            red[tid] = acc;
+            __syncthreads();
+            if (i < K && sl == 0) {
+                double a = red[tid];
+                for (int u = 1; u < tps; ++u) a += red[tid + u];
+                llv[i] = log(a) - Z;
+            }
+        } else {
+            for (int ii = tid; ii < K; ii += KDE_THREADS) {      // K > 128: one thread per sample, several samples per thread
+                double a = 0.0;
+                for (int j = 0; j < K; ++j) {
+                    double q = 0.0;
+                    for (int c = 0; c < d; ++c) {
+                        const double t = Yp[ii * d + c] - Yp[j * d + c];
+                        q += t * t;
+                    }
+                    a += exp(-0.5 * q);
+                }
+                llv[ii] = log(a) - Z;
+            }
+        }
     }
     __syncthreads();
     // normalise over the samples: ll -= logsumexp(ll)
@@ -208,7 +248,8 @@ inline hipError_t launch_kde(const KdeArgs& g0, hipStream_t st) {
     KdeArgs g = g0;
     const int d = 2 * g.A;
     g.y_in_lds = kde_y_in_lds(g.A, g.K);
-    const size_t lds = kde_lds_bytes(d, g.K, g.y_in_lds != 0);
+    g.p_in_lds = kde_lds_bytes(d, g.K, g.y_in_lds != 0, true) <= 150 * 1024;
+    const size_t lds = kde_lds_bytes(d, g.K, g.y_in_lds != 0, g.p_in_lds != 0);
     static DevSeen seen;
     if (auto once_ = first_use_on_device(seen))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&kde_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -229,6 +229,31 @@ class JmidEngine:
                                         self._mem(dev)))
         return sel, lw
 
+    def predict(self, x_st: np.ndarray, nbr_sum: np.ndarray, edge_mask: np.ndarray, x_T: np.ndarray, p0: np.ndarray, k: int,
+                dt: float = 0.25, precision: str = "f32"):
+        """One predictor call end to end (``jmid_predict``): encoder -> denoise loop -> integrator -> joint-KDE top-k, host arrays in
+        and out, one upload, one download, nothing in between.  x_st [E*A, hist, 6], nbr_sum [E*A, 2, hist, 6], edge_mask [E*A, 2],
+        x_T [E, K*A, T, 2], p0 [E, A, 2].  k < K -> (kept [E, A, k, T, 2], log-weights [E, A, k]); k == K -> (pos [E, K, A, T, 2], None)."""
+        import math
+        E, KA, T, _ = (int(v) for v in x_T.shape)
+        A = int(p0.shape[1])
+        K = KA // A
+        if tuple(x_st.shape) != (E * A, self.hist_len, 6) or tuple(nbr_sum.shape) != (E * A, 2, self.hist_len, 6) \
+                or tuple(edge_mask.shape) != (E * A, 2) or KA != K * A or tuple(p0.shape) != (E, A, 2):
+            raise ValueError("bad predict() input shapes")
+        b = [_Buf(a, False) for a in (x_st, nbr_sum, edge_mask, x_T, p0)]
+        if k < K:
+            bw = np.ascontiguousarray(torch.exp(torch.linspace(math.log(0.01), math.log(0.1), steps=T)).numpy())   # mid_sim_wrapper.py:26-30
+            sel = np.empty((E, A, k, T, 2), dtype=np.float32)
+            lw = np.empty((E, A, k), dtype=np.float32)
+            self._check(self._lib.jmid_predict(self._h, E, A, K, T, int(k), *[x.ptr for x in b], float(dt), _lib.PRECISIONS[precision],
+                                               C.c_void_p(bw.ctypes.data), C.c_void_p(sel.ctypes.data), C.c_void_p(lw.ctypes.data), None))
+            return sel, lw
+        pos = np.empty((E, K, A, T, 2), dtype=np.float32)
+        self._check(self._lib.jmid_predict(self._h, E, A, K, T, int(k), *[x.ptr for x in b], float(dt), _lib.PRECISIONS[precision],
+                                           None, None, None, C.c_void_p(pos.ctypes.data)))
+        return pos, None
+
     def net_eval(self, x: ArrayLike, ctx: ArrayLike, step_idx: int = 0, precision: str = "f32"):
         """One evaluation of e_theta for DDIM table entry ``step_idx``; x [E, K*A, T, 2] -> e same shape."""
         dev = _is_cuda(x)

@@ -255,26 +255,43 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
         with self._engine_lock:               # the engine is shared between forecaster instances and not re-entrant
             if self.engine.step != self.step_size or self.engine.sampling != "ddim":
                 self.engine.set_step(self.step_size, "ddim")   # eval_sicnav hard-codes sampling="ddim" (MID/mid.py:333)
-            ctx = self.engine.encode(sb.x_st, sb.nbr_sum, sb.edge_mask)
             x_np = x_T.numpy()[None]
             # the K samples stay on the GPU (only the k kept ones come back) while jmid_topk takes the shape; beyond its limits
             # - the reference has none - the host twin ranks them
             on_dev = k < K and self.device_topk and topk_fits_device(A, K, H)
             check = self.self_check and tuple(x_np.shape) not in self._checked_shapes
-            pos = self._denoise(x_np, ctx[None], sb.p0[None], want_pos=not on_dev or check)
-            if check:        # first call of this shape in an opt-in mode: pos is the result to use (possibly f16x3's)
-                pos = self._self_check(x_np, ctx[None], sb.p0[None], pos)
-            t2 = time.perf_counter()
-            if on_dev:
-                # joint-KDE top-k on the device (jmid_topk) over the positions the denoise call left in the workspace
-                sel, lw = self.engine.topk(pos if check else None, k, dims=(1, A, K, H))
-                in_cluster, logw_in = sel[0], lw[0].astype(np.float64)
-            elif k < K:
-                in_cluster, logw_in = most_likely_samples(pos[0], k)          # [A, k, H, 2], [A, k]: host path
-                logw_in = logw_in.astype(np.float64)
-            else:
-                in_cluster = pos[0].transpose(1, 0, 2, 3)                     # [K, A, H, 2] -> agents by ascending id
-                logw_in = np.log(np.ones((A, K), dtype=np.float64) / K)
+            in_cluster = None
+            if (on_dev or k == K) and not check:
+                # the whole call in ONE library entry (jmid_predict: encoder -> denoise -> integrator -> top-k chained on the
+                # stream, one upload, one download); JMID_ERANGE -> the staged path below in exact fp32
+                try:
+                    out, lw = self.engine.predict(sb.x_st, sb.nbr_sum, sb.edge_mask, x_np, sb.p0[None], k, dt=self.time_step,
+                                                  precision=self.precision)
+                    if on_dev:
+                        in_cluster, logw_in = out[0], lw[0].astype(np.float64)
+                    else:
+                        in_cluster = out[0].transpose(1, 0, 2, 3)                 # [K, A, H, 2] -> agents by ascending id
+                        logw_in = np.log(np.ones((A, K), dtype=np.float64) / K)
+                    t2 = time.perf_counter()
+                except JmidError as e:
+                    if e.code != -5 or self.precision == "f32":                   # JMID_ERANGE
+                        raise
+            if in_cluster is None:
+                ctx = self.engine.encode(sb.x_st, sb.nbr_sum, sb.edge_mask)
+                pos = self._denoise(x_np, ctx[None], sb.p0[None], want_pos=not on_dev or check)
+                if check:        # first call of this shape in an opt-in mode: pos is the result to use (possibly f16x3's)
+                    pos = self._self_check(x_np, ctx[None], sb.p0[None], pos)
+                t2 = time.perf_counter()
+                if on_dev:
+                    # joint-KDE top-k on the device (jmid_topk) over the positions the denoise call left in the workspace
+                    sel, lw = self.engine.topk(pos if check else None, k, dims=(1, A, K, H))
+                    in_cluster, logw_in = sel[0], lw[0].astype(np.float64)
+                elif k < K:
+                    in_cluster, logw_in = most_likely_samples(pos[0], k)          # [A, k, H, 2], [A, k]: host path
+                    logw_in = logw_in.astype(np.float64)
+                else:
+                    in_cluster = pos[0].transpose(1, 0, 2, 3)                     # [K, A, H, 2] -> agents by ascending id
+                    logw_in = np.log(np.ones((A, K), dtype=np.float64) / K)
         t3 = time.perf_counter()
         forecasts = np.zeros((self.num_hums, k, H, 2), dtype=np.float64)
         logw = np.zeros((self.num_hums, k), dtype=np.float64)

@@ -40,9 +40,12 @@ class HistoryTooShortError(TypeError):
 
 def derivative_of(x: np.ndarray, dt: float) -> np.ndarray:
     """data_utils.py:24-37 for NaN-free input: first difference, first element duplicated."""
-    if x.shape[-1] < 2:
+    if x.shape[0] < 2:
         return np.zeros_like(x)
-    return np.ediff1d(x, to_begin=(x[1] - x[0])) / dt
+    d = np.empty_like(x)                 # (x: [F] or [F, C], differences along the first axis; the values np.ediff1d(x, to_begin=x[1] - x[0]) gives)
+    np.subtract(x[1:], x[:-1], out=d[1:])
+    d[0] = d[1]
+    return d / dt
 
 
 # --------------------------------------------------------------------------------------------- history table
@@ -150,9 +153,8 @@ def build_scene(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float, ho
     ids_out_all = track_ids[~in_mask]
 
     def node_state(xy):                                                        # [F, 2] -> [F, 6]
-        vx, vy = derivative_of(xy[:, 0], dt), derivative_of(xy[:, 1], dt)
-        ax, ay = derivative_of(vx, dt), derivative_of(vy, dt)
-        return np.stack([xy[:, 0], xy[:, 1], vx, vy, ax, ay], axis=1)
+        v = derivative_of(xy, dt)                                              # both coordinates at once (element-wise: same values)
+        return np.concatenate([xy, v, derivative_of(v, dt)], axis=1)
 
     # scene nodes in track-id order (robot first when it is in the cluster)
     node_ids = list(ids_in_all)

@@ -46,16 +46,18 @@ def test_net_and_sampler_match_reference(case):
     with torch.no_grad():
         beta = O.variance_schedule()["betas"][[100] * (K * A)]
         e = O.net_forward(w, x_T, ctx.repeat(K, 1), beta, joint=joint)
-        vel = torch.from_numpy(z["vel"]) if heavy else O.denoise(w, ctx, x_T, sample=K, step=step, joint=joint)
+        vel = None if heavy else O.denoise(w, ctx, x_T, sample=K, step=step, joint=joint)
     # mean ADE-style metric: mean L2 over (sample, agent, t).  Gate of the project is 1e-4.
     # The oracle restates the same torch-CPU ops: bit-exact at width 32, and within fp32 GEMM
     # blocking noise at width 256 (measured <= 1.4e-6 after 50 steps, below the reference's own
     # fp32-vs-fp64 distance of 1.7e-6) -> held to 5e-6.
     d_e = np.linalg.norm(e.numpy() - z["e_first"], axis=-1).mean()
-    d_v = np.linalg.norm(vel.numpy() - z["vel"], axis=-1).mean()
     assert d_e <= 1e-6, d_e
-    assert d_v <= 5e-6, d_v
     assert int(z["nsteps"]) == K * (100 // int(100 / step) + 1)
+    if heavy:
+        pytest.skip("first net evaluation checked; the 50-step sampler of this fixture runs with JMID_SLOW_TESTS=1")
+    d_v = np.linalg.norm(vel.numpy() - z["vel"], axis=-1).mean()
+    assert d_v <= 5e-6, d_v
 
 
 WRAP_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "wrapper_*.npz")))

@@ -19,9 +19,8 @@ ctx = torch.randn([E, A, 256], generator=g).cuda()
 x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
 engs = []
 for p in paths:
-    _lib._LIB = None
-    _lib.library_path = lambda p=p: os.path.join(ROOT, p)
-    engs.append(JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 0), joint=os.environ.get("AB_NET", "jmid") == "jmid", step=50))
+    engs.append(JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 0), joint=os.environ.get("AB_NET", "jmid") == "jmid", step=50,
+                           lib_path=os.path.join(ROOT, p)))
 res = [[] for _ in paths]
 outs = [None] * len(paths)
 for rep in range(5):
