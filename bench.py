@@ -106,6 +106,29 @@ def pmc_summary(mode):
     return None, None
 
 
+def sustained_mfma_tflops():
+    """What a pure v_mfma_f32_32x32x16_f16 loop sustains on THIS box with fresh random operands (tools/mfma_peak.hip: every CU, two
+    waves per SIMD, warm clocks; the chip is power-limited well below the 2.5 PFLOP/s dense peak).  Compiled and run next to the
+    bench (hipcc is part of the image); None when that is not possible."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = os.path.join(REPO, "tools", "mfma_peak.hip")
+    if not (os.path.exists(hipcc) and os.path.exists(src)):
+        return None
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            exe = os.path.join(td, "mfma_peak")
+            subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", src, "-o", exe], check=True, capture_output=True, timeout=180)
+            out = subprocess.run([exe, "sustained"], check=True, capture_output=True, text=True, timeout=120).stdout
+        tf = float(out.split("TFLOP/s")[0].split()[-1])
+        mhz = float(out.split("shader clock")[1].split()[0])
+        return {"tflops": tf, "shader_clock_mhz": mhz}
+    except Exception:
+        return None
+
+
 _T0 = time.perf_counter()
 
 
@@ -532,6 +555,19 @@ def main():
             if src:
                 src = dict(src, measured_in_run=False)
         fill_pmc(results[m], m, pmc, src)
+
+    # the MFMA rate this box sustains (power-limited), measured next to the bench: frac_of_sustained = MFMA FLOPs the dominant
+    # kernel ISSUES per second / that rate
+    sus = sustained_mfma_tflops() if world == 1 else None
+    for m in modes:
+        roof = results[m].get("roofline")
+        if roof and sus:
+            roof["peak_sustained_random_operands"] = sus["tflops"]
+            roof["sustained_source"] = {"measured_in_run": True, "tool": "tools/mfma_peak.hip sustained (fp16 32x32x16 MFMA loop, fresh random "
+                                        "operands, 2 waves per SIMD on every CU, warm clocks)", "shader_clock_mhz": sus["shader_clock_mhz"]}
+            roof["frac_of_sustained"] = round(roof["achieved"] * roof["mfma_passes_per_product"] / sus["tflops"], 4)
+    if sus:
+        log(f"sustained MFMA rate on this box: {sus['tflops']:.0f} TFLOP/s at {sus['shader_clock_mhz']:.0f} MHz")
 
     head = results[args.precision]
     out = {

@@ -222,7 +222,7 @@ int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
  * The diagnostics flavour of the library (built with -DJMID_DIAGNOSTICS as csrc/libjmid_hip_diag.so; what tests/ and tools/
  * load) additionally takes the implementation knobs the experiments of docs/NOTEBOOK.md are made with - kernel-variant
  * selectors such as "gemm_h_variant", "ln_fuse", "ln_rows", "mx_ln", "attn_mx", "attn_nsplit", "vt_stage", "graph",
- * "tail_fuse", "out_traj", "csl_swap", "attn_pf" (listed with their value ranges in csrc/jmid_api.hip::jmid_set_tuning and
+ * "tail_fuse", "out_traj", "csl_swap", "attn_pf" (listed with their value ranges in csrc/jmid_abi.hip::jmid_set_tuning and
  * csrc/common.hpp::Tuning; every variant of a key computes the same values, most of them bit-identically) - and, with
  * -DJMID_ABLATIONS on top, the timing ablations "gemm_abl" / "attn_abl" (WRONG results).  Every switch belongs to the handle it
  * is set on.  Unknown keys return JMID_EINVAL. */

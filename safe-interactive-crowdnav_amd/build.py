@@ -10,7 +10,8 @@ LIB = os.path.join(CSRC, "libjmid_hip.so")
 # the diagnostics flavour: the same kernels + the jmid_dbg_* single-kernel entry points and the jmid_set_tuning experiment knobs
 # (-DJMID_DIAGNOSTICS).  tests/ and tools/ load it (tests/conftest.py sets JMID_LIB); the product never does.
 LIB_DIAG = os.path.join(CSRC, "libjmid_hip_diag.so")
-SOURCES = ["jmid_api.hip"]
+# translation units of the host side (csrc/jmid_ctx.hpp says what each holds); every unit instantiates the kernels it launches
+SOURCES = ["jmid_abi.hip", "jmid_weights.hip", "jmid_planner.hip", "jmid_profile.hip", "jmid_diag.hip"]
 
 
 def _newest_source_mtime() -> float:
@@ -43,14 +44,32 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
     # 400 overlaps, 0 with straight selects or other co-runners) - the cause of the run-to-run variation with several
     # chunks in flight (docs/NOTEBOOK.md section 3).  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
     # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-ffp-contract=off",
-           "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else []) + \
-          ["-Wl,--version-script=libjmid.map", "-o", LIB] + SOURCES
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-ffp-contract=off",
+             "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else [])
+    objdir = os.path.join(CSRC, "obj_diag" if diagnostics else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    # the units compile side by side (the planner - every GEMM / attention instantiation of the denoise loop - is the long one)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        jobs.append((src, obj, subprocess.Popen(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs, failed = [], []
+    for src, obj, proc in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            failed.append(f"{src}:\n{out}")
+        objs.append(obj)
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(failed))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=libjmid.map", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{proc.stdout}\n{proc.stderr}")
+        raise RuntimeError(f"hipcc (link) failed:\n{proc.stdout}\n{proc.stderr}")
     return LIB
 
 

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 }
 
 // merge the nsplit partial results of the split-KV launch: O = sum_i 2^(m_i - M) O_i / sum_i 2^(m_i - M) l_i
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t Mtot, int HD) {
+static __global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t Mtot, int HD) {
     const int d = a.d, d4 = d >> 2;
     const size_t total = Mtot * d4;
     bool overflow = false;

@@ -83,9 +83,9 @@ struct Tuning {
     int attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA
     int attn_pack = 1;       // 0 = one short sequence per wave even when S <= 16
     int vt_stage = 0;        // 256x256 QKV kernel: V^T through LDS in full rows (0 / 1 on, 2 = direct 8-byte stores)
-    int graph = 0;           // captured denoise loop (hipGraph) of one-chunk calls: 1 on, 0 / 2 off (default: not faster, see jmid_api.hip)
+    int graph = 0;           // captured denoise loop (hipGraph) of one-chunk calls: 1 on, 0 / 2 off (default: not faster, see jmid_planner.hip)
     int attn_nsplit = 0;     // split-KV factor of the head_dim-128 attention launches: 0 auto, 1..16 forced
-    int tail_fuse = 0;       // tail of the net in one kernel (tail_f16x3.hpp, d_model 512): 1 on, 0 / 2 off (default: slower, see jmid_api.hip)
+    int tail_fuse = 0;       // tail of the net in one kernel (tail_f16x3.hpp, d_model 512): 1 on, 0 / 2 off (default: slower, see jmid_planner.hip)
     int tail_rows = 0;       // its row tile: 0 auto, 32, 64
     int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
     int out_traj = 0;        // output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories, 1 = always, 2 = one wave per token
@@ -94,6 +94,7 @@ struct Tuning {
     int attn_pf = 0;         // F16MX / F16X2 attention with one plane of P: 2 = fragment reads one step ahead instead of three (A/B; same bits)
     int gemm_small = 0;      // launches of at most one workgroup per CU (gemm_small.hpp): 0 = the deep-ring k64 kernel, 1 = the round-3 tile shapes, 2 = the deep-ring kernel only up to one workgroup per CU
     int small_ln = 0;        // out_proj / linear2 + residual + LayerNorm of a small launch in ONE kernel (last-arriver tail): 1 on (measured slower: the tail's VALU work lands on 19 workgroups), 0 / 2 off (GEMM + add_ln*)
+    int gemm_pn = 0;         // F16MX large-tile GEMMs: column groups of the XCD tile order (0 / 1 = N fastest over all N-tiles)
     int small_now = 1;       // set per call by run_network: the small-launch kernels only while ONE chunk is in flight (with two lanes their
                              // one-workgroup-per-CU launches collide: 4 episodes as 2 x 2 measured 4 % slower with them)
     int small_pn = 0;        // its column groups per launch (two-dimensional XCD tile order): 0 = fewest Infinity-Cache bytes, 1 / 2 / 4 / 8 forced

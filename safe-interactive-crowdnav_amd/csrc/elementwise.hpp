@@ -76,7 +76,7 @@ __device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, in
 }
 
 // one thread per (token, 4 channels)
-__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+static __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
     const int d4 = a.d >> 2;
     const long total = (long)a.M * d4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs
 
 // ------------------------------------------------------------------------------------------------ integrator
 // vel [R, T, 2] (R = E*K*A rows, r = (e*K+s)*A + a) -> pos = cumsum_t(vel)*dt + p0[e, a]
-__global__ void integrate_kernel(const float* vel, const float* p0, float* pos, int R, int T, int A, int KA, float dt) {
+static __global__ void integrate_kernel(const float* vel, const float* p0, float* pos, int R, int T, int A, int KA, float dt) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (row, c)
     if (idx >= R * 2) return;
     const int r = idx >> 1, c = idx & 1;
@@ -359,7 +359,7 @@ __global__ void integrate_kernel(const float* vel, const float* p0, float* pos, 
 //   out[e] = { mean ADE over (sample, agent, t),  min over samples of the agent-mean ADE,
 //              mean FDE over (sample, agent),     min over samples of the agent-mean FDE }
 // pos [E, K, A, T, 2], gt [E, A, T, 2].  One workgroup per episode, one wave per sample (strided).
-__global__ __launch_bounds__(256) void episode_metrics_kernel(const float* pos, const float* gt, float* out, int K, int A,
+static __global__ __launch_bounds__(256) void episode_metrics_kernel(const float* pos, const float* gt, float* out, int K, int A,
                                                               int T) {
     __shared__ float s_ade[256], s_fde[256];
     const int e = blockIdx.x, tid = threadIdx.x;

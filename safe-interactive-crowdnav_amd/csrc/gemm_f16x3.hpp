@@ -77,14 +77,15 @@ __device__ __forceinline__ bool split_range_exceeded(unsigned amax16) {
     return (amax16 & 0xffffu) > kHalfMaxBits || (amax16 >> 16) > kHalfMaxBits;
 }
 
-// epilogue stores of streamed outputs (Q / K / V^T planes: written once, read by another kernel): with -DJMID_NT_STORES they
-// carry the non-temporal hint, so that they do not push the launch's operand panels out of the XCD's L2 (A/B: tools/ab_builds.py)
+// epilogue stores of streamed outputs (the staged Q / K / V^T rows of the in_proj GEMM: written once, read by another kernel) carry
+// the non-temporal hint, so that they do not push the launch's operand panels out of the XCD's L2: a 51-episode f16mx call 113.7 ->
+// 112.8 ms, f16x3 unchanged, same bits (tools/ab_builds.py; -DJMID_NO_NT_STORES for the A/B)
 template <typename T>
 __device__ __forceinline__ void store_stream(T* p, const T& v) {
-#ifdef JMID_NT_STORES
-    __builtin_nontemporal_store(v, p);
-#else
+#ifdef JMID_NO_NT_STORES
     *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
 #endif
 }
 
@@ -1097,7 +1098,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // fp32 [N, K] -> bf8 (e5m2) image of W_lo = W * scale - fp16(W * scale): the top byte of fp16(W_lo) after rounding to nearest
-__global__ void w8_image_kernel(const float* W, unsigned char* out, int N, int K, float scale) {
+static __global__ void w8_image_kernel(const float* W, unsigned char* out, int N, int K, float scale) {
     const size_t n = (size_t)N * K;
     const int nb32 = N / 32;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -1155,7 +1156,10 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int tm = swz / ntn, tn = swz - tm * ntn;
+    // (experiment knob "gemm_pn": the tile sequence cut into column groups of gw N-tiles, each walked M-major - gemm_small.hpp's order)
+    const int gw = (stage_vt >> 8) ? (stage_vt >> 8) : ntn;
+    const int per_g = ntm * gw, cg = swz / per_g, rem_g = swz - cg * per_g;
+    const int tm = rem_g / gw, tn = cg * gw + (rem_g - tm * gw);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = g.K / GEMMH_BK;                     // even: K is a multiple of 64
     const int nrb = (g.M + 127) / 128;
@@ -1329,7 +1333,8 @@ inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
     }
     const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only; bit 2: row-wise ConcatSquash epilogue
     hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
-                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0));
+                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0) |
+                           ((tune().gemm_pn > 1 && ntn % tune().gemm_pn == 0 ? ntn / tune().gemm_pn : 0) << 8));
     return hipGetLastError();
 }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_64(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 1, 1, 4>(g, st); }
@@ -1499,7 +1504,7 @@ inline hipError_t launch_gemm_h(const GemmHArgs& g, hipStream_t st) {
 }
 
 // fp32 -> hi/lo planes (weights at load time, activations produced by fp32-only kernels)
-__global__ void split_planes_kernel(const float* in, half_t* hi, half_t* lo, size_t n, int* range_flag) {
+static __global__ void split_planes_kernel(const float* in, half_t* hi, half_t* lo, size_t n, int* range_flag) {
     bool overflow = false;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float v = in[i];
@@ -1513,7 +1518,7 @@ __global__ void split_planes_kernel(const float* in, half_t* hi, half_t* lo, siz
 }
 
 // fp32 row-major [rows, K] -> hi/lo planes in the blocked panel layout (weights at load time, diagnostics)
-__global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K, int* range_flag,
+static __global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K, int* range_flag,
                                             float scale) {   // scale = kWScale for weights, 1 for activations
     bool overflow = false;
     const size_t n = (size_t)rows * K;
@@ -1533,7 +1538,7 @@ __global__ void split_planes_blocked_kernel(const float* in, half_t* hi, half_t*
 // V planes [nseq*S, d] (token-major, as the QKV GEMM emits them) -> V^T planes [nseq][nhead][hd][Spad]
 // (key-contiguous: the k-operand layout of the PV product).  64x64 tiles through LDS; both planes per block.
 // Key order inside every 16-key group: common.hpp::vt_key_pos.   grid = (ceil(S/64), d/64, nseq)
-__global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, const half_t* vl, half_t* vth, half_t* vtl,
+static __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, const half_t* vl, half_t* vth, half_t* vtl,
                                                           int S, int Spad, int d, int hd) {
     __shared__ half_t tile[2][64][64 + 8];
     const int tid = threadIdx.x;
@@ -1564,7 +1569,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const half_t* vh, cons
 }
 
 // blocked hi/lo planes [rows, K] -> fp32 row-major (diagnostics)
-__global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* out, int rows, int K) {
+static __global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* out, int rows, int K) {
     const size_t n = (size_t)rows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t o = blk_index((int)(i / K), (int)(i % K), K);
@@ -1574,7 +1579,7 @@ __global__ void merge_planes_kernel(const half_t* hi, const half_t* lo, float* o
 
 // packed fp32 QKV [M, 3d] -> Q/K planes [M, d] + V^T planes [nseq][nhead][hd][Spad] (diagnostics; the pipeline
 // gets these straight from the QKV GEMM epilogue)
-__global__ void qkv_to_planes_kernel(const float* qkv, half_t* qh, half_t* ql, half_t* kh, half_t* kl, half_t* vth,
+static __global__ void qkv_to_planes_kernel(const float* qkv, half_t* qh, half_t* ql, half_t* kh, half_t* kl, half_t* vth,
                                      half_t* vtl, size_t M, int d, int hd, int S, int Spad, float qscale) {
     const size_t n = M * d;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {

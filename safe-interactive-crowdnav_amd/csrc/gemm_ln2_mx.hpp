@@ -375,7 +375,7 @@ inline hipError_t launch_gemm_ln2_mx(const GemmLn2Args& g, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------
 // The unfused partner (launches too small to fill the chip): X <- LN(X + Y) for the same planes, with the row statistics
 // summed in the canonical order - lane (row, c, h) of a wave of 4 rows owns the 32 columns of partial(c, h).
-__global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, const float* gamma, const float* beta, int M, float eps,
+static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, const float* gamma, const float* beta, int M, float eps,
                                                       half_t* Xh, unsigned char* Xl8, int no_lo_out, int* range_flag) {
     constexpr int d = GLN_BN;
     const int lane = threadIdx.x & 63;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, const floa
 }
 
 // fp32 row-major [rows, 512] <-> the residual-stream planes of this mode (fp16 hi, blocked; bf8 image of lo): diagnostics
-__global__ void split_planes_lo8_kernel(const float* in, half_t* hi, unsigned char* lo8, int rows) {
+static __global__ void split_planes_lo8_kernel(const float* in, half_t* hi, unsigned char* lo8, int rows) {
     const size_t n = (size_t)rows * GLN_BN;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / GLN_BN), k = (int)(i % GLN_BN);
@@ -451,7 +451,7 @@ __global__ void split_planes_lo8_kernel(const float* in, half_t* hi, unsigned ch
         lo8[blk8_index(r, k, GLN_BN)] = bf8_of_f16(l);
     }
 }
-__global__ void merge_planes_lo8_kernel(const half_t* hi, const unsigned char* lo8, float* out, int rows) {
+static __global__ void merge_planes_lo8_kernel(const half_t* hi, const unsigned char* lo8, float* out, int rows) {
     const size_t n = (size_t)rows * GLN_BN;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / GLN_BN), k = (int)(i % GLN_BN);

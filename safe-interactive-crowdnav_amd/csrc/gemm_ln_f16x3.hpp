@@ -44,7 +44,7 @@ struct GemmLnArgs {
 };
 
 // fp32 row-major [512, K] -> k16-panel hi/lo planes
-__global__ void split_planes_k16_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K) {
+static __global__ void split_planes_k16_kernel(const float* in, half_t* hi, half_t* lo, int rows, int K) {
     const size_t n = (size_t)rows * K;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / K), k = (int)(i % K);

@@ -65,7 +65,7 @@ __device__ __forceinline__ void kde_tri_inverse(const double* G, double* X, int 
 }
 
 // one workgroup per (episode, horizon step): ll[e, h, :]
-__global__ __launch_bounds__(KDE_THREADS) void kde_step_kernel(KdeArgs g) {
+static __global__ __launch_bounds__(KDE_THREADS) void kde_step_kernel(KdeArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char kde_lds_raw[];
     const int tid = threadIdx.x, blk = blockIdx.x;
     const int e = blk / g.T, h = blk - e * g.T;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(KDE_THREADS) void kde_step_kernel(KdeArgs g) {
 }
 
 // one workgroup per episode: totals over the horizon, stable ascending rank, the last k, their log-weights, the gather
-__global__ __launch_bounds__(KDE_THREADS) void kde_select_kernel(KdeArgs g) {
+static __global__ __launch_bounds__(KDE_THREADS) void kde_select_kernel(KdeArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char kde_lds_raw[];
     const int tid = threadIdx.x, e = blockIdx.x;
     const int A = g.A, K = g.K, T = g.T, k = g.k;

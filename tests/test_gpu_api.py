@@ -198,3 +198,35 @@ def test_two_handles_run_concurrently_from_two_host_threads():
     for eng, *_ in jobs:
         eng.close()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("ctx_dim,precision", [(32, "f32"), (256, "f16x3"), (256, "f16mx")])
+@pytest.mark.parametrize("E,A,K,T,k", [(1, 3, 100, 8, 15), (1, 5, 20, 12, 20), (3, 2, 12, 6, 4)])
+def test_predict_entry_equals_the_staged_calls(ctx_dim, precision, E, A, K, T, k):
+    """jmid_predict (what predict_ret_best() issues per MPC step: mid_sim_wrapper.py:482-510) = jmid_encode -> jmid_denoise ->
+    jmid_topk chained on the stream: the same bits as the three calls, for the shipped shape, for k == K (no ranking) and for
+    several episodes; repeated calls (the pinned staging buffers are reused) agree."""
+    e = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), 3), joint=True, step=2)
+    try:
+        g = torch.Generator().manual_seed(E * 100 + A * 10 + k)
+        x_st = torch.randn([E * A, 6, 6], generator=g).numpy()
+        nbr = torch.randn([E * A, 2, 6, 6], generator=g).numpy()
+        em = torch.rand([E * A, 2], generator=g).numpy()
+        x_T = torch.randn([E, K * A, T, 2], generator=g).numpy()
+        p0 = torch.randn([E, A, 2], generator=g).numpy()
+        ctx = e.encode(x_st, nbr, em).reshape(E, A, -1)
+        _, pos = e.denoise(x_T, ctx, p0, dt=0.25, precision=precision, want_vel=False)
+        for _ in range(2):
+            out, lw = e.predict(x_st, nbr, em, x_T, p0, k, dt=0.25, precision=precision)
+            if k < K:
+                sel_ref, lw_ref = e.topk(pos, k)
+                np.testing.assert_array_equal(out, sel_ref)
+                np.testing.assert_array_equal(lw, lw_ref)
+            else:
+                assert lw is None
+                np.testing.assert_array_equal(out, pos)
+        with pytest.raises(JmidError) as ei:
+            e.predict(x_st, nbr, em, x_T, p0, K + 1, precision=precision)
+        assert ei.value.code == -1
+    finally:
+        e.close()

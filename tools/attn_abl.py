@@ -1,7 +1,7 @@
 # Timing ablations of the kernel (results are WRONG by construction).  NEEDS A BUILD WITH -DJMID_ABLATIONS - the production
 # library has no ablation knobs:
 #   (cd safe-interactive-crowdnav_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value \
-#        -ffp-contract=off -DJMID_ABLATIONS -o ../../build/libjmid_abl.so jmid_api.hip)
+#        -ffp-contract=off -DJMID_ABLATIONS -o ../../build/libjmid_abl.so jmid_abi.hip jmid_weights.hip jmid_planner.hip jmid_profile.hip jmid_diag.hip)
 #   JMID_LIB=build/libjmid_abl.so python tools/attn_abl.py
 import os, sys
 import numpy as np

@@ -91,8 +91,13 @@ void run(const char* name, K kern, int blocks, int threads, int iters, int nacc,
            threads / 64, ms, nm * flop_per_mfma / ms / 1e9, ms * 1e-3 * 2.4e9 / (iters * nacc * (threads / 256.0)));
     hipFree(d);
 }
-int main() {
+int main(int argc, char** argv) {
     const double f16 = 2.0 * 32 * 32 * 16, f32 = 2.0 * 32 * 32 * 2;
+    if (argc > 1) {      // `mfma_peak sustained`: only the rate a pure fp16 MFMA loop sustains on fresh random operands, warm clocks, two
+                         // waves per SIMD on every CU (what bench.py quotes roofline.frac_of_sustained against)
+        run_rand<4>("f16 RANDOM data 4acc 2w/SIMD", 512, 20000);
+        return 0;
+    }
     run("f16 32x32x16 4acc 1w/SIMD", k_f16<4>, 256, 256, 20000, 4, f16);
     run("f16 32x32x16 4acc 2w/SIMD", k_f16<4>, 512, 256, 20000, 4, f16);
     run("f16 32x32x16 1acc 1w/SIMD", k_f16<1>, 256, 256, 40000, 1, f16);
