@@ -303,7 +303,7 @@ def main():
     ap.add_argument("--total-episodes", type=int, default=4096, help="episodes of the whole job with --scaling strong")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not re-run one 51-episode call under rocprofv3 --pmc after the timed region (roofline.traffic / mfma_busy "
-                         "then come from the committed profiles/ summary, labelled as such)")
+                         "then come from the committed profiles/ summary, labelled as such) and do not run the sustained-MFMA probe")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run every collective even with one rank (exercises the RCCL calls "
                          "of the N > 1 path on a one-GPU box)")
@@ -558,7 +558,7 @@ def main():
 
     # the MFMA rate this box sustains (power-limited), measured next to the bench: frac_of_sustained = MFMA FLOPs the dominant
     # kernel ISSUES per second / that rate
-    sus = sustained_mfma_tflops() if world == 1 else None
+    sus = sustained_mfma_tflops() if world == 1 and not args.no_pmc else None
     for m in modes:
         roof = results[m].get("roofline")
         if roof and sus:

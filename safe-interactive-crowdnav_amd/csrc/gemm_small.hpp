@@ -49,9 +49,13 @@ struct SmCfg {
     static constexpr int A_PLANES = MODE == SM_X3 ? 2 : 1, W_PLANES = MODE == SM_MX ? 1 : 2;
     static constexpr int BLK = 2 * (A_PLANES * A_SUB + W_PLANES * W_SUB) + (MODE == SM_MX ? BN * 64 : 0);     // one k64 block, all planes
     // k64 blocks per ring stage: a stage costs a wave one wait + barrier + LDS round trip however deep it is (the wave is alone
-    // on its SIMD: nothing hides them), so stages are k128 wherever three of them fit the CU's LDS
+    // on its SIMD: nothing hides them), so stages are k128 wherever TWO of them fit the LDS budget (three: one scene 11.92 vs
+    // 11.71 ms in f16mx, 13.78 vs 13.66 in f16x3; -DJMID_SMALL_KB_STAGES=3 for the A/B)
     static constexpr int BUDGET = TWO ? 80 * 1024 : 144 * 1024;
-    static constexpr int KB = (TWO ? 2 : 3) * 2 * BLK <= BUDGET ? 2 : 1;
+#ifndef JMID_SMALL_KB_STAGES
+#define JMID_SMALL_KB_STAGES 2
+#endif
+    static constexpr int KB = (TWO ? 2 : JMID_SMALL_KB_STAGES) * 2 * BLK <= BUDGET ? 2 : 1;
     static constexpr int A_BYTES = KB * 2 * A_SUB, W_BYTES = KB * 2 * W_SUB;          // one plane of a stage
     static constexpr int W8_BLOCK = MODE == SM_MX ? BN * 64 : 0;                    // bf8(W_lo) of one k64 block
     static constexpr int OFF_AH = 0, OFF_AL = A_BYTES, OFF_WH = A_PLANES * A_BYTES, OFF_WL = OFF_WH + W_BYTES;

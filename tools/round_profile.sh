@@ -2,7 +2,7 @@
 # All measurements profiles/ holds for a round, in one GPU-box call (about 15 minutes).  Output: gpurun_out/$R/
 #   R=r02 tools/round_profile.sh ; then python tools/update_profiles.py r02
 export TMPDIR=/tmp
-R=${R:-r03}
+R=${R:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 # PMC first: HBM bytes and MFMA busy per production kernel over one whole call, per mode; the summaries go into profiles/ of
@@ -14,28 +14,33 @@ for m in f16mx f16x2 f16x3; do
 done
 # default bench (BASELINE configs[2]), all split modes measured identically, parity sample over all chunks
 timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
-timeout 300 python bench.py --precision f32 --modes f32 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
-timeout 300 python bench.py --workload cfg2 --cpu-episodes 0 --no-e2e --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
-timeout 300 python bench.py --workload cfg4 --cpu-episodes 0 --no-e2e --steps 3 > $O/bench_cfg4.json 2>/dev/null
-timeout 400 python bench.py --workload cfg5 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg5_1gpu.json 2>/dev/null
-timeout 300 python bench.py --net imid --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_imid.json 2>/dev/null
-timeout 300 python bench.py --scenes orca --cpu-episodes 4 --no-e2e --steps 2 > $O/bench_cfg3_orca.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --precision f32 --modes f32 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --workload cfg2 --cpu-episodes 0 --no-e2e --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --workload cfg4 --cpu-episodes 0 --no-e2e --steps 3 > $O/bench_cfg4.json 2>/dev/null
+timeout 400 python bench.py --no-pmc --workload cfg5 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg5_1gpu.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --net imid --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_imid.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --scenes orca --cpu-episodes 4 --no-e2e --steps 2 > $O/bench_cfg3_orca.json 2>/dev/null
 # episodes per call sweep (weak-scaling unit), both modes
 for e in 1 2 4 8 16 32 52 104 256 512; do
-  timeout 300 python bench.py --cpu-episodes 0 --no-e2e --episodes-per-gpu $e --steps 2 --warmup 1 --no-profile 2>/dev/null | python -c "
+  timeout 300 python bench.py --no-pmc --cpu-episodes 0 --no-e2e --episodes-per-gpu $e --steps 2 --warmup 1 --no-profile 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print('episodes/call', $e, {m: (v['value'], v['ms_per_step']) for m, v in d['modes'].items()})"
 done > $O/episode_sweep.log
 # rocprofv3 kernel stats of one step on a 51-episode chunk, per mode
 for m in f16mx f16x2 f16x3; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --precision $m --modes $m --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --no-e2e --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
-  find $O/prof_$m -name "*kernel_stats.csv" -exec cp {} $O/${m}_kernel_stats.csv \;
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$m -- python bench.py --no-pmc --precision $m --modes $m --lanes 1 --steps 1 --warmup 0 --cpu-episodes 0 --no-e2e --episodes-per-gpu 51 > $O/prof_bench_$m.log 2>&1
+  cp "$(find $O/prof_$m -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2-)" $O/${m}_kernel_stats.csv
   rm -rf $O/prof_$m
 done
 # single-scene kernel stats
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --workload cfg2 --modes f16mx --steps 20 --warmup 3 --cpu-episodes 0 --no-e2e --no-profile > $O/prof_bench_cfg2.log 2>&1
-find $O/prof_ss -name "*kernel_stats.csv" -exec cp {} $O/cfg2_f16mx_kernel_stats.csv \;
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ss -- python bench.py --no-pmc --workload cfg2 --modes f16mx --steps 20 --warmup 3 --cpu-episodes 0 --no-e2e --no-profile > $O/prof_bench_cfg2.log 2>&1
+cp "$(find $O/prof_ss -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d" " -f2-)" $O/cfg2_f16mx_kernel_stats.csv
 rm -rf $O/prof_ss
+# round 4: the shipped operating point end to end (wall split + kernel stats), the one-scene launch traces, the 2-rank strong-scaling line
+for m in f16mx f16x3; do JMID_PREC=$m tools/shipped_profile.sh; done > $O/shipped_profile.log 2>&1
+JMID_PREC=f16mx tools/small_pmc.sh 1 > /dev/null 2>&1; cp gpurun_out/small_pmc_f16mx_E1.txt $O/small_pmc_f16mx_E1.txt
+for t in small_gemm_trace_0 attn_small_trace; do if [ -x build/$t ]; then ./build/$t; fi; done > $O/small_launch_traces.log 2>&1
+timeout 600 python bench.py --gpus 2 --dist-backend gloo --device 0 --total-episodes 512 --steps 2 --warmup 1 --cpu-episodes 0 --no-profile 2>/dev/null | grep '^{' > $O/bench_strong_2ranks_1gpu.json
 # reproducibility soak of the default path + the documented multi-lane disturbance
 # reproducibility soak: one chunk in flight, and 2 / 3 / 4 chunks in flight against the one-chunk reference (bitwise)
 python tools/rerun_soak.py f16mx 20 256 1 > $O/soak.log 2>&1
