@@ -60,7 +60,13 @@ struct AttnHArgs {
     // of the fp16 K_lo plane): the two correction terms of the logits run as bf8 x bf8 MFMAs.  Null: the fp16 terms.
     const unsigned char *K8h, *K8l;
     const unsigned char* Q8l;    // with them: bf8 image of Q_lo in the Q_lo plane's place (null: made here from the fp16 plane)
+    // reciprocals of the three divisors of the workgroup index (q-tiles, splits, heads), filled in by launch_attn_f16x3: the
+    // kernel's index arithmetic was 625 instructions before its first copy went out (nine run-time integer divisions, two of
+    // them 64-bit: 1.8 us of a one-scene wave's 10 us).  0 = not filled in (probes that launch the kernel directly): divide.
+    unsigned mq = 0, ms = 0, mh = 0;
+    int nseq = 0;
 };
+
 
 template <int HD>
 __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
@@ -274,6 +280,7 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
+    args_now_each(a, nqt, abl, trace);
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
     unsigned long long rt0 = 0;
     if (TRACE) {
@@ -288,9 +295,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int qt = swz % nqt, sh0 = swz / nqt;
-    const int split = sh0 % a.nsplit, sh = sh0 / a.nsplit;
-    const int h = sh % a.nhead, seq = sh / a.nhead;
+    const int sh0 = fast_div(swz, nqt, a.mq), qt = swz - sh0 * nqt;
+    const int sh = fast_div(sh0, a.nsplit, a.ms), split = sh0 - sh * a.nsplit;
+    const int seq = fast_div(sh, a.nhead, a.mh), h = sh - seq * a.nhead;
     const int S = a.S, d = a.d;
     const size_t tok0 = (size_t)seq * S;
     const int q = (qt * 4 + wid) * 32 + l31;
@@ -449,8 +456,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     for (int mf = 0; mf < 2; ++mf) vbase[mf] = l31 * 32 + (((2 * mf + hi) ^ ((l31 >> 2) & 3)) * 8);
 
     const int ntiles_all = (S + KT - 1) / KT;
-    const int kt_begin = (int)((long)split * ntiles_all / a.nsplit);
-    const int ntiles = (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
+    const bool fd = a.ms != 0 || a.nsplit == 1;
+    const int kt_begin = fd ? fast_div(split * ntiles_all, a.nsplit, a.ms) : (int)((long)split * ntiles_all / a.nsplit);
+    const int ntiles = fd ? fast_div((split + 1) * ntiles_all, a.nsplit, a.ms)
+                          : (int)((long)(split + 1) * ntiles_all / a.nsplit);   // exclusive end of this split's key tiles
     {
     if (kt_begin == last_tile) use_last_offsets();
     ATT_STAMP(7)   // arguments, tile arithmetic, Q loads requested
@@ -674,7 +683,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 
     if (a.nsplit > 1) {
         if (q < S) {
-            const size_t Mtot = (size_t)(gridDim.x / (nqt * a.nhead * a.nsplit)) * S;   // nseq * S
+            const size_t Mtot = (size_t)(a.nseq ? a.nseq : gridDim.x / (nqt * a.nhead * a.nsplit)) * S;   // nseq * S
             const size_t tok = tok0 + q;
             float* op = a.Opart + ((size_t)split * Mtot + tok) * d + h * HD;
 #pragma unroll
@@ -723,23 +732,53 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 
 // merge the nsplit partial results of the split-KV launch: O = sum_i 2^(m_i - M) O_i / sum_i 2^(m_i - M) l_i
 static __global__ __launch_bounds__(256) void attn_combine_kernel(AttnHArgs a, size_t Mtot, int HD) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    args_now_each(a, Mtot, HD);
     const int d = a.d, d4 = d >> 2;
     const size_t total = Mtot * d4;
+    // index arithmetic in 32 bits and shifts when d / 4 is a power of two (it is: 128 at d_model 512); the size_t divisions were
+    // 250 instructions in front of the first load of a kernel whose body is 3 us
+    const bool fast = (d4 & (d4 - 1)) == 0 && total < (1ull << 31);
+    const int sh4 = __builtin_ctz((unsigned)d4);
     bool overflow = false;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const size_t tok = idx / d4;
-        const int c = (int)(idx % d4) * 4, h = c / HD;
+        const size_t tok = fast ? (size_t)((unsigned)idx >> sh4) : idx / d4;
+        const int c = (fast ? (int)((unsigned)idx & (unsigned)(d4 - 1)) : (int)(idx % d4)) * 4, h = HD == 128 ? c >> 7 : c / HD;
         float M = -INFINITY;
-        for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, a.MLpart[(((size_t)i * Mtot + tok) * a.nhead + h) * 2]);
         float L = 0.f;
         f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < a.nsplit; ++i) {
-            const float* ml = a.MLpart + (((size_t)i * Mtot + tok) * a.nhead + h) * 2;
-            const float w = __builtin_amdgcn_exp2f(ml[0] - M);
-            L = fmaf(w, ml[1], L);
-            const f32x4 p = *reinterpret_cast<const f32x4*>(a.Opart + ((size_t)i * Mtot + tok) * d + c);
+        if (a.nsplit <= 8) {
+            // every partial requested before the first is used: one memory round trip instead of two (the same operations in the
+            // same order as the loops below)
+            f32x2_ ml[8];
+            f32x4 p[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaf(w, p[e], o[e]);
+            for (int i = 0; i < 8; ++i)
+                if (i < a.nsplit) {
+                    ml[i] = *reinterpret_cast<const f32x2_*>(a.MLpart + (((size_t)i * Mtot + tok) * a.nhead + h) * 2);
+                    p[i] = *reinterpret_cast<const f32x4*>(a.Opart + ((size_t)i * Mtot + tok) * d + c);
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < a.nsplit) M = fmaxf(M, ml[i][0]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < a.nsplit) {
+                    const float w = __builtin_amdgcn_exp2f(ml[i][0] - M);
+                    L = fmaf(w, ml[i][1], L);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf(w, p[i][e], o[e]);
+                }
+        } else {
+            for (int i = 0; i < a.nsplit; ++i) M = fmaxf(M, a.MLpart[(((size_t)i * Mtot + tok) * a.nhead + h) * 2]);
+            for (int i = 0; i < a.nsplit; ++i) {
+                const float* ml = a.MLpart + (((size_t)i * Mtot + tok) * a.nhead + h) * 2;
+                const float w = __builtin_amdgcn_exp2f(ml[0] - M);
+                L = fmaf(w, ml[1], L);
+                const f32x4 p = *reinterpret_cast<const f32x4*>(a.Opart + ((size_t)i * Mtot + tok) * d + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(w, p[e], o[e]);
+            }
         }
         const float inv = 1.0f / L;
         f16x4 vh, vl;
@@ -799,10 +838,16 @@ inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }
 
-inline hipError_t launch_attn_f16x3(const AttnHArgs& a, int nseq, int head_dim, hipStream_t st) {
+inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
+    AttnHArgs a = a_in;
     if (head_dim == 128 && tune().attn_h_variant != 1) {
         const int nqt = (a.S + 127) / 128;
         const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
+        const unsigned long long x_max = std::max<unsigned long long>(grid1.x, (unsigned long long)a.nsplit * ((a.S + 31) / 32));
+        a.mq = fast_div_magic(nqt, x_max);
+        a.ms = fast_div_magic(a.nsplit, x_max);
+        a.mh = fast_div_magic(a.nhead, x_max);
+        a.nseq = nseq;
         // the mode is a template parameter (a run-time flag in the key-tile loop costs F16X3 ~4 %).  F16X2 / F16MX: one fp16 plane
         // of P unless "attn_mx" = 1; F16MX with bf8 K images: the logits' correction terms as bf8 MFMAs
         const bool p1 = tune().attn_mx != 1;

@@ -36,16 +36,33 @@ __host__ __device__ inline HyperLayout make_hyper_layout(int d_model, int d_mid,
     return L;
 }
 
+// x / d for 0 <= x, x * d < 2^32, with m = 2^32 / d + 1 made on the host (fast_div_magic; 0: plain division)
+__device__ __forceinline__ int fast_div(int x, int d, unsigned m) {
+    return m ? (int)__umulhi((unsigned)x, m) : (d == 1 ? x : x / d);
+}
+inline unsigned fast_div_magic(int d, unsigned long long x_max) {
+    return d > 1 && x_max * (unsigned long long)d < (1ull << 32) ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u;
+}
+
 // token m -> (episode, agent) row of the hyper buffer.  rows: r = (e*K + s)*A + a ; m = r*T + t
 struct RowMap {
     int T, A, KA;  // KA = K*A
+    unsigned mT = 0, mKA = 0, mA = 0;     // reciprocals (make_rowmap); 0: divide
     __device__ __forceinline__ int ea(int m) const {
-        int r = m / T;
-        int e = r / KA;
-        int a = r % A;
+        const int r = fast_div(m, T, mT);
+        const int e = fast_div(r, KA, mKA);
+        const int a = r - fast_div(r, A, mA) * A;
         return e * A + a;
     }
+    __device__ __forceinline__ int t_of(int m) const { return m - fast_div(m, T, mT) * T; }
 };
+inline RowMap make_rowmap(int T, int A, int KA, unsigned long long M) {
+    RowMap r{T, A, KA};
+    r.mT = fast_div_magic(T, M);
+    r.mKA = fast_div_magic(KA, M);
+    r.mA = fast_div_magic(A, M);
+    return r;
+}
 
 // Blocked ("panel") layout of an fp16 operand plane [rows, K] of the split-fp16 GEMMs: 128-row x 32-half tiles of
 // 8 KB stored contiguously, tile (rb, kb) at ((rb * K/32 + kb) * 4096) halfs.  Inside a tile, row r is a 64-byte line
@@ -69,6 +86,23 @@ __host__ __device__ __forceinline__ int vt_key_pos(int key) {
     return (key & ~15) | ((((g & 1) << 1) | (g >> 1)) << 2) | (key & 3);
 }
 __host__ __device__ __forceinline__ int vt_spad(int S) { return (S + 15) / 16 * 16; }
+
+// A kernel's argument block, requested in ONE batch at entry.  Left to itself hipcc sinks the scalar loads of fields that are used
+// late or conditionally next to their uses: the attention kernel waited for its arguments three times in a row, each a cold miss
+// (the scalar cache is invalidated at every kernel boundary and the block was just written by the host) of ~0.7 us - in a
+// one-scene launch that lives 10 us.  args_now(a) makes every dword of the block an input of an empty asm statement at the top.
+template <typename T>
+__device__ __forceinline__ void args_now(const T& a) {
+    static_assert(sizeof(T) % 4 == 0, "argument block of whole dwords");
+    struct Words { unsigned w[sizeof(T) / 4]; };
+    const Words w = __builtin_bit_cast(Words, a);
+    // inputs only: the values the kernel goes on to use are the original ones (a pointer that went THROUGH the asm would lose its
+    // address space: flat loads with vmcnt + lgkmcnt waits instead of global loads)
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) asm volatile("" ::"s"(w.w[i]));
+}
+template <typename... T>
+__device__ __forceinline__ void args_now_each(const T&... t) { (args_now(t), ...); }
 
 // Tuning knobs (jmid_set_tuning).  They belong to a handle: every entry point of the C ABI installs its handle's
 // set for the duration of the call (TuneScope, thread-local), the launch helpers read it through tune().
@@ -97,6 +131,7 @@ struct Tuning {
     int gemm_pn = 0;         // F16MX large-tile GEMMs: column groups of the XCD tile order (0 / 1 = N fastest over all N-tiles)
     int small_now = 1;       // set per call by run_network: the small-launch kernels only while ONE chunk is in flight (with two lanes their
                              // one-workgroup-per-CU launches collide: 4 episodes as 2 x 2 measured 4 % slower with them)
+    int small_lanes = 0;     // experiment: the small-launch kernels with several chunks in flight too: 1 = all of them, 2 = only the two-workgroups-per-CU shape
     int small_pn = 0;        // its column groups per launch (two-dimensional XCD tile order): 0 = fewest Infinity-Cache bytes, 1 / 2 / 4 / 8 forced
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS
     int gemm_abl = 0;

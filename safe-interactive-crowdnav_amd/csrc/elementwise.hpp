@@ -77,11 +77,12 @@ __device__ __forceinline__ void embed_store(const EmbedArgs& a, int m, int j, in
 
 // one thread per (token, 4 channels)
 static __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
+    args_now(a);
     const int d4 = a.d >> 2;
     const long total = (long)a.M * d4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int m = (int)(idx / d4), j = (int)(idx % d4) * 4;
-        embed_store(a, m, j, m % a.rmap.T, a.x[2 * (size_t)m], a.x[2 * (size_t)m + 1],
+        embed_store(a, m, j, a.rmap.t_of(m), a.x[2 * (size_t)m], a.x[2 * (size_t)m + 1],
                     a.hyp + (size_t)a.rmap.ea(m) * a.hyp_ld);
     }
 }
@@ -94,6 +95,7 @@ static __global__ __launch_bounds__(256) void embed_kernel(EmbedArgs a) {
 template <int VPL, bool PLANES>  // float4 vectors per lane
 __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, const float* gamma, const float* beta,
                                                      int M, int d, float eps, half_t* Xh, half_t* Xl) {
+    args_now_each(X, Y, gamma, beta, M, d, eps, Xh, Xl);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -101,6 +103,17 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
     const float* yr = Y + (size_t)row * d;
     f32x4 v[VPL];
     float s = 0.f;
+    // gamma / beta requested with the row (behind the statistics they are VPL more dependent round trips: the compiler cannot
+    // move them above the stores of the vector before)
+    f32x4 gmv[VPL], btv[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < d) {
+            gmv[i] = *reinterpret_cast<const f32x4*>(gamma + c);
+            btv[i] = *reinterpret_cast<const f32x4*>(beta + c);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * 64 + lane) * 4;
@@ -140,8 +153,7 @@ __global__ __launch_bounds__(256) void add_ln_kernel(float* X, const float* Y, c
     for (int i = 0; i < VPL; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < d) {
-            f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c);
-            f32x4 bt = *reinterpret_cast<const f32x4*>(beta + c);
+            const f32x4 gm = gmv[i], bt = btv[i];
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * gm[e] + bt[e];
@@ -222,7 +234,7 @@ __device__ __forceinline__ void out_update(const OutArgs& a, int m, float s0, fl
     }
 }
 __device__ __forceinline__ void embed_row(const EmbedArgs& nxt, int m, int lane, float x0, float x1) {
-    const int t = m % nxt.rmap.T;
+    const int t = nxt.rmap.t_of(m);
     const float* hrow = nxt.hyp + (size_t)nxt.rmap.ea(m) * nxt.hyp_ld;
     for (int j = lane * 4; j < nxt.d; j += 256) embed_store(nxt, m, j, t, x0, x1, hrow);
 }
@@ -239,6 +251,7 @@ __device__ __forceinline__ void out_ddim_row(const OutArgs& a, const EmbedArgs& 
 // one wave per token.  EMBED_NEXT: one launch and one pass over x less per denoise step.
 template <bool EMBED_NEXT>
 __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt) {
+    args_now_each(a, nxt);
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= a.M) return;
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs
     // tpw tokens per wave (a divisor of T: a whole trajectory, or a piece of one when there are few trajectories)
     const int lane = threadIdx.x & 63;
     const int piece = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int m0 = piece * tpw, t0 = m0 % a.rmap.T;
+    const int m0 = piece * tpw, t0 = a.rmap.t_of(m0);
     if (m0 >= a.M) return;
     EmbedCols c[2];
     const int j0 = lane * 4, j1 = lane * 4 + 256;

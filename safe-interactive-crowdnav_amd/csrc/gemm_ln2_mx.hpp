@@ -378,12 +378,22 @@ inline hipError_t launch_gemm_ln2_mx(const GemmLn2Args& g, hipStream_t st) {
 static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, const float* gamma, const float* beta, int M, float eps,
                                                       half_t* Xh, unsigned char* Xl8, int no_lo_out, int* range_flag) {
     constexpr int d = GLN_BN;
+    args_now_each(Y, gamma, beta, M, eps, Xh, Xl8, no_lo_out, range_flag);
     const int lane = threadIdx.x & 63;
     const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const int c = (lane >> 1) & 7, hi = lane & 1;
     const int rowc = row < M ? row : M - 1;
     float v[32];
     float s = 0.f;
+    // gamma / beta requested with the row itself: behind the statistics they were four more dependent round trips (the compiler
+    // cannot move them above the stores of the block before)
+    f32x4 gm[8], bt[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
+        gm[2 * u] = *reinterpret_cast<const f32x4*>(gamma + c0), gm[2 * u + 1] = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+        bt[2 * u] = *reinterpret_cast<const f32x4*>(beta + c0), bt[2 * u + 1] = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
@@ -420,8 +430,7 @@ static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, con
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(beta + c0), t1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+        const f32x4 g0 = gm[2 * u], g1 = gm[2 * u + 1], t0 = bt[2 * u], t1 = bt[2 * u + 1];
         f16x8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {

@@ -300,11 +300,12 @@ __device__ __forceinline__ void ln_tail_planes(const float* Y, const float* gamm
 }
 
 template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
-__global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags) {
+__global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags, unsigned mper, unsigned mgw) {
     using C = SmCfg<MODE, WC, TWO>;
     constexpr bool X2 = MODE != SM_X3, MX = MODE == SM_MX;
     constexpr int BM = C::BM, BN = C::BN, NS = C::NS, L = C::L, KB = C::KB;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    args_now_each(g, ntm, ntn, gw, flags, mper, mgw);      // (four dependent scalar-cache misses in front of the first copy otherwise)
 #ifdef JMID_SMALL_TRACE
     unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;     // (loaded before the ring starts: vmcnt stays the ring's)
     asm volatile("" : "+s"(sm_trace_p));
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int s = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int per = ntm * gw, cg = s / per, rem = s - cg * per;
-    const int tm = rem / gw, tn = cg * gw + (rem - tm * gw);
+    const int per = ntm * gw, cg = fast_div(s, per, mper), rem = s - cg * per;      // (reciprocals from the host: common.hpp)
+    const int tm = fast_div(rem, gw, mgw), tn = cg * gw + (rem - tm * gw);
     const int m0 = tm * BM, n0 = tn * BN;
     const int nk = g.K / 32, nst = g.K / (64 * KB);
 
@@ -541,8 +542,9 @@ inline hipError_t launch_gemm_small_cfg(const GemmHArgs& g, hipStream_t st) {
     const int pn = tune().small_pn > 0 ? (ntn % tune().small_pn == 0 ? tune().small_pn : 1)
                                        : small_pick_groups(g, ntn, MODE == SM_MX ? 3.0 : 4.0, MODE == SM_X3 ? 4.0 : 2.0);
     const int flags = (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0);
+    const int gw = ntn / pn;
     hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, MODE, WC, TWO>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
-                       ntn / pn, flags);
+                       gw, flags, fast_div_magic(ntm * gw, (unsigned long long)ntm * ntn), fast_div_magic(gw, (unsigned long long)ntm * ntn));
     return hipGetLastError();
 }
 
@@ -552,6 +554,7 @@ inline int small_gemm_shape(const GemmHArgs& g) {
     if (tune().gemm_small == 1 || tune().gemm_h_variant != 0 || !tune().small_now) return 0;
     if (g.K % 128 != 0 || g.N % 128 != 0) return 0;       // (k128 ring stages)
     const long ntm = (g.M + 63) / 64;
+    if (tune().small_now == 2) return g.x2 && ntm * (g.N / 128) <= 512 ? 8 : 0;      // (experiment "small_lanes" = 2)
     if (ntm * (g.N / 64) <= 256) return 2;
     if (ntm * (g.N / 128) <= 256) return 4;
     // 257 ... 512 tiles of 64 x 128 (two scenes; the reference's shipped K = 100): the same kernel, two workgroups per CU

@@ -106,7 +106,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
-    RowMap rm{T, A, K * A};
+    const RowMap rm = make_rowmap(T, A, K * A, (unsigned long long)M);
     // JMID_PREC_F16MX at d_model 512: second-generation LayerNorm kernels (gemm_ln2_mx.hpp) - the lo plane of the residual stream
     // is a byte plane (it lives in the memory of the fp16 one), the row statistics are summed in that file's order
     const bool mxv2 = split && h->mx && d == GLN_BN && tune().mx_ln != 2;
@@ -489,7 +489,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         Tuning& t;
         SmallNow(Tuning& t_, int v) : t(t_) { t.small_now = v; }
         ~SmallNow() { t.small_now = 1; }
-    } small_now_scope(h->tune, lanes == 1 ? 1 : 0);
+    } small_now_scope(h->tune, lanes == 1 || h->tune.small_lanes == 1 ? 1 : h->tune.small_lanes == 2 ? 2 : 0);
     const size_t lane_floats = step_ws_floats(h, Mc, precision, sg_full, ns_call, nullptr, nullptr);
     const size_t need = io_off + lanes * lane_floats;
     if (int rc = ensure_arena(h, need)) return rc;

@@ -23,7 +23,7 @@ for p in paths:
                            lib_path=os.path.join(ROOT, p)))
 res = [[] for _ in paths]
 outs = [None] * len(paths)
-for rep in range(5):
+for rep in range(int(os.environ.get("AB_REPS", "5"))):
     for i, eng in enumerate(engs):
         eng.synchronize()
         t0 = time.perf_counter()

@@ -21,6 +21,9 @@ int main(int argc, char** argv) {
     a.Opart = (float*)dalloc((size_t)ns * M * d * 4, 0); a.MLpart = (float*)dalloc((size_t)ns * M * nhead * 2 * 4, 0);
     a.range_flag = (int*)dalloc(4, 0);
     const int nqt = (S + 127) / 128, nblk = nqt * nhead * nseq * ns;
+    if (argc <= 3 || atoi(argv[3])) {      // the reciprocals launch_attn_f16x3 hands the kernel (third argument 0: run-time divisions, as before round 4)
+        a.mq = fast_div_magic(nqt, nblk); a.ms = fast_div_magic(ns, nblk); a.mh = fast_div_magic(nhead, nblk); a.nseq = nseq;
+    }
     unsigned long long* trace = (unsigned long long*)dalloc((size_t)nblk * 4 * 12 * 8, 0);
     auto kt = &attn_f16x3_dma_kernel<true, true, true, false, true, true>;
     auto kp = &attn_f16x3_dma_kernel<false, true, true, false, true, true>;

@@ -49,7 +49,7 @@ void run(const char* name, int M, int N, int K) {
             for (int it = 0; it < n; ++it) {
                 // a dependent predecessor that dirties the A plane (as the real chain does), so the operands are not L2-warm
                 hipLaunchKernelGGL(dirty_kernel, dim3(256), dim3(256), 0, 0, reinterpret_cast<unsigned*>(ah), pa / 2);
-                hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, SM_MX, WC>), dim3(nwg), dim3(C::NT), C::LDS_BYTES, 0, g, ntm, ntn, ntn / pn, 4);
+                hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, SM_MX, WC>), dim3(nwg), dim3(C::NT), C::LDS_BYTES, 0, g, ntm, ntn, ntn / pn, 4, 0u, 0u);
             }
         };
         chain(reps);                 // warm clocks
