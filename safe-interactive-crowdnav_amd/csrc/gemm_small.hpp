@@ -560,6 +560,8 @@ inline int small_gemm_shape(const GemmHArgs& g) {
     // 257 ... 512 tiles of 64 x 128 (two scenes; the reference's shipped K = 100): the same kernel, two workgroups per CU
     // (not F16X3: two k64 stages of its four operand planes do not fit half a CU's LDS)
     if (g.x2 && tune().gemm_small != 2 && ntm * (g.N / 128) <= 512) return 8;
+    // (F16X3 at 257 ... 512 tiles in two rounds of one workgroup per CU measured slower than the round-3 kernels: 0.996 vs 0.977 ms
+    //  per shipped-point call)
     return 0;
 }
 
