@@ -132,6 +132,8 @@ struct Tuning {
     int small_now = 1;       // set per call by run_network: the small-launch kernels only while ONE chunk is in flight (with two lanes their
                              // one-workgroup-per-CU launches collide: 4 episodes as 2 x 2 measured 4 % slower with them)
     int small_lanes = 0;     // experiment: the small-launch kernels with several chunks in flight too: 1 = all of them, 2 = only the two-workgroups-per-CU shape
+    int small_out = 0;       // concat4 + output layer + DDIM update + next embedding of a small launch in one kernel (gemm_small_out_kernel): 1 on (measured slower: 19 workgroups walk the output stage of 1200 tokens), 0 / 2 off
+    int small_qk = 0;        // Q / K tiles of a small in_proj launch out through LDS in full rows: 0 / 1 on, 2 = the generic element-wise epilogue
     int small_pn = 0;        // its column groups per launch (two-dimensional XCD tile order): 0 = fewest Infinity-Cache bytes, 1 / 2 / 4 / 8 forced
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS
     int gemm_abl = 0;

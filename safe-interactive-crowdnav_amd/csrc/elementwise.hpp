@@ -263,13 +263,11 @@ __global__ __launch_bounds__(256) void out_ddim_kernel(OutArgs a, EmbedArgs nxt)
 // per token in the kernel above - are computed once per trajectory, and a wave's stores walk through adjacent rows of the
 // blocked planes.  Same expressions per element (embed_cols / embed_store_cols): the same bits.  70 -> 4x us per 61 200-token
 // launch (the kernel above was 2.3 % of an F16MX step).
-template <bool EMBED_NEXT>
-__global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs nxt, int tpw) {
-    // tpw tokens per wave (a divisor of T: a whole trajectory, or a piece of one when there are few trajectories)
-    const int lane = threadIdx.x & 63;
-    const int piece = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int m0 = piece * tpw, t0 = a.rmap.t_of(m0);
-    if (m0 >= a.M) return;
+// The body: tokens m0 ... m0 + tpw - 1 (inside one trajectory) by one wave; `y` = the Y4 row of token m0, rows y_ld floats apart
+// (YP: a global pointer into a.Y4, or an LDS pointer into the tile a GEMM epilogue left there: gemm_small_out_kernel).
+template <bool EMBED_NEXT, typename YP>
+__device__ __forceinline__ void out_ddim_piece(const OutArgs& a, const EmbedArgs& nxt, int m0, int tpw, int lane, YP y, int y_ld) {
+    const int t0 = a.rmap.t_of(m0);
     EmbedCols c[2];
     const int j0 = lane * 4, j1 = lane * 4 + 256;
     if (EMBED_NEXT) {
@@ -295,9 +293,9 @@ __global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs
         if (regs) {
 #pragma unroll
             for (int u = 0; u < 12; ++u) {
-                const float* y = a.Y4 + (size_t)(m0 + tb + (u < nb ? u : 0)) * a.dl;
-                yv[u][0] = c0 < a.dl ? y[c0] : 0.f;
-                yv[u][1] = c1 < a.dl ? y[c1] : 0.f;
+                const YP yu = y + (size_t)(tb + (u < nb ? u : 0)) * y_ld;
+                yv[u][0] = c0 < a.dl ? yu[c0] : 0.f;
+                yv[u][1] = c1 < a.dl ? yu[c1] : 0.f;
             }
         }
         // lane u holds x (and the DDPM draw) of token u of the block
@@ -349,6 +347,16 @@ __global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs
             }
         }
     }
+}
+
+template <bool EMBED_NEXT>
+__global__ __launch_bounds__(256) void out_ddim_traj_kernel(OutArgs a, EmbedArgs nxt, int tpw) {
+    // tpw tokens per wave (a divisor of T: a whole trajectory, or a piece of one when there are few trajectories)
+    const int lane = threadIdx.x & 63;
+    const int piece = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int m0 = piece * tpw;
+    if (m0 >= a.M) return;
+    out_ddim_piece<EMBED_NEXT>(a, nxt, m0, tpw, lane, a.Y4 + (size_t)m0 * a.dl, a.dl);
 }
 
 // ------------------------------------------------------------------------------------------------ integrator

@@ -36,9 +36,11 @@ __device__ unsigned long long* g_small_trace;
 #define JMID_SMALL_ABL 0
 #endif
 #define SM_ABL(bit) ((JMID_SMALL_ABL & (bit)) != 0)      // compile-time ablations: 16 no copies, 32 no fp16 MFMAs, 64 the launch alone
+#define SM_TRACE_ARG , sm_trace_p
 #else
 #define SM_STAMP(i)
 #define SM_ABL(bit) false
+#define SM_TRACE_ARG
 #endif
 
 
@@ -95,6 +97,7 @@ __device__ __forceinline__ f32x4 load_sc1_b128(const float* p) {
 //   i = 2 u + half: the four floats 64 c + 32 (u >> 1) + 16 (u & 1) + 8 h + 4 half + 0..3.  Block c (16 KB, contiguous) is exactly
 //   what the workgroup of N-tile c produces; consumer wave w owns blocks 2 w and 2 w + 1 (lanes 0-31 / 32-63) for all 64 rows, and the
 //   row totals are formed from the eight P_c in LDS, in the canonical order.
+__device__ __forceinline__ bool tune_small_qk(int flags) { return (flags & 16) == 0; }      // ("small_qk" = 2: the generic epilogue, A/B)
 constexpr int SM_LN_TILE_BYTES = 64 * GLN_BN * 4;          // one row tile of the hand-off buffer: 128 KB
 constexpr int SM_STG_LD = 68;                              // floats per row of the staged 64 x 64 tile (272 B: conflict-free b128)
 
@@ -299,30 +302,21 @@ __device__ __forceinline__ void ln_tail_planes(const float* Y, const float* gamm
     }
 }
 
-template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
-__global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags, unsigned mper, unsigned mgw) {
+// The K loop of one tile (tm, tn): ring primed, then per stage wait + barrier + the mode's canonical MFMA sequence per k64 block.
+// SWAP: the transposed product (W fragment first).  Shared by gemm_small_kernel and gemm_small_out_kernel.
+template <int MODE, int WC, bool TWO, bool SWAP>
+__device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char* lds_raw, int tm, int tn, int tid
+#ifdef JMID_SMALL_TRACE
+                                              , unsigned long long* sm_trace_p
+#endif
+) {
     using C = SmCfg<MODE, WC, TWO>;
     constexpr bool X2 = MODE != SM_X3, MX = MODE == SM_MX;
-    constexpr int BM = C::BM, BN = C::BN, NS = C::NS, L = C::L, KB = C::KB;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    args_now_each(g, ntm, ntn, gw, flags, mper, mgw);      // (four dependent scalar-cache misses in front of the first copy otherwise)
-#ifdef JMID_SMALL_TRACE
-    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;     // (loaded before the ring starts: vmcnt stays the ring's)
-    asm volatile("" : "+s"(sm_trace_p));
-    if (SM_ABL(64)) return;          // ablation: the launch alone
-#endif
-    SM_STAMP(0);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int BN = C::BN, NS = C::NS, L = C::L, KB = C::KB;
+    const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wr = wid / WC, wc = wid % WC;
-    // XCD-contiguous ranges of the tile sequence (block b runs on XCD b % 8: for speed only); the sequence is cut into column
-    // groups of gw N-tiles, each walked M-major with the group's N-tiles fastest
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
-    const int s = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int per = ntm * gw, cg = fast_div(s, per, mper), rem = s - cg * per;      // (reciprocals from the host: common.hpp)
-    const int tm = fast_div(rem, gw, mgw), tn = cg * gw + (rem - tm * gw);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int n0 = tn * BN;
     const int nk = g.K / 32, nst = g.K / (64 * KB);
 
     // DMA sources of stage 0, one per wave-instruction of a stage ("round"), in the fixed order A_hi [A_lo] W_hi [W_lo] [W8];
@@ -371,7 +365,6 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
                                              (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 0);
         }
     };
-    f32x16 acc[1][1];
     const int rowA = wr * 32 + l31, rowW = wc * 32 + l31;
     int offA[2], offW[2];               // bytes inside a k32 sub-tile, per 16-deep step
 #pragma unroll
@@ -379,82 +372,176 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
         offA[ks] = (rowA * 32 + (((ks * 2 + hi) ^ ((rowA >> 2) & 3)) * 8)) * 2;
         offW[ks] = (rowW * 32 + (((ks * 2 + hi) ^ ((rowW >> 2) & 3)) * 8)) * 2;
     }
-    auto kloop = [&](auto swap_c) {
-        constexpr bool SWAP = decltype(swap_c)::value;
-        f32x16 c;
+
+    f32x16 c;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < L; ++t)
-            if (t < nst) issue(t, t);
-        SM_STAMP(1);
-        int slot = 0;
-        for (int si = 0; si < nst; ++si) {
-            if (si + L - 1 < nst) wait_vmcnt<(L - 1) * C::NR>();       // stage si has landed (this wave's share) ...
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                              // ... and everybody else's; the slot of stage si - 1 is free
-            __builtin_amdgcn_sched_barrier(0);
+    for (int t = 0; t < L; ++t)
+        if (t < nst) issue(t, t);
+    SM_STAMP(1);
+    int slot = 0;
+    for (int si = 0; si < nst; ++si) {
+        if (si + L - 1 < nst) wait_vmcnt<(L - 1) * C::NR>();       // stage si has landed (this wave's share) ...
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                              // ... and everybody else's; the slot of stage si - 1 is free
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef JMID_SMALL_TRACE
-            if (si == 0) SM_STAMP(2);
+        if (si == 0) SM_STAMP(2);
 #endif
-            if (si + L < nst) issue(si + L, slot == 0 ? NS - 1 : slot - 1);
-            const unsigned char* st = lds_raw + slot * C::STAGE;
+        if (si + L < nst) issue(si + L, slot == 0 ? NS - 1 : slot - 1);
+        const unsigned char* st = lds_raw + slot * C::STAGE;
 #pragma unroll
-            for (int j = 0; j < KB; ++j) {          // the k64 blocks of the stage; per block the canonical MFMA sequence of the mode
-                f16x8 ah[4], al[4], wh[4], wl[4];
+        for (int j = 0; j < KB; ++j) {          // the k64 blocks of the stage; per block the canonical MFMA sequence of the mode
+            f16x8 ah[4], al[4], wh[4], wl[4];
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int sub = 2 * j + (ks >> 1), step = ks & 1;
-                    ah[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_AH + sub * C::A_SUB + offA[step]);
-                    wh[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_WH + sub * C::W_SUB + offW[step]);
-                    if (!X2) al[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_AL + sub * C::A_SUB + offA[step]);
-                    if (!MX) wl[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_WL + sub * C::W_SUB + offW[step]);
-                }
-                i32x8 w8, a8;
-                if (MX) {
-                    const unsigned char* p = st + C::OFF_W8 + j * C::W8_BLOCK + wc * 2048 + lane * 16;
-                    const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
-                    const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
-                    w8 = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (!SM_ABL(32))
-                    c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah[ks], c, 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], wh[ks], c, 0, 0, 0);
-                    if (MX) {
-                        // the bf8 image of this step's A fragment, in the shadow of the MFMA just issued (pinned: left to itself the
-                        // compiler sinks all eight packs in front of the fp8 instruction, onto the wave's critical path)
-                        const i32x4 d = __builtin_bit_cast(i32x4, ah[ks]);
-                        int p0 = bf8_of_f16x4(d[0], d[1]), p1 = bf8_of_f16x4(d[2], d[3]);
-                        asm volatile("" : "+v"(p0), "+v"(p1));
-                        a8[ks * 2 + 0] = p0;
-                        a8[ks * 2 + 1] = p1;
-                    } else {
-                        c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah[ks], c, 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], wl[ks], c, 0, 0, 0);
-                        if (!X2)
-                            c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al[ks], c, 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], wh[ks], c, 0, 0, 0);
-                    }
-                }
-                if (MX)      // both operands bf8, literal zero scales: the UNSCALED instruction (gemm_f16x3.hpp)
-                    c = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, c, 1, 1, 0, 0, 0, 0)
-                             : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, c, 1, 1, 0, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) {
+                const int sub = 2 * j + (ks >> 1), step = ks & 1;
+                ah[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_AH + sub * C::A_SUB + offA[step]);
+                wh[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_WH + sub * C::W_SUB + offW[step]);
+                if (!X2) al[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_AL + sub * C::A_SUB + offA[step]);
+                if (!MX) wl[ks] = *reinterpret_cast<const f16x8*>(st + C::OFF_WL + sub * C::W_SUB + offW[step]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            slot = slot + 1 == NS ? 0 : slot + 1;
+            i32x8 w8, a8;
+            if (MX) {
+                const unsigned char* p = st + C::OFF_W8 + j * C::W8_BLOCK + wc * 2048 + lane * 16;
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(p);
+                const i32x4 up = *reinterpret_cast<const i32x4*>(p + 1024);
+                w8 = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (!SM_ABL(32))
+                c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], ah[ks], c, 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], wh[ks], c, 0, 0, 0);
+                if (MX) {
+                    // the bf8 image of this step's A fragment, in the shadow of the MFMA just issued (pinned: left to itself the
+                    // compiler sinks all eight packs in front of the fp8 instruction, onto the wave's critical path)
+                    const i32x4 d = __builtin_bit_cast(i32x4, ah[ks]);
+                    int p0 = bf8_of_f16x4(d[0], d[1]), p1 = bf8_of_f16x4(d[2], d[3]);
+                    asm volatile("" : "+v"(p0), "+v"(p1));
+                    a8[ks * 2 + 0] = p0;
+                    a8[ks * 2 + 1] = p1;
+                } else {
+                    c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], ah[ks], c, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], wl[ks], c, 0, 0, 0);
+                    if (!X2)
+                        c = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], al[ks], c, 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], wh[ks], c, 0, 0, 0);
+                }
+            }
+            if (MX)      // both operands bf8, literal zero scales: the UNSCALED instruction (gemm_f16x3.hpp)
+                c = SWAP ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(w8, a8, c, 1, 1, 0, 0, 0, 0)
+                         : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, w8, c, 1, 1, 0, 0, 0, 0);
         }
-        acc[0][0] = c;
-        SM_STAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    }
+    SM_STAMP(3);
+    return c;
+}
+
+// Q / K tile (64 tokens x one head of 128 columns) of the in_proj GEMM of a small launch, out through LDS in full rows: the
+// transposed product leaves a lane with four runs of 4 consecutive columns of ONE token, the workgroup's 8 waves fill one 64 x 128
+// fp16 tile (qk_staged_store's swizzle), and the rows leave as 16 bytes per lane, 256 contiguous bytes per token and plane - the
+// bf8 images (F16MX) made from the rows on their way out.  The generic epilogue wrote every element with a 2-byte store and every
+// image byte with a 1-byte store (48 store instructions per lane of a K tile): the in_proj launch of one scene spent 1.8 us (its
+// slowest workgroup 3.0) behind its K loop where linear1 spends 0.65 (tools/small_gemm_trace.hip).  Same values, same bits.
+template <bool K8IMG>
+__device__ __forceinline__ void small_qk_staged_store(const GemmHArgs& g, const f32x16& acc, int m0, int n0, half_t* tile, int tid) {
+    const int lane = tid & 63, wid = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid >> 2, wc = wid & 3;
+    const int part = n0 / g.d, nn0 = n0 - part * g.d;
+    half_t* dst_base[2] = {part == 0 ? g.Chi : g.Khi, part == 0 ? g.Clo : g.Klo};
+    const float qs = part == 0 ? g.qscale : 1.0f;
+    const bool k8 = K8IMG && part == 1 && g.K8h != nullptr;     // K tile in F16MX: plane 1 is the two bf8 images instead of fp16 K_lo
+    const bool q8 = K8IMG && part == 0 && g.Q8l != nullptr;     // Q tile: the bf8 image of Q_lo instead of the fp16 plane
+    const int row = wr * 32 + l31;
+    auto lds_at = [&](int q) {
+        const int c = (8 * wc + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
+        return reinterpret_cast<f16x4*>(tile + row * 128 + c * 4);
     };
+    unsigned am = 0;
+    i32x2_s lo_pk[4];
+    {
+        f32x4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 32 + 8 * q + 4 * hi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = fmaf(acc[4 * q + e], kWInv, bv[q][e]);
+                if (part == 0) v[e] *= qs;
+            }
+            const Split4 sp = split_f32x4(v[0], v[1], v[2], v[3], am);
+            *lds_at(q) = __builtin_bit_cast(f16x4, sp.hi);
+            lo_pk[q] = sp.lo;
+        }
+    }
+    if (m0 + row < g.M && split_range_exceeded(am)) atomicOr(g.range_flag, 1);       // (rows past M hold what the padding held)
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+        if (plane == 1) {
+            __syncthreads();                                   // the hi rows have left the tile
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *lds_at(q) = __builtin_bit_cast(f16x4, lo_pk[q]);
+        }
+        __syncthreads();
+        half_t* dst = dst_base[plane] + (size_t)m0 * g.d + nn0;
+        const bool img = k8 || (q8 && plane == 1);
+        unsigned char* dst8 = img ? (k8 ? (plane == 0 ? g.K8h : g.K8l) : g.Q8l) + (size_t)m0 * g.d + nn0 : nullptr;
+#pragma unroll
+        for (int t = 2 * wid; t < 2 * wid + 2; ++t) {          // 16 groups of 4 rows, two per wave
+            const int r = t * 4 + (lane >> 4), u = lane & 15;
+            const f16x8 v8 = *reinterpret_cast<const f16x8*>(tile + r * 128 + ((u ^ (r & 15)) << 3));
+            if (m0 + r < g.M) {
+                if (!((k8 || q8) && plane == 1)) *reinterpret_cast<f16x8*>(dst + (size_t)r * g.d + u * 8) = v8;
+                if (img) {
+                    const i32x4_e dw = __builtin_bit_cast(i32x4_e, v8);
+                    i32x2_e b8;
+                    b8[0] = bf8_of_f16x4_e(dw[0], dw[1]);
+                    b8[1] = bf8_of_f16x4_e(dw[2], dw[3]);
+                    *reinterpret_cast<i32x2_e*>(dst8 + (size_t)r * g.d + u * 8) = b8;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
+__global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags, unsigned mper, unsigned mgw) {
+    using C = SmCfg<MODE, WC, TWO>;
+    constexpr bool X2 = MODE != SM_X3, MX = MODE == SM_MX;
+    constexpr int BM = C::BM, BN = C::BN, NS = C::NS, L = C::L, KB = C::KB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    args_now_each(g, ntm, ntn, gw, flags, mper, mgw);      // (four dependent scalar-cache misses in front of the first copy otherwise)
+#ifdef JMID_SMALL_TRACE
+    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;     // (loaded before the ring starts: vmcnt stays the ring's)
+    asm volatile("" : "+s"(sm_trace_p));
+    if (SM_ABL(64)) return;          // ablation: the launch alone
+#endif
+    SM_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid / WC, wc = wid % WC;
+    // XCD-contiguous ranges of the tile sequence (block b runs on XCD b % 8: for speed only); the sequence is cut into column
+    // groups of gw N-tiles, each walked M-major with the group's N-tiles fastest
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int s = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int per = ntm * gw, cg = fast_div(s, per, mper), rem = s - cg * per;      // (reciprocals from the host: common.hpp)
+    const int tm = fast_div(rem, gw, mgw), tn = cg * gw + (rem - tm * gw);
+    const int m0 = tm * BM, n0 = tn * BN;
+    f32x16 acc[1][1];
     if constexpr (OUT == OUT_LN) {
         // Transposed product: a lane owns token row l31 of its wave's block and four runs of 4 consecutive columns.  The fp32 rows
         // (accumulator + bias: what the stand-alone GEMM hands add_ln*) go out write-through (sc1), the workgroup's arrival is counted
         // per row tile, and the LAST of the ntn workgroups of a tile - whoever that is, wherever it runs - reads the complete rows
         // back (sc1: past its L1) and normalises them.  No spinning: nobody waits for anybody.
         static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
-        kloop(std::true_type{});
+        acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
         __syncthreads();                                       // everybody is done with the operand ring: it becomes the staging tile
         float* stg = reinterpret_cast<float*>(lds_raw);
         {
@@ -497,14 +584,24 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
     // the ConcatSquash GEMMs (and, on request, linear1) run transposed with the row-wise epilogue, as in the large-tile kernels
     if constexpr (csl_rowwise<EPI, OUT>() || (EPI == EPI_BIAS_RELU && OUT == OUT_SPLIT)) {
         if (csl_rowwise<EPI, OUT>() ? (!MX || (flags & 4)) : (flags & 8)) {
-            kloop(std::true_type{});
+            acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
             csl_swapped_epilogue<1, 1, EPI, OUT, X2>(g, acc, m0 + wr * 32, n0 + wc * 32, l31, hi);
             SM_STAMP(4);
             return;
         }
     }
+    // Q / K tiles of in_proj (a 64 x 128 tile is one head of one of Q, K, V): transposed product, rows out through LDS
+    if constexpr (OUT == OUT_QKV && WC == 4) {
+        if (n0 < 2 * g.d && g.d % BN == 0 && tune_small_qk(flags)) {
+            acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
+            __syncthreads();                                   // everybody is done with the operand ring: it becomes the staging tile
+            small_qk_staged_store<MX>(g, acc[0][0], m0, n0, reinterpret_cast<half_t*>(lds_raw), tid);
+            SM_STAMP(4);
+            return;
+        }
+    }
     if constexpr (OUT != OUT_LN) {
-    kloop(std::false_type{});
+    acc[0][0] = small_kloop<MODE, WC, TWO, false>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
     gemm_h_epilogue<1, 1, EPI, OUT, X2, MX && OUT == OUT_QKV>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
     }
     SM_STAMP(4);
@@ -512,6 +609,91 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SM_STAMP(5);
 #endif
+}
+
+// concat4 (ConcatSquash 256 -> 128) + output layer + DDIM / DDPM update + the next step's embedding in ONE small launch: N = 128 is
+// one 64 x 128 tile, i.e. the workgroup owns complete Y4 rows - the only GEMM of the net whose consumer can follow in the same
+// workgroup without another workgroup's data.  The gated Y4 tile stays in LDS (the ring's place), then every wave walks its share
+// of the tile's tokens in pieces of tpw (out_ddim_piece: out_ddim_traj_kernel's body, the same expressions: the same bits as
+// concat4's launch + out_ddim_kernel).  One launch and one pass of Y4 through memory less per denoise step - and MEASURED SLOWER
+// (one scene 12.06 vs 11.55 ms per call in f16mx, 14.08 vs 13.61 in f16x3; the shipped 2-step point 0.766 vs 0.750): the output
+// stage of 1200 tokens lands on 19 workgroups whose waves each walk two pieces one after the other, every piece with its own
+// round trips for the hyper-net rows, x and the stores, where out_ddim_kernel spreads the same latencies over 1200 waves.
+// Opt-in ("small_out" = 1, diagnostics flavour); kept as the fourth data point on why row-complete fusions lose at M = 1200.
+constexpr int SM_Y4_LD = 132;        // floats per row of the Y4 tile in LDS (conflict-free 16-byte rows)
+template <int MODE, bool EMBED_NEXT>
+__global__ __launch_bounds__(512, 1) void gemm_small_out_kernel(GemmHArgs g, OutArgs oa, EmbedArgs nxt, int tpw) {
+    using C = SmCfg<MODE, 4>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    args_now_each(g, oa, nxt, tpw);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid / 4, wc = wid % 4;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;     // (XCD-contiguous row tiles, as everywhere)
+    const int m0 = tm * C::BM;
+#ifdef JMID_SMALL_TRACE
+    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;
+#endif
+    const f32x16 acc = small_kloop<MODE, 4, false, true>(g, lds_raw, tm, 0, tid SM_TRACE_ARG);
+    __syncthreads();                                       // everybody is done with the operand ring: it becomes the Y4 tile
+    float* y4 = reinterpret_cast<float*>(lds_raw);
+    {   // csl_swapped_epilogue<1, 1, EPI_CSL, OUT_F32>, into LDS: lane = token row l31 of its wave's block, four runs of 4 columns
+        const int r = wr * 32 + l31, m = m0 + r;
+        if (m < g.M) {
+            const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0 = wc * 32 + 8 * q + 4 * hi;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + c0);
+                const f32x4 tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0), tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
+                const f32x4 hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0), hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaf(acc[4 * q + e], kWInv, bv[e]);
+                    o[e] = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
+                }
+                *reinterpret_cast<f32x4*>(y4 + r * SM_Y4_LD + c0) = o;
+            }
+        }
+    }
+    __syncthreads();
+    // 64 / tpw pieces of tpw tokens (tpw divides T and 64: a piece lies inside one trajectory), dealt round-robin to the 8 waves
+    typedef const __attribute__((address_space(3))) float* lds_cfp;
+    for (int p = wid; p * tpw < C::BM; p += 8) {
+        const int mp = m0 + p * tpw;
+        if (mp >= g.M) break;
+        out_ddim_piece<EMBED_NEXT>(oa, nxt, mp, tpw, lane, (lds_cfp)(y4 + p * tpw * SM_Y4_LD), SM_Y4_LD);
+    }
+}
+
+// does the tail of a step run as concat3 + this kernel?  (opt-in; one chunk in flight, one workgroup per CU, d_low 128, d_model <= 512)
+inline bool small_out_fits(const GemmHArgs& g, int d_model) {
+    return tune().gemm_small != 1 && tune().gemm_h_variant == 0 && tune().small_now == 1 && tune().small_out == 1 && g.N == 128 &&
+           g.K % 128 == 0 && d_model <= 512 && (g.M + 63) / 64 <= 256;
+}
+template <int MODE>
+inline hipError_t launch_gemm_small_out_mode(const GemmHArgs& g, const OutArgs& oa, const EmbedArgs& nxt, bool embed_next, int T, hipStream_t st) {
+    using C = SmCfg<MODE, 4>;
+    int tpw = 1;
+    while (tpw < 8 && T % (2 * tpw) == 0) tpw *= 2;          // gcd(T, 8): divides T and the 64-row tile, at most one piece per wave
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_out_kernel<MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_out_kernel<MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    }
+    static_assert(C::LDS_BYTES >= size_t(64) * SM_Y4_LD * 4, "the Y4 tile must fit the ring");
+    const dim3 grid((g.M + 63) / 64);
+    if (embed_next) hipLaunchKernelGGL((gemm_small_out_kernel<MODE, true>), grid, dim3(512), C::LDS_BYTES, st, g, oa, nxt, tpw);
+    else hipLaunchKernelGGL((gemm_small_out_kernel<MODE, false>), grid, dim3(512), C::LDS_BYTES, st, g, oa, nxt, tpw);
+    return hipGetLastError();
+}
+inline hipError_t launch_gemm_small_out(const GemmHArgs& g, const OutArgs& oa, const EmbedArgs& nxt, bool embed_next, int T, hipStream_t st) {
+    if (g.x2 && g.W8) return launch_gemm_small_out_mode<SM_MX>(g, oa, nxt, embed_next, T, st);
+    if (g.x2) return launch_gemm_small_out_mode<SM_X2>(g, oa, nxt, embed_next, T, st);
+    return launch_gemm_small_out_mode<SM_X3>(g, oa, nxt, embed_next, T, st);
 }
 
 // bytes all eight XCDs pull from the Infinity Cache with pn column groups: every XCD its column group's share of W and the A rows
@@ -541,7 +723,7 @@ inline hipError_t launch_gemm_small_cfg(const GemmHArgs& g, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
     const int pn = tune().small_pn > 0 ? (ntn % tune().small_pn == 0 ? tune().small_pn : 1)
                                        : small_pick_groups(g, ntn, MODE == SM_MX ? 3.0 : 4.0, MODE == SM_X3 ? 4.0 : 2.0);
-    const int flags = (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0);
+    const int flags = (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0) | (tune().small_qk == 2 ? 16 : 0);
     const int gw = ntn / pn;
     hipLaunchKernelGGL((gemm_small_kernel<EPI, OUT, MODE, WC, TWO>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
                        gw, flags, fast_div_magic(ntm * gw, (unsigned long long)ntm * ntn), fast_div_magic(gw, (unsigned long long)ntm * ntn));

@@ -436,6 +436,8 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
         {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches
         {"small_lanes", &Tuning::small_lanes, 0, 2},
+        {"small_out", &Tuning::small_out, 0, 2},
+        {"small_qk", &Tuning::small_qk, 0, 2},
         {"small_pn", &Tuning::small_pn, 0, 8},                 // column groups of its XCD tile order: 0 auto
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
 #ifdef JMID_ABLATIONS

@@ -102,7 +102,8 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     // embed_done: the previous step's output kernel already embedded x for this step; next_step >= 0: this step's
     // output kernel does the same for step `next_step` (same chunk, same buffers)
     const bool split = precision != JMID_PREC_F32;
-    bool tail_fused = false;
+    bool tail_fused = false, out_fused = false;
+    GemmHArgs g4{};
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
@@ -309,7 +310,11 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         set_w8(h, g, "concat4._layer.weight");
         g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
         g.goff = h->hl.g4; g.boff = h->hl.b4;
-        if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
+        // a small launch runs concat4 together with everything behind it (gemm_small_out_kernel, below)
+        g.x2 = h->x2; g.range_flag = h->range_flag;
+        out_fused = small_out_fits(g, d);
+        if (out_fused) g4 = g;
+        else if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
         }
     }
     {
@@ -325,7 +330,10 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.c1 = h->p_c1[step_idx];
             oa.sigma = h->p_sigma[step_idx];
         }
-        if (tail_fused) {
+        if (out_fused) {
+            const bool en = next_step >= 0 && !e_out;
+            HIPCHK(h, launch_gemm_small_out(g4, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, T, h->stream));
+        } else if (tail_fused) {
             const HalfPair& w3 = h->w16["concat3._layer.weight"];
             const HalfPair& w4 = h->w16["concat4._layer.weight"];
             TailArgs ta{sb.Xh, sb.Xl, w3.hi, w3.lo, w4.hi, w4.lo, W(h, "concat3._layer.bias"), W(h, "concat4._layer.bias"),

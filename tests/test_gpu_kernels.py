@@ -164,3 +164,25 @@ def test_small_launch_gemm_with_layernorm_tail_equals_its_unfused_pair(M, K):
     v = X.astype(np.float64) + A.astype(np.float64) @ W.astype(np.float64).T + b
     ref = (v - v.mean(1, keepdims=True)) / np.sqrt(v.var(1, keepdims=True) + 1e-5) * g + t
     assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("precision", ["f16mx", "f16x2", "f16x3"])
+@pytest.mark.parametrize("A,K,T,steps", [(5, 20, 12, 4), (3, 100, 8, 2), (2, 7, 6, 2), (1, 3, 5, 2)])
+def test_small_launch_tail_in_one_kernel_equals_its_unfused_pair(precision, A, K, T, steps):
+    """gemm_small_out_kernel (opt-in knob small_out = 1: concat4 + output layer + DDIM update + next embedding in ONE launch,
+    the gated Y4 tile in LDS) against the default chain (concat4's launch + out_ddim_kernel): every word of the velocities and
+    the positions, for pieces of 4 / 8 / 2 / 1 tokens (T = 12 / 8 / 6 / 5) and row counts that end inside a 64-row tile."""
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 2), joint=True, step=steps)
+    try:
+        g = torch.Generator().manual_seed(A * 1000 + K)
+        ctx = torch.randn([1, A, 256], generator=g).cuda()
+        x_T = torch.randn([1, K * A, T, 2], generator=g).cuda()
+        p0 = torch.randn([1, A, 2], generator=g).cuda()
+        ref = [t.clone() for t in eng.denoise(x_T, ctx, p0, precision=precision)]
+        eng.set_tuning("small_out", 1)
+        got = eng.denoise(x_T, ctx, p0, precision=precision)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        assert eng.erange_count() == 0
+    finally:
+        eng.close()
