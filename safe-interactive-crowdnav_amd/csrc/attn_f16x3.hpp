@@ -44,6 +44,31 @@ __device__ __forceinline__ void split8(const float* p, f16x8& hi, f16x8& lo) {
     lo = __builtin_bit_cast(f16x8, l);
 }
 
+// The cross-half exchange of a row statistic (lane l <-> lane l ^ 32) as ONE vector instruction: v_permlane32_swap leaves {x[l % 32]} and
+// {x[l % 32 + 32]} in both halves of its two operands - no LDS round trip (ds_bpermute behind __shfl_xor) in the middle of the softmax.
+// max(a, b) and a + b of the pair are what max(x, shfl_xor(x, 32)) and x + shfl_xor(x, 32) give, bit for bit (both commutative).
+// (Inline assembly: hipcc folds the two results of __builtin_amdgcn_permlane32_swap into one register - max(a, b) became a and a + b
+//  became a + a.  The instruction needs two wait states after a vector write of its operands.)
+__device__ __forceinline__ void half_swap(float x, float& lo_half, float& hi_half) {
+#ifdef JMID_ATT_SHFL      // (A/B: the ds_bpermute form)
+    lo_half = x;
+    hi_half = __shfl_xor(x, 32, 64);
+#else
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo_half = a;
+    hi_half = b;
+#endif
+}
+
+// The reference maximum of the online softmax is LAZY: it moves to the row's new tile maximum only when that exceeds it by more than
+// ATT_LAZY_TAU (log2 units), so P = 2^(s - m) can reach 2^8 - exact in fp32, far inside fp16 once rounded, and the row sum carries the
+// same factor: O / l is the same softmax.  The strict form max(m, tile max) rescales the O accumulators whenever ANY of a wave's 32
+// rows finds a new maximum - with 38 key tiles that is more than every second tile; the lazy one after the first tile only.  (For the
+// one-wave-per-SIMD kernel of attn_q64.hpp, whose O lives in the accumulation registers, a rescale is 192 instructions per block.)
+constexpr float ATT_LAZY_TAU = 8.0f;
+__device__ __forceinline__ float att_lazy_max(float m_run, float tile_max) { return tile_max > m_run + ATT_LAZY_TAU ? tile_max : m_run; }
+
 struct AttnHArgs {
     const half_t *Qhi, *Qlo, *Khi, *Klo, *Vthi, *Vtlo;
     half_t *Ohi, *Olo;
@@ -169,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void attn_f16x3_kernel(AttnHArgs a) {
             tmax = fmaxf(tmax, s);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
+        const float m_new = att_lazy_max(m_run, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
@@ -519,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             }
             if (P1) {
 #pragma unroll
-                for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i >> 1) * 1024 + vbase[i & 1]);
+                for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i & 3) * 1024 + vbase[i >> 2]);
             }
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
@@ -582,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
         if (PF && P1 && !MX) {
 #pragma unroll
-            for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i >> 1) * 1024 + vbase[i & 1]);
+            for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i & 3) * 1024 + vbase[i >> 2]);
         }
         ATT_STAMP(4)
         if (!(abl & 2)) {
@@ -594,10 +619,14 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         float tmax = sm[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sm[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
+        {
+            float x0, x1;
+            half_swap(tmax, x0, x1);
+            tmax = fmaxf(x0, x1);
+        }
+        const float m_new = att_lazy_max(m_run, tmax);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        // the running max of most rows stops moving after a few tiles: alpha == 1 exactly, skip the O rescale
+        // the reference max of most rows stops moving after the first tiles: alpha == 1 exactly, skip the O rescale
         const bool rescale = !__all(m_new == m_run);
         float psum = 0.f;
 #pragma unroll
@@ -605,7 +634,11 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             sm[r] = __builtin_amdgcn_exp2f(sm[r] - m_new);
             psum += sm[r];
         }
-        psum += __shfl_xor(psum, 32, 64);
+        {
+            float x0, x1;
+            half_swap(psum, x0, x1);
+            psum = x0 + x1;
+        }
         l_run = fmaf(l_run, alpha, psum);
         m_run = m_new;
         if (rescale) {
@@ -633,13 +666,15 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         }
         ATT_STAMP(5)
         if (PF && P1 && X2) {
+            // step i = 4 mf + n: the 16-key half mf outermost, so that the two matrix instructions of an accumulator are four apart instead of
+            // back to back (each accumulator still sees mf = 0, then mf = 1: the same bits)
             f16x8 vf[2 * NT];
 #pragma unroll
             for (int i = 0; i < PFD; ++i) vf[i] = vpre[i];
 #pragma unroll
-            for (int step = 0; step < 2 * NT; ++step) {
-                if (step + PFD < 2 * NT) vf[step + PFD] = *reinterpret_cast<const f16x8*>(Vh + ((step + PFD) >> 1) * 1024 + vbase[(step + PFD) & 1]);
-                ot[step >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[step], ph[step & 1], ot[step >> 1], 0, 0, 0);
+            for (int i = 0; i < 2 * NT; ++i) {
+                if (i + PFD < 2 * NT) vf[i + PFD] = *reinterpret_cast<const f16x8*>(Vh + ((i + PFD) & 3) * 1024 + vbase[(i + PFD) >> 2]);
+                ot[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i], ph[i >> 2], ot[i & 3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else
@@ -838,8 +873,18 @@ inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }
 
+#ifdef JMID_DIAGNOSTICS
+// experiment (knob "attn_q64" = 1, diagnostics flavour only): F16MX launches without a key split on the one-wave-per-SIMD kernel with two
+// query blocks per wave (attn_q64.hpp, included at the end of this file) - bit-identical, measured 7-14 % slower than the kernel below
+inline bool attn_q64_applies(const AttnHArgs& a, int nseq);
+inline hipError_t launch_attn_q64(const AttnHArgs& a_in, int nseq, hipStream_t st);
+#endif
+
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
     AttnHArgs a = a_in;
+#ifdef JMID_DIAGNOSTICS
+    if (head_dim == 128 && tune().attn_h_variant != 1 && attn_q64_applies(a, nseq)) return launch_attn_q64(a, nseq, st);
+#endif
     if (head_dim == 128 && tune().attn_h_variant != 1) {
         const int nqt = (a.S + 127) / 128;
         const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
@@ -881,3 +926,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 }
 
 }  // namespace jmid
+
+#ifdef JMID_DIAGNOSTICS
+#include "attn_q64.hpp"
+#endif

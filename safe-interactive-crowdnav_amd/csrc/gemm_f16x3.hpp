@@ -890,6 +890,63 @@ __device__ __forceinline__ void qk_staged_store(const GemmHArgs& g, f32x16 (&acc
     if (overflow) atomicOr(g.range_flag, 1);
 }
 
+// linear1 (bias + ReLU, ONE fp16 plane: the F16X2 / F16MX consumer takes A_hi only) the same way: the wave's 64-token x 128-column tile
+// of the TRANSPOSED product goes into its 16 KB of LDS with 8-byte writes and leaves as 16 bytes per lane - a wave-instruction then
+// writes 4 token rows x 4 panels x 64 bytes, i.e. eight whole 128-byte lines of the blocked plane (two consecutive rows of a panel
+// share a line), where the element-wise epilogue issued 128 two-byte store instructions per lane that each touched two half lines.
+// Same arithmetic as gemm_h_epilogue_impl<.., EPI_BIAS_RELU, OUT_SPLIT, X2 = true>: the same bits.
+__device__ __forceinline__ void h1_staged_store(const GemmHArgs& g, f32x16 (&acc)[2][4], int mw0, int nw0, half_t* wlds, int l31, int hi,
+                                                int lane) {
+    unsigned amax16 = 0;
+    auto lds_at = [&](int i, int j, int q) {
+        const int row = i * 32 + l31;
+        const int c = (8 * j + 2 * q + hi) ^ ((row & 15) << 1);       // 8-byte chunk of the row, swizzled in 16-byte units
+        return reinterpret_cast<f16x4*>(wlds + row * 128 + c * 4);
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        unsigned am = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(g.bias + nw0 + j * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bv[q]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaf(acc[i][j][4 * q + e], kWInv, bv[q][e]);
+                    v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                const Split4 sp = split_f32x4(v[0], v[1], v[2], v[3], am);
+                *lds_at(i, j, q) = __builtin_bit_cast(f16x4, sp.hi);
+            }
+        }
+        if (mw0 + i * 32 + l31 < g.M) {      // rows past M hold whatever the padding held: they stay out of the range check
+            const u16x2_s m = __builtin_elementwise_max(__builtin_bit_cast(u16x2_s, amax16), __builtin_bit_cast(u16x2_s, am));
+            amax16 = __builtin_bit_cast(unsigned, m);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // lane = (token row 4 t + lane / 16, 16-byte unit u = lane % 16 of its 256 bytes): panel nw0 / 32 + u / 4, chunk u % 4 of the panel
+    // row, swizzled as blk_index does.  The tile starts at row 0 or 64 of its 128-row block, so bits 2-3 of panel row 4 t + lane / 16
+    // are t & 3: the stored chunk is (u % 4) ^ (t & 3) - four lane offsets, and 4 rows = 256 bytes per step of t as an immediate
+    const int row0 = lane >> 4, u = lane & 15;
+    half_t* const dst = g.Chi + ((size_t)(mw0 >> 7) * (g.N >> 5) + (nw0 >> 5) + (u >> 2)) * 4096 + (size_t)((mw0 & 127) + row0) * 32;
+    const int cb[4] = {(u & 3) << 3, ((u & 3) ^ 1) << 3, ((u & 3) ^ 2) << 3, ((u & 3) ^ 3) << 3};
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        const int row = t * 4 + row0;
+        const f16x8 v8 = *reinterpret_cast<const f16x8*>(wlds + row * 128 + ((u ^ (row & 15)) << 3));
+        if (mw0 + row < g.M) store_stream(reinterpret_cast<f16x8*>(dst + t * 128 + cb[t & 3]), v8);
+    }
+    if (split_range_exceeded(amax16)) atomicOr(g.range_flag, 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // 256x256 LDS-DMA variant (N a multiple of 256: in_proj 1536, linear1 1024): 8 waves (4 along M x 2 along N), wave tile
 // 64 x 128 - possible since the product needs ONE accumulator set (128 VGPRs).  A third fewer operand bytes per FLOP
@@ -1144,7 +1201,7 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int EPI, int OUT, int WR, int WC, int WM, int WN, int NS, bool K8IMG = false>
-__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) void gemm_mx_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
+__global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2 && NS > 2) ? 1 : 2) void gemm_mx_kernel(GemmHArgs g, int ntm, int ntn, int stage_vt) {
     using C = MxCfg<WR, WC, WM, WN, NS>;
     constexpr int BM = C::BM, BN = C::BN, L = NS - 1;          // L tiles of look-ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1310,6 +1367,15 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2) ? 1 : 2) vo
             return;
         }
     }
+    if constexpr (EPI == EPI_BIAS_RELU && OUT == OUT_SPLIT && WM == 2 && WN == 4) {
+        // linear1 in the 64 x 128 wave tile: transposed product, the tile out through LDS in whole lines (block-uniform)
+        if (stage_vt & 16) {
+            kloop(std::true_type{});
+            __syncthreads();      // everybody is done with the operand rings
+            h1_staged_store(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
+            return;
+        }
+    }
     kloop(std::false_type{});
     if constexpr (OUT == OUT_QKV && WM == 2 && WN == 4) {
         if (g.vt_direct && g.hd == 128 && n0 >= 2 * g.d && (stage_vt & 1)) {
@@ -1333,7 +1399,7 @@ inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
     }
     const int vs = tune().vt_stage;     // 0 / 1: V^T and Q / K through LDS, 2: neither, 3: V^T only; bit 2: row-wise ConcatSquash epilogue
     hipLaunchKernelGGL((gemm_mx_kernel<EPI, OUT, WR, WC, WM, WN, NS, K8IMG>), dim3(ntm * ntn), dim3(C::NT), C::LDS_BYTES, st, g, ntm, ntn,
-                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0) |
+                       (vs == 2 ? 0 : (vs == 3 ? 1 : 3)) | (tune().csl_swap == 2 ? 0 : 4) | (tune().csl_swap == 3 ? 8 : 0) | (tune().h1_stage == 2 ? 0 : 16) |
                            ((tune().gemm_pn > 1 && ntn % tune().gemm_pn == 0 ? ntn / tune().gemm_pn : 0) << 8));
     return hipGetLastError();
 }
@@ -1341,6 +1407,9 @@ template <int EPI, int OUT> inline hipError_t launch_gemm_mx_64(const GemmHArgs&
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_128(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 2, 2, 4>(g, st); }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x128(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 2, 3>(g, st); }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x256(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 4, 3>(g, st); }
+// 128 x 256 with four waves (the 256 x 256 shape's wave tile), a two-stage ring: 80 KB of LDS and <= 256 registers, so TWO workgroups
+// share a CU - one's epilogue (stores through LDS, no MFMA) under the other's K loop
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_128x256(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 2, 4, 2>(g, st); }
 
 // the F16X2 shape rules (launch_gemm_h_mode below) for the fp8-correction kernels
 template <int EPI, int OUT>
@@ -1353,8 +1422,12 @@ inline hipError_t launch_gemm_mx(const GemmHArgs& g, hipStream_t st) {
     if constexpr (has_256x128)
         if (v == 4) return launch_gemm_mx_256x128<EPI, OUT>(g, st);
     if (v == 5) return launch_gemm_mx_64<EPI, OUT>(g, st);
-    if constexpr (EPI != EPI_CSL)
+    if constexpr (EPI != EPI_CSL) {
         if (v == 6 && g.N % 256 == 0) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
+#ifdef JMID_DIAGNOSTICS      // measured: 51 episodes in ONE chunk 119.95 -> 117.82 ms, as two chunks in flight (the default plan) 114.62 -> 115.63
+        if (v == 7 && g.N % 256 == 0) return launch_gemm_mx_128x256<EPI, OUT>(g, st);
+#endif
+    }
     if (big < 256) return launch_gemm_mx_64<EPI, OUT>(g, st);
     const long nb256 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     auto eff = [](long nb) { return (double)nb / (double)(((nb + 255) / 256) * 256); };

@@ -248,17 +248,53 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     float mean[WM], rstd[WM];
     // one row block (a literal at every call site: every accumulator index is a compile-time constant).  The residual chunks of
     // a row (16 + 8 bytes each) are requested together: one memory round trip per row block.
-    auto pass1 = [&](auto i_c) {
-        constexpr int i = decltype(i_c)::value;
-        const int row = m0 + i * 32 + l31;      // rows past M exist in the padded planes: loads need no guard
-        f16x8 xh[2 * WN];
-        i32x2 xb[2 * WN];
+    // The residual chunks of ALL row blocks are requested before the first is used: the K loop's operand registers are free here
+    // (96 registers of residual next to the 128 accumulators), and the four dependent memory round trips of a row-block-at-a-time
+    // epilogue (each waited to vmcnt(0) before the next block's loads went out) become one.
+    f16x8 xh_all[WM][2 * WN];
+    i32x2 xb_all[WM][2 * WN];
+    // Addresses: the tile is ONE 128-row block of the blocked planes (BM == 128) or half of one, so chunk (i, u) of a lane sits at
+    //   wave-uniform base + compile-time constant + a per-lane offset that does not depend on the row block
+    // (blk_index / blk8_index spelled out: panel = 128 rows x 32 columns, 64 resp. 32 bytes per row) - three 32-bit VGPR offsets
+    // instead of a 64-bit address per access (32 of them live across the statistics passes spilled).
+    const int wcu = __builtin_amdgcn_readfirstlane(wc);
+    const size_t pan0 = (size_t)(m0 >> 7) * (d >> 5) + (size_t)wcu * (WCOLS >> 5);      // first panel of this wave's columns
+    typedef __attribute__((address_space(1))) char gchar;
+    // a scalar-register base per 4 KB of constant offset (the rest fits the instruction's immediate): pinned, or hipcc folds the
+    // constants into 64-bit VECTOR addresses again.  (Through an integer: a pointer that passes an asm operand comes back generic.)
+    auto sbase = [](const void* p, size_t bytes) {
+        unsigned long long v = reinterpret_cast<unsigned long long>(p) + bytes;
+        asm volatile("" : "+s"(v));
+        return reinterpret_cast<gchar*>(v);
+    };
+    const size_t tile0 = pan0 * 4096 + (size_t)(m0 & 127) * 32;      // elements
+    gchar* xh_b[WN][WM / 2];      // [u >> 1][i >> 1]
+    gchar* x8_b[WN];              // [u >> 1]
+#pragma unroll
+    for (int q = 0; q < WN; ++q) {
+#pragma unroll
+        for (int ih = 0; ih < WM / 2; ++ih) xh_b[q][ih] = sbase(g.Xh, (tile0 + q * 4096 + ih * 2048) * sizeof(half_t));
+        x8_b[q] = sbase(g.Xl8, tile0 + q * 4096);
+    }
+    // the fp16 panels are XOR-swizzled in 16-byte chunks (common.hpp::blk_index: chunk c of row r at c ^ ((r >> 2) & 3), and bits 2-3 of
+    // the tile row are those of l31): chunk 2 (u & 1) + hi of a lane sits at one of TWO lane offsets, by the parity of u
+    const unsigned xoff8 = (unsigned)(l31 * 32 + hi * 8);
+    const int xsw = (l31 >> 2) & 3;
+    const unsigned xoffh[2] = {(unsigned)(l31 * 64 + ((hi ^ xsw) << 4)), (unsigned)(l31 * 64 + (((2 + hi) ^ xsw) << 4))};
+    auto xh_at = [&](int i, int u) { return xh_b[u >> 1][i >> 1] + (i & 1) * 2048 + xoffh[u & 1]; };
+    auto x8_at = [&](int i, int u) { return x8_b[u >> 1] + i * 1024 + (u & 1) * 16 + xoff8; };
+    auto load1 = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;       // rows past M exist in the padded planes: loads need no guard
 #pragma unroll
         for (int u = 0; u < 2 * WN; ++u) {
-            const int c0 = wc * WCOLS + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
-            xh[u] = *reinterpret_cast<const f16x8*>(g.Xh + blk_index(row, c0, d));
-            xb[u] = *reinterpret_cast<const i32x2*>(g.Xl8 + blk8_index(row, c0, d));
+            xh_all[i][u] = *reinterpret_cast<const __attribute__((address_space(1))) f16x8*>(xh_at(i, u));
+            xb_all[i][u] = *reinterpret_cast<const __attribute__((address_space(1))) i32x2*>(x8_at(i, u));
         }
+    };
+    auto pass1 = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        const f16x8 (&xh)[2 * WN] = xh_all[i];
+        const i32x2 (&xb)[2 * WN] = xb_all[i];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             float s = 0.f;
@@ -324,9 +360,9 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
                     o[e] = (acc[i][j][8 * p + e] - mean[i]) * rstd[i] * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
                 const Split4 s0 = split_f32x4(o[0], o[1], o[2], o[3], am), s1 = split_f32x4(o[4], o[5], o[6], o[7], am);
                 if (row < g.M) {
-                    *reinterpret_cast<i32x4*>(g.Xh + blk_index(row, c0, d)) = i32x4{s0.hi[0], s0.hi[1], s1.hi[0], s1.hi[1]};
+                    *reinterpret_cast<__attribute__((address_space(1))) i32x4*>(xh_at(i, 2 * j + p)) = i32x4{s0.hi[0], s0.hi[1], s1.hi[0], s1.hi[1]};
                     if (!g.no_lo_out)
-                        *reinterpret_cast<i32x2*>(g.Xl8 + blk8_index(row, c0, d)) =
+                        *reinterpret_cast<__attribute__((address_space(1))) i32x2*>(x8_at(i, 2 * j + p)) =
                             i32x2{bf8_of_f16x4(s0.lo[0], s0.lo[1]), bf8_of_f16x4(s1.lo[0], s1.lo[1])};
                 }
             }
@@ -339,7 +375,16 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
-    pass1(I0{}); pass1(I1{});
+    // (all four at once is 5 registers more than the budget of two waves per SIMD holds: three, and the fourth as soon as the
+    // first block's registers are free - its round trip passes under the statistics of blocks 1 and 2)
+    load1(I0{}); load1(I1{});
+    if constexpr (WM == 4) load1(I2{});
+    __builtin_amdgcn_sched_barrier(0);
+    pass1(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WM == 4) load1(I3{});
+    __builtin_amdgcn_sched_barrier(0);
+    pass1(I1{});
     if constexpr (WM == 4) { pass1(I2{}); pass1(I3{}); }
     __syncthreads();
     pass2(I0{}); pass2(I1{});

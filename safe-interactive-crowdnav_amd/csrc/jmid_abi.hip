@@ -414,7 +414,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     // every knob belongs to the handle (h->tune); none is process-wide
 #ifdef JMID_DIAGNOSTICS
     static const Knob knobs[] = {
-        {"gemm_h_variant", &Tuning::gemm_h_variant, 0, 6},     // 0 auto, 1..6 force a tile variant of the split GEMM
+        {"gemm_h_variant", &Tuning::gemm_h_variant, 0, 7},     // 0 auto, 1..7 force a tile variant of the split GEMM
         {"attn_pack", &Tuning::attn_pack, 0, 1},               // 0: one short sequence per wave, 1: packed (iMID)
         {"fuse_embed", &Tuning::fuse_embed, 0, 1},             // 0: separate embed_kernel at the start of every step
         {"bystander_lds", &Tuning::bystander_lds, 0, 160 * 1024},   // unused dynamic LDS requested by row-wise kernels
@@ -432,6 +432,8 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_pf", &Tuning::attn_pf, 0, 2},
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
+        {"h1_stage", &Tuning::h1_stage, 0, 2},
+        {"attn_q64", &Tuning::attn_q64, 0, 1},
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
         {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches

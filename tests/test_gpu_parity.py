@@ -474,7 +474,62 @@ def test_vt_through_lds_is_bit_identical_to_direct_stores(precision):
     assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
 
 
-KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
+def test_linear1_tile_through_lds_is_bit_identical_to_the_elementwise_epilogue():
+    """F16MX linear1 in the 64 x 128 wave tile (256 x 256 and 128 x 256 workgroup shapes): bias + ReLU + the fp16 plane written
+    through LDS in whole lines (h1_staged_store, transposed product) against the element-wise epilogue ("h1_stage" = 2), on a
+    batch that ends in a partial row tile (19 x 1200 % 256 != 0) - nn.TransformerEncoderLayer's linear1 + activation as built
+    at MID/models/diffusion.py:161-166."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(4)
+    E, A, K, T = 19, 5, 20, 12
+    g = torch.Generator().manual_seed(31)
+    ctx = torch.randn([E, A, 256], generator=g).cuda()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    out = {}
+    try:
+        for variant in (0, 7):
+            for stage in (0, 2):
+                eng.set_tuning("gemm_h_variant", variant)
+                eng.set_tuning("h1_stage", stage)
+                out[(variant, stage)] = eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy()
+    finally:
+        eng.set_tuning("h1_stage", 0)
+        eng.set_tuning("gemm_h_variant", 0)
+    for k in ((0, 2), (7, 0), (7, 2)):
+        np.testing.assert_array_equal(out[k], out[(0, 0)])
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True)
+    assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
+
+
+@pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (16, 3, 7, 5), (14, 2, 9, 7)])
+def test_attention_q64_equals_the_two_wave_kernel(E, A, K, T):
+    """The one-wave-per-SIMD attention experiment (attn_q64.hpp, knob "attn_q64" = 1: two query blocks per wave, the softmax of tile t
+    in the gaps of the matrix instructions of tile t + 1) performs attn_f16x3_dma_kernel's operations in its order: bit-identical
+    outputs on S = 1200 (37.5 key tiles, the last wave of a sequence half empty), S = 105 and S = 126 (one 256-query workgroup per
+    sequence and head with idle waves, a partial last key tile) - nn.MultiheadAttention inside the encoder layers of
+    MID/models/diffusion.py:161-166."""
+    eng, w = get_engine(256, 23, True)
+    eng.set_step(4)
+    g = torch.Generator().manual_seed(13 + E)
+    ctx = torch.randn([E, A, 256], generator=g).cuda()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    out = {}
+    try:
+        for v in (0, 1):
+            eng.set_tuning("attn_q64", v)
+            eng.set_tuning("attn_nsplit", 1)        # (the experiment has no key split: both arms unsplit)
+            out[v] = eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy()
+    finally:
+        eng.set_tuning("attn_q64", 0)
+        eng.set_tuning("attn_nsplit", 0)
+    np.testing.assert_array_equal(out[1], out[0])
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True)
+    assert ade(out[0][:2], ref.numpy()) <= ADE_GATE
+
+
+KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7)), ("h1_stage", (2,)), ("attn_q64", (1,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
                ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("tail_fuse", (1,)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
                ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,))]
