@@ -306,6 +306,9 @@ template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool 
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     args_now_each(a, nqt, abl, trace);
+#ifndef JMID_ABLATIONS
+    if (!TRACE) abl = 0;      // (the launch helpers pass 0 then: said here, every `abl` test below folds away)
+#endif
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, tstart = 0;
     unsigned long long rt0 = 0;
     if (TRACE) {
@@ -447,9 +450,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         offK8 = offK8_last;
         offV = offV_last;
     };
-    auto issue_one = [&](int kt, int i) {
+    auto issue_one = [&](int kt, int i, int stage) {
         if (i >= 6 && X2) return;   // F16X2: the V^T lo plane is neither written by the QKV epilogue nor read here
-        half_t* st = lds + (kt & 1) * ATT_STAGE + wid_s * 512;
+        half_t* st = lds + stage * ATT_STAGE + wid_s * 512;
         const char* src;
         half_t* dst;
         if (MX && (i == 2 || i == 3)) {
@@ -468,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    auto issue = [&](int kt) {
+    auto issue = [&](int kt, int stage) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) issue_one(kt, i);
+        for (int i = 0; i < 8; ++i) issue_one(kt, i, stage);
     };
     // fragment read offsets (halfs), kept to a handful of registers:
     //   K : row l31, chunk (2ks+hi) ^ (l31&15)                        -> kbase + (((2ks+hi) ^ kx) << 3)
@@ -488,10 +491,15 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     {
     if (kt_begin == last_tile) use_last_offsets();
     ATT_STAMP(7)   // arguments, tile arithmetic, Q loads requested
-    issue(kt_begin);
+    issue(kt_begin, 0);
     q_finish();
     ATT_STAMP(0)   // prologue: Q loads, first DMA issue
-    for (int kt = kt_begin; kt < ntiles; ++kt) {
+    // One key tile.  STG (the ring stage of tile kt = the parity of kt - kt_begin) and MORE (tile kt + 1 exists: its copies go out during
+    // this tile) are compile-time: every LDS address of the tile is then the lane's precomputed offset + an IMMEDIATE (13 vector adds
+    // per tile with a run-time stage base), and the eight `if (more)` around the copies are gone from the instruction stream.
+    auto tile_body = [&](const int kt, auto stg_c, auto more_c) {
+        constexpr int STG = decltype(stg_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;
         if (kt + 1 == last_tile) use_last_offsets();       // (uniform: the copies of tile kt + 1 go out during this iteration)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of tile kt has landed
         ATT_STAMP(1)
@@ -500,14 +508,14 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         ATT_STAMP(2)
         // the DMA of tile kt+1 is issued one wave-instruction per QK^T step below, behind that step's MFMAs: a burst of
         // 8 right here stalls the wave ~850 cycles per tile in the CU's address path (tools/attn_trace.hip)
-        const bool more = kt + 1 < ntiles && !(abl & 1);    // abl: timing ablations (diagnostics only)
-        if (more && (abl & 16)) issue(kt + 1);
+        const bool more = MORE && !(abl & 1);    // abl: timing ablations (diagnostics only; zero otherwise, see the top of the kernel)
+        if (more && (abl & 16)) issue(kt + 1, 1 - STG);
         ATT_STAMP(3)
         if (wave_idle) {       // S = 1200: 2 of the 40 waves of a (sequence, head) - 5 % of the kernel's MFMA work
-            if (more && !(abl & 16)) issue(kt + 1);
-            continue;
+            if (more && !(abl & 16)) issue(kt + 1, 1 - STG);
+            return;
         }
-        const half_t* Kh = lds + ((abl & 1) ? 0 : (kt & 1)) * ATT_STAGE;
+        const half_t* Kh = lds + ((abl & 1) ? 0 : STG) * ATT_STAGE;
         const half_t* Kl = Kh + ATT_KPLANE;
         const half_t* Vh = Kh + 2 * ATT_KPLANE;
         const half_t* Vl = Vh + ATT_VPLANE;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                     k8f[blk][1][0] = k8read(1, blk, 0); k8f[blk][1][1] = k8read(1, blk, 1);
                 }
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qh[ks], sm, 0, 0, 0);
-                if (more && !(abl & 16)) issue_one(kt + 1, ks);
+                if (more && !(abl & 16)) issue_one(kt + 1, ks, 1 - STG);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (P1) {
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 f16x8 kh_n = kh_c;
                 if (ks + 1 < NKS) kh_n = *reinterpret_cast<const f16x8*>(Kh + kbase + (((2 * (ks + 1) + hi) ^ kx) << 3));
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
-                if (more && !(abl & 16)) issue_one(kt + 1, ks);
+                if (more && !(abl & 16)) issue_one(kt + 1, ks, 1 - STG);
                 __builtin_amdgcn_sched_barrier(0);
                 kh_c = kh_n;
             }
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, qh[ks], sm, 0, 0, 0);
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh_c, ql[MX ? 0 : ks], sm, 0, 0, 0);
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl_c, qh[ks], sm, 0, 0, 0);
-                if (more && !(abl & 16)) issue_one(kt + 1, ks);
+                if (more && !(abl & 16)) issue_one(kt + 1, ks, 1 - STG);
                 __builtin_amdgcn_sched_barrier(0);
                 kh_c = kh_n;
                 kl_c = kl_n;
@@ -701,6 +709,21 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             }
         }
         ATT_STAMP(6)
+    };
+    {
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        int kt = kt_begin;
+        for (; kt + 2 < ntiles; kt += 2) {
+            tile_body(kt, S0{}, std::true_type{});
+            tile_body(kt + 1, S1{}, std::true_type{});
+        }
+        if (kt + 1 < ntiles) {
+            tile_body(kt, S0{}, std::true_type{});
+            tile_body(kt + 1, S1{}, std::false_type{});
+        } else {
+            tile_body(kt, S0{}, std::false_type{});
+        }
     }
     }
     if (TRACE) {

@@ -111,7 +111,7 @@ struct Tuning {
     int ln_fuse = 0;         // 0 auto, 1 always, 2 never: fused GEMM + residual + LayerNorm
     int ln_rows = 0;         // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
     int bystander_lds = 0;   // dynamic LDS the small row-wise kernels request although they use none
-    int gemm_h_variant = 0;  // 0 auto, 1..6 force a tile variant of the split-fp16 GEMM
+    int gemm_h_variant = 0;  // 0 auto, 1..6 force a tile variant of the split-fp16 GEMM (diagnostics: 7 = 128 x 256 two per CU, 8 = 256 x 256 with a three-stage ring)
     int gemm_ng = 0;         // N-tiles per L2 group of the 256x128 GEMM (0 = auto)
     int no_vt_direct = 0;    // 1: V row-major + v_transpose_kernel even when the fused V^T epilogue applies
     int attn_h_variant = 0;  // 0 auto (DMA when head_dim == 128), 1 = register-staged, 2 = DMA

@@ -1221,6 +1221,9 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2 && NS > 2) ?
     const int nk = g.K / GEMMH_BK;                     // even: K is a multiple of 64
     const int nrb = (g.M + 127) / 128;
     // DMA sources: piece p of the A (W) tile is C::PIECE halfs of the blocked panel image(s) of this tile's rows
+    // wave-uniform bases (scalar registers) + ONE 32-bit lane offset for every copy: a thread's 16 bytes of a piece are at tid * 16 in
+    // each of them (per-thread 64-bit pointers cost a 64-bit vector add and a v_readfirstlane pair per copy: 26 of the K loop's ~100
+    // vector instructions per k64 block)
     const half_t* srcA[C::NA];
     const half_t* srcW[C::NW];
 #pragma unroll
@@ -1228,28 +1231,35 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2 && NS > 2) ?
         const int h0 = (m0 & 127) * 32 + p * C::PIECE;                   // halfs from the start of the tile's first panel image
         int rb = m0 / 128 + h0 / 4096;
         rb = rb < nrb ? rb : nrb - 1;
-        srcA[p] = g.Ahi + (size_t)rb * nk * 4096 + h0 % 4096 + tid * 8;
+        srcA[p] = g.Ahi + (size_t)rb * nk * 4096 + h0 % 4096;
     }
 #pragma unroll
     for (int p = 0; p < C::NW; ++p) {
         const int h0 = (n0 & 127) * 32 + p * C::PIECE;
-        srcW[p] = g.Whi + (size_t)(n0 / 128 + h0 / 4096) * nk * 4096 + h0 % 4096 + tid * 8;
+        srcW[p] = g.Whi + (size_t)(n0 / 128 + h0 / 4096) * nk * 4096 + h0 % 4096;
     }
-    const unsigned char* src8 = g.W8 + (size_t)(n0 / 32) * 2048 + tid * 16;
+    const unsigned char* src8 = g.W8 + (size_t)(n0 / 32) * 2048;
+    unsigned lane_off = (unsigned)tid * 16u;      // (re-pinned once per K tile in top(): zero-extended and hoisted out of the loop as a 64-bit pair it defeats the scalar-base form of the copies)
     const size_t w8_kstride = (size_t)(g.N / 32) * 2048;
     unsigned char* lds8 = lds_raw + C::W8_OFF;
-    auto dma16 = [](const void* s, void* d) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    // (the uniform part is pinned in scalar registers - through an integer, a pointer that passes an asm operand comes back generic:
+    //  left alone, hipcc hoists base + lane offset out of the K loop as a 64-bit vector and adds the tile stride to THAT per copy)
+    auto dma16 = [&](const void* s, void* d) {
+        unsigned long long u = reinterpret_cast<unsigned long long>(s);
+        asm volatile("" : "+s"(u));
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
     };
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);      // (the LDS destination of a copy is a scalar: M0)
     auto issue = [&](int kt, int stg) {                // NA + NW wave-instructions, + N8 for an odd tile
-        half_t* st = lds + stg * C::STAGE + wid * 512;
+        half_t* st = lds + stg * C::STAGE + wid_s * 512;
 #pragma unroll
         for (int p = 0; p < C::NA; ++p) dma16(srcA[p] + (size_t)kt * 4096, st + p * C::PIECE);
 #pragma unroll
         for (int p = 0; p < C::NW; ++p) dma16(srcW[p] + (size_t)kt * 4096, st + C::A_HALFS + p * C::PIECE);
         if (kt & 1) {                                  // the fp8 image of k64 block kt / 2, into buffer (kt / 2) & 1 (last read L + 1 tiles ago)
             const unsigned char* s8 = src8 + (size_t)(kt >> 1) * w8_kstride;
-            unsigned char* d8 = lds8 + ((kt >> 1) & 1) * C::W8_BYTES + wid * 1024;
+            unsigned char* d8 = lds8 + ((kt >> 1) & 1) * C::W8_BYTES + wid_s * 1024;
 #pragma unroll
             for (int q = 0; q < C::N8; ++q) dma16(s8 + q * C::NT * 16, d8 + q * C::NT * 16);
         }
@@ -1312,6 +1322,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2 && NS > 2) ?
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(lane_off));
         if (kt + L < nk) issue(kt + L, stg_next);
     };
     auto kloop = [&](auto swap_c) {
@@ -1406,7 +1417,11 @@ inline hipError_t launch_gemm_mx_cfg(const GemmHArgs& g, hipStream_t st) {
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_64(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 1, 1, 4>(g, st); }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_128(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 2, 2, 4>(g, st); }
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x128(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 2, 3>(g, st); }
-template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x256(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 4, 3>(g, st); }
+// 256 x 256: a TWO-stage ring - the K loop's body is two tiles, so every tile's stage is a constant and its fragment reads are lane offset +
+// immediate (29 vector address instructions per k64 block less than with three stages, whose extra tile of look-ahead measured neutral in
+// round 2); a 51-episode call 113.4 -> 112.8 ms, 256 episodes 573 -> 560 ms.  Diagnostics variant 8: the three-stage ring, for the A/B.
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x256(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 4, 2>(g, st); }
+template <int EPI, int OUT> inline hipError_t launch_gemm_mx_256x256_ns3(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 4, 2, 2, 4, 3>(g, st); }
 // 128 x 256 with four waves (the 256 x 256 shape's wave tile), a two-stage ring: 80 KB of LDS and <= 256 registers, so TWO workgroups
 // share a CU - one's epilogue (stores through LDS, no MFMA) under the other's K loop
 template <int EPI, int OUT> inline hipError_t launch_gemm_mx_128x256(const GemmHArgs& g, hipStream_t st) { return launch_gemm_mx_cfg<EPI, OUT, 2, 2, 2, 4, 2>(g, st); }
@@ -1426,6 +1441,7 @@ inline hipError_t launch_gemm_mx(const GemmHArgs& g, hipStream_t st) {
         if (v == 6 && g.N % 256 == 0) return launch_gemm_mx_256x256<EPI, OUT>(g, st);
 #ifdef JMID_DIAGNOSTICS      // measured: 51 episodes in ONE chunk 119.95 -> 117.82 ms, as two chunks in flight (the default plan) 114.62 -> 115.63
         if (v == 7 && g.N % 256 == 0) return launch_gemm_mx_128x256<EPI, OUT>(g, st);
+        if (v == 8 && g.N % 256 == 0) return launch_gemm_mx_256x256_ns3<EPI, OUT>(g, st);
 #endif
     }
     if (big < 256) return launch_gemm_mx_64<EPI, OUT>(g, st);

@@ -112,23 +112,32 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
         if (tid < 128) *reinterpret_cast<f32x4*>(par + 2 * GLN_BN + tid * 4) = pc;
     }
 
-    auto dma16 = [](const void* s, void* dd) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s, (__attribute__((address_space(3))) void*)dd, 16, 0, 0);
+    // every copy: wave-uniform base (pinned in scalar registers, through an integer) + ONE 32-bit lane offset, lane * 16 bytes - per-thread
+    // 64-bit pointers cost a 64-bit vector add per copy and a v_readfirstlane pair for its LDS destination (29 of the K loop's ~170 vector
+    // instructions per k64 block).  The lane offset is re-pinned once per k64 block: zero-extended and hoisted out of the loop as a 64-bit
+    // pair it defeats the scalar-base form.
+    const int wcs = __builtin_amdgcn_readfirstlane(wc);
+    unsigned lane_off = (unsigned)lane * 16u;
+    auto dma16 = [&](const void* s, void* dd) {
+        unsigned long long u = reinterpret_cast<unsigned long long>(s);
+        asm volatile("" : "+s"(u));
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
+                                         (__attribute__((address_space(3))) void*)dd, 16, 0, 0);
     };
     // A: this tile's rows of a k32 panel image (a whole 8 KB image for 128 rows, its 4 KB half for 64); one wave-instruction per
     // wave and tile.  Past the end the last tile / slice is copied again into its own stage (identical bytes: harmless), which
     // keeps the number of DMA instructions in flight at every wait a compile-time constant.
-    const half_t* a_src = WM == 4 ? g.Ahi + (size_t)tm * nk * 4096 + tid * 8
-                                  : g.Ahi + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + tid * 8;
+    const half_t* a_src = WM == 4 ? g.Ahi + (size_t)tm * nk * 4096 + wcs * 512
+                                  : g.Ahi + (size_t)(tm >> 1) * nk * 4096 + (tm & 1) * 2048 + wcs * 512;
     auto issueA = [&](int ka) {
         const int kk = ka < nk ? ka : nk - 1;
-        dma16(a_src + (size_t)kk * 4096, lds + C::A_OFF + (kk % C::NSA) * C::A_STAGE + wc * 512);
+        dma16(a_src + (size_t)kk * 4096, lds + C::A_OFF + (kk % C::NSA) * C::A_STAGE + wcs * 512);
     };
     // W_hi: the wave's own 32 WN rows of a k16 slice (WN wave-instructions of 1 KB): wave-private, no workgroup barrier
-    const half_t* w_src = g.W16hi + (size_t)(wc * WCOLS) * 16 + lane * 8;
+    const half_t* w_src = g.W16hi + (size_t)(wcs * WCOLS) * 16;
     auto issueW = [&](int s) {
         const int ss = s < nsteps ? s : nsteps - 1;
-        half_t* st = lds + (ss % C::NSW) * C::W_STAGE + wc * (WCOLS * 16);
+        half_t* st = lds + (ss % C::NSW) * C::W_STAGE + wcs * (WCOLS * 16);
 #pragma unroll
         for (int q = 0; q < WN; ++q) dma16(w_src + ((size_t)ss * GLN_BN + q * 32) * 16, st + q * 512);
     };
@@ -147,8 +156,8 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
         }
     };
     // W8_LDS: the wave's WN blocks x 2 pieces of 1 KB in image order (lane-linear copies); fragment reads pick the permuted row
-    unsigned char* w8buf = lds_raw + C::W8_OFF + wc * (WN * 2048);
-    const unsigned char* w8dma = g.W8 + (size_t)(wc * WN) * 2048 + lane * 16;
+    unsigned char* w8buf = lds_raw + C::W8_OFF + wcs * (WN * 2048);
+    const unsigned char* w8dma = g.W8 + (size_t)(wcs * WN) * 2048;
     const int nkb = g.K / 64;
     auto issueW8 = [&](int kb) {
         const int kk = kb < nkb ? kb : nkb - 1;
@@ -233,6 +242,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
         __builtin_amdgcn_sched_barrier(0);
     };
     for (int s = 0; s < nsteps; s += 4) {
+        asm volatile("" : "+v"(lane_off));
         step(s, std::integral_constant<int, 0>{});
         step(s + 1, std::integral_constant<int, 1>{});
         step(s + 2, std::integral_constant<int, 2>{});

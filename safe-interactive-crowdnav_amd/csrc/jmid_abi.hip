@@ -414,7 +414,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
     // every knob belongs to the handle (h->tune); none is process-wide
 #ifdef JMID_DIAGNOSTICS
     static const Knob knobs[] = {
-        {"gemm_h_variant", &Tuning::gemm_h_variant, 0, 7},     // 0 auto, 1..7 force a tile variant of the split GEMM
+        {"gemm_h_variant", &Tuning::gemm_h_variant, 0, 8},     // 0 auto, 1..8 force a tile variant of the split GEMM
         {"attn_pack", &Tuning::attn_pack, 0, 1},               // 0: one short sequence per wave, 1: packed (iMID)
         {"fuse_embed", &Tuning::fuse_embed, 0, 1},             // 0: separate embed_kernel at the start of every step
         {"bystander_lds", &Tuning::bystander_lds, 0, 160 * 1024},   // unused dynamic LDS requested by row-wise kernels

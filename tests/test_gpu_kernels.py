@@ -89,7 +89,7 @@ def test_add_layernorm_matches_torch(engine, M):
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f16x2", "f16mx"])
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("M,N,K", [(700, 512, 512), (513, 256, 64), (1025, 1536, 512)])
 def test_f16x3_gemm_variants_agree_bitwise(engine, variant, M, N, K, precision):
     """Every tile configuration of the split-fp16 GEMM accumulates k in the same order with the same three MFMAs per

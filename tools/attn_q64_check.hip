@@ -1,8 +1,9 @@
 // attn_q64_kernel (one wave per SIMD, two query blocks) against attn_f16x3_dma_kernel<MX, P1, PF> (two waves per SIMD) on the same
 // random planes: bitwise comparison of the O_hi plane, then the time per launch of each.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops -w \
-//         -I safe-interactive-crowdnav_amd/csrc -I include tools/attn_q64_check.hip -o build/attn_q64_check
-//   build/attn_q64_check [nseq = 51] [S = 1200] [reps = 20]
+//         -DJMID_DIAGNOSTICS -I safe-interactive-crowdnav_amd/csrc -I include tools/attn_q64_check.hip -o build/attn_q64_check
+//   build/attn_q64_check [nseq = 51] [S = 1200] [reps = 20]      (-DJMID_DIAGNOSTICS: the experiment is compiled in that flavour only;
+//   -DAQ_TRACE: cycles per phase of the one-wave kernel; AQ_TRACE_TWO_WAVE=1 in the environment: of the two-wave kernel)
 #include "attn_f16x3.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -92,6 +93,34 @@ int main(int argc, char** argv) {
         printf("  total %.1f cycles per tile\n", tot / nw / nt);
     }
 #endif
+    if (getenv("AQ_TRACE_TWO_WAVE")) {      // cycles per phase of the two-wave kernel's key-tile loop (its TRACE instantiation, F16MX operands)
+        const int nqt = (S + 127) / 128, nblk = nqt * nhead * nseq;
+        unsigned long long* tr;
+        CK(hipMalloc(&tr, (size_t)nblk * 4 * 12 * 8));
+        const auto kern = &attn_f16x3_dma_kernel<true, true, true, false, true, true>;
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS));
+        AttnHArgs a{dQ, reinterpret_cast<half_t*>(dQ8), dK, nullptr, dV, nullptr, dO[0], nullptr, S, Spad, d, nhead, 1.f, flag, 1, nullptr, nullptr, 1,
+                    dK8h, dK8l, dQ8};
+        for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), ATT_DMA_LDS, st, a, nqt, 0, tr);
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> t((size_t)nblk * 4 * 12);
+        CK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+        const char* names[8] = {"prologue", "wait vmcnt", "barrier", "issue DMA", "QK^T mfma", "softmax", "PV mfma", "setup"};
+        const int idx[8] = {0, 1, 2, 3, 4, 5, 6, 9};
+        double sum[8] = {0};
+        size_t nw = 0;
+        for (size_t w = 0; w < (size_t)nblk * 4; ++w) {
+            if (!t[w * 12 + 4]) continue;      // idle wave
+            ++nw;
+            for (int i = 0; i < 8; ++i) sum[i] += (double)t[w * 12 + idx[i]];
+        }
+        const int nt = (S + 31) / 32;
+        double tot = 0;
+        for (int i = 1; i < 7; ++i) tot += sum[i];
+        printf("two-wave kernel, traced: %zu active waves; cycles per wave per key tile (32 queries):\n", nw);
+        for (int i = 1; i < 7; ++i) printf("  %-12s %8.1f  %5.1f %%\n", names[i], sum[i] / nw / nt, 100 * sum[i] / tot);
+        printf("  total %.1f per tile;  setup %.0f + prologue %.0f cycles per wave\n", tot / nw / nt, sum[7] / nw, sum[0] / nw);
+    }
     std::vector<half_t> o0(oelems), o1(oelems);
     CK(hipMemcpy(o0.data(), dO[0], oelems * 2, hipMemcpyDeviceToHost));
     CK(hipMemcpy(o1.data(), dO[1], oelems * 2, hipMemcpyDeviceToHost));
