@@ -973,19 +973,25 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
     const int nk = g.K / GEMMH_BK;
     const int nrb = (g.M + 127) / 128;
     const int rb0 = 2 * tm, rb1 = (2 * tm + 1 < nrb) ? 2 * tm + 1 : nrb - 1;
+    // copies: wave-uniform base (pinned in scalar registers, through an integer) + ONE 32-bit lane offset, tid * 16 bytes - eight
+    // per-thread 64-bit pointers cost 16 registers, a 64-bit vector add per copy and a v_readfirstlane pair for its LDS destination
     const half_t* src[8];
-    src[0] = g.Ahi + (size_t)rb0 * nk * 4096 + tid * 8;
-    src[1] = g.Ahi + (size_t)rb1 * nk * 4096 + tid * 8;
-    src[2] = g.Alo + (size_t)rb0 * nk * 4096 + tid * 8;
-    src[3] = g.Alo + (size_t)rb1 * nk * 4096 + tid * 8;
-    src[4] = g.Whi + (size_t)(2 * tn) * nk * 4096 + tid * 8;
-    src[5] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
-    src[6] = g.Wlo + (size_t)(2 * tn) * nk * 4096 + tid * 8;
-    src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096 + tid * 8;
-    auto issue_one = [&](int kt, int i) {
-        half_t* st = lds + (kt & 1) * DMA3_STAGE + wid * 512;
+    src[0] = g.Ahi + (size_t)rb0 * nk * 4096;
+    src[1] = g.Ahi + (size_t)rb1 * nk * 4096;
+    src[2] = g.Alo + (size_t)rb0 * nk * 4096;
+    src[3] = g.Alo + (size_t)rb1 * nk * 4096;
+    src[4] = g.Whi + (size_t)(2 * tn) * nk * 4096;
+    src[5] = g.Whi + (size_t)(2 * tn + 1) * nk * 4096;
+    src[6] = g.Wlo + (size_t)(2 * tn) * nk * 4096;
+    src[7] = g.Wlo + (size_t)(2 * tn + 1) * nk * 4096;
+    unsigned lane_off = (unsigned)tid * 16u;      // (re-pinned once per K tile: hoisted out of the loop as a 64-bit pair it defeats the scalar-base form)
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    auto issue_one = [&](int kt, int i, int stage) {
+        half_t* st = lds + stage * DMA3_STAGE + wid_s * 512;
         if ((i == 2 || i == 3) && X2) return;   // F16X2: the A lo images stay out of LDS
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kt * 4096),
+        unsigned long long u = reinterpret_cast<unsigned long long>(src[i] + (size_t)kt * 4096);
+        asm volatile("" : "+s"(u));
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                          (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
     };
     f32x16 acc[WM][WN];
@@ -1015,16 +1021,19 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
     // same values: a product does not care which operand it came in as)
     if (OUT == OUT_QKV && (stage_vt & 2) && n0 < 2 * g.d && g.d % 128 == 0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) issue_one(0, i);
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int i = 0; i < 8; ++i) issue_one(0, i, 0);
+        // one K tile with its ring stage as a constant (two tiles per trip below): every fragment read is lane offset + immediate
+        auto ktile = [&](const int kt, auto stg_c) {
+            constexpr int STG = decltype(stg_c)::value;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            asm volatile("" : "+v"(lane_off));
             if (kt + 1 < nk) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) issue_one(kt + 1, i);
+                for (int i = 0; i < 8; ++i) issue_one(kt + 1, i, 1 - STG);
             }
-            const half_t* st = lds + (kt & 1) * DMA3_STAGE;
+            const half_t* st = lds + STG * DMA3_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 f16x8 ah[WM], al[WM], wh[WN], wl[WN];
@@ -1053,23 +1062,33 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
                     for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        {
+            int kt = 0;
+            for (; kt + 1 < nk; kt += 2) {
+                ktile(kt, std::integral_constant<int, 0>{});
+                ktile(kt + 1, std::integral_constant<int, 1>{});
+            }
+            if (kt < nk) ktile(kt, std::integral_constant<int, 0>{});
         }
         __syncthreads();      // everybody is done with the operand rings (all DMAs landed: vmcnt(0) in the last K-tile)
         qk_staged_store(g, acc, m0 + wr * 64, n0 + wc * 128, lds + wid * 8192, l31, hi, lane);
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) issue_one(0, i);
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int i = 0; i < 8; ++i) issue_one(0, i, 0);
+    auto ktile2 = [&](const int kt, auto stg_c) {
+        constexpr int STG = decltype(stg_c)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(lane_off));
         const bool more = kt + 1 < nk && !burst;
         if (burst && kt + 1 < nk) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) issue_one(kt + 1, i);
+            for (int i = 0; i < 8; ++i) issue_one(kt + 1, i, 1 - STG);
         }
-        const half_t* st = lds + (kt & 1) * DMA3_STAGE;
+        const half_t* st = lds + STG * DMA3_STAGE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f16x8 ah[WM], al[WM], wh[WN], wl[WN];
@@ -1090,16 +1109,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
             if (more) {
-                issue_one(kt + 1, 4 * ks + 0);
-                issue_one(kt + 1, 4 * ks + 1);
+                issue_one(kt + 1, 4 * ks + 0, 1 - STG);
+                issue_one(kt + 1, 4 * ks + 1, 1 - STG);
             }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
             if (more) {
-                issue_one(kt + 1, 4 * ks + 2);
-                issue_one(kt + 1, 4 * ks + 3);
+                issue_one(kt + 1, 4 * ks + 2, 1 - STG);
+                issue_one(kt + 1, 4 * ks + 3, 1 - STG);
             }
             if (!X2)
 #pragma unroll
@@ -1108,6 +1127,14 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    {
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            ktile2(kt, std::integral_constant<int, 0>{});
+            ktile2(kt + 1, std::integral_constant<int, 1>{});
+        }
+        if (kt < nk) ktile2(kt, std::integral_constant<int, 0>{});
     }
     if (OUT == OUT_QKV) {
         // a V tile (block-uniform: n0 is a multiple of 256 and d_model of 128): V^T goes out through LDS in full rows

@@ -358,26 +358,30 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
     const int m0 = tm * GLN2_BM;
     const int nk = g.K / 32, nsteps = 2 * nk;
 
-    const half_t* a_hi = g.Ahi + (size_t)tm * nk * 4096 + tid * 8;
-    const half_t* a_lo = g.Alo + (size_t)tm * nk * 4096 + tid * 8;
+    // copies: wave-uniform base (pinned in scalar registers, through an integer) + ONE 32-bit lane offset, lane * 16 bytes (per-thread
+    // 64-bit pointers cost a 64-bit vector add per copy and a v_readfirstlane pair for its LDS destination)
+    const int wcs = __builtin_amdgcn_readfirstlane(wid);
+    unsigned lane_off = (unsigned)lane * 16u;      // (re-pinned per pair of steps below)
+    auto dma16 = [&](const void* sp, void* dd) {
+        unsigned long long u = reinterpret_cast<unsigned long long>(sp);
+        asm volatile("" : "+s"(u));
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
+                                         (__attribute__((address_space(3))) void*)dd, 16, 0, 0);
+    };
+    const half_t* a_hi = g.Ahi + (size_t)tm * nk * 4096 + wcs * 512;
+    const half_t* a_lo = g.Alo + (size_t)tm * nk * 4096 + wcs * 512;
     auto issueA = [&](int ka) {     // two wave-instructions; past the end: the last tile again into its own stage
         const int kk = ka < nk ? ka : nk - 1;       // (identical bytes: harmless while that stage is being read)
-        half_t* dst = lds + GLN2_A_OFF + (kk % 3) * GLN2_A_STAGE + wid * 512;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_hi + (size_t)kk * 4096),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        half_t* dst = lds + GLN2_A_OFF + (kk % 3) * GLN2_A_STAGE + wcs * 512;
+        dma16(a_hi + (size_t)kk * 4096, dst);
         if (X2) return;             // F16X2: A_lo is neither copied nor read (one instruction per tile: vmcnt 5 below)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_lo + (size_t)kk * 4096),
-                                         (__attribute__((address_space(3))) void*)(dst + 4096), 16, 0, 0);
+        dma16(a_lo + (size_t)kk * 4096, dst + 4096);
     };
     auto issueW = [&](int s, int stage) {
-        half_t* st = lds + GLN_W_OFF + stage * GLN_W_STAGE + wc * 64 * 16;
+        half_t* st = lds + GLN_W_OFF + stage * GLN_W_STAGE + wcs * 64 * 16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const half_t* src = ((q >> 1) ? g.W16lo : g.W16hi) + ((size_t)s * GLN_BN + wc * 64 + (q & 1) * 32) * 16 + lane * 8;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + (q >> 1) * GLN_BN * 16 + (q & 1) * 512),
-                                             16, 0, 0);
-        }
+        for (int q = 0; q < 4; ++q)
+            dma16(((q >> 1) ? g.W16lo : g.W16hi) + ((size_t)s * GLN_BN + wcs * 64 + (q & 1) * 32) * 16, st + (q >> 1) * GLN_BN * 16 + (q & 1) * 512);
     };
     f32x16 acc[WM][WN];
 #pragma unroll
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
         if (ks == 1) ast = ast == 2 ? 0 : ast + 1;
     };
     for (int s = 0; s < nsteps; s += 2) {
+        asm volatile("" : "+v"(lane_off));
         step(s, 0);
         step(s + 1, 1);
     }

@@ -322,10 +322,16 @@ __device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char*
     // DMA sources of stage 0, one per wave-instruction of a stage ("round"), in the fixed order A_hi [A_lo] W_hi [W_lo] [W8];
     // round q of a plane moves bytes [q ROUND, (q + 1) ROUND) of the plane's stage image = its 2 KB k32 sub-tiles back to back
     constexpr int IAL = C::RA, IWH = C::A_PLANES * C::RA, IWL = IWH + C::RW, I8 = IWH + C::W_PLANES * C::RW;
+    // (wave-uniform: a wave's 1 KB slice of a round lies inside one k32 sub-tile; the lane's 16 bytes are at lane * 16 in every one of
+    //  them, so a copy is scalar base + ONE 32-bit lane offset - a per-thread 64-bit pointer costs a 64-bit vector add per copy and a
+    //  v_readfirstlane for its LDS destination, on a wave that is alone on its SIMD and issues ~one instruction per five cycles)
+    const int wid_s = __builtin_amdgcn_readfirstlane(wid);
+    unsigned lane_off = (unsigned)lane * 16u;
     const char* src[C::NR];
     auto plane_src = [&](const void* base, int tile, auto rows_c, int q) {
         constexpr int ROWS = decltype(rows_c)::value, SUB = ROWS * 64;
-        const int o = q * C::ROUND + tid * 16, sub = o / SUB, within = o - sub * SUB;
+        static_assert(SUB % 1024 == 0, "a wave's slice of a round stays inside one sub-tile");
+        const int o = q * C::ROUND + wid_s * 1024, sub = o / SUB, within = o - sub * SUB;
         const size_t panel = ROWS == 128 ? (size_t)tile * nk : (size_t)(tile >> 1) * nk;
         return reinterpret_cast<const char*>(base) + (panel + sub) * 8192 + (ROWS == 128 ? 0 : (tile & 1) * 4096) + within;
     };
@@ -344,7 +350,7 @@ __device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char*
 #pragma unroll
         for (int q = 0; q < C::R8; ++q)      // block q / R8B of the stage, round q % R8B of its image
             src[I8 + q] = reinterpret_cast<const char*>(g.W8) + (size_t)(q / C::R8B) * w8_kstride + (size_t)(n0 / 32) * 2048 +
-                          (q % C::R8B) * C::ROUND + tid * 16;
+                          (q % C::R8B) * C::ROUND + wid_s * 1024;
     }
     // destination of round r inside a stage (compile-time) + this wave's 1 KB slice of the round
     auto dst_of = [&](int r) {
@@ -356,12 +362,14 @@ __device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char*
     };
     auto issue = [&](int st_idx, int slot) {
         if (SM_ABL(16)) return;
-        unsigned char* st = lds_raw + slot * C::STAGE + wid * 1024;
+        unsigned char* st = lds_raw + slot * C::STAGE + wid_s * 1024;
+        asm volatile("" : "+v"(lane_off));      // (once per stage: hoisted out of the loop as a 64-bit pair it defeats the scalar-base form)
 #pragma unroll
         for (int r = 0; r < C::NR; ++r) {
             const bool is8 = MX && r >= I8;
-            const char* sp = src[r] + (is8 ? (size_t)st_idx * KB * w8_kstride : (size_t)st_idx * KB * 16384);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+            unsigned long long u = reinterpret_cast<unsigned long long>(src[r] + (is8 ? (size_t)st_idx * KB * w8_kstride : (size_t)st_idx * KB * 16384));
+            asm volatile("" : "+s"(u));          // (through an integer: a pointer that passes an asm operand comes back generic)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                              (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 0);
         }
     };
