@@ -104,6 +104,17 @@ __device__ __forceinline__ void args_now(const T& a) {
 template <typename... T>
 __device__ __forceinline__ void args_now_each(const T&... t) { (args_now(t), ...); }
 
+// A wave-uniform 64-bit value (an address) pinned in a scalar register pair.  LDS-DMA copies and epilogue accesses address memory as
+// scalar base + 32-bit lane offset; left alone, hipcc re-associates base + offset into a per-lane 64-bit vector address (a 64-bit vector
+// add per access, two registers per pointer kept).  Through an integer: a pointer that passes an asm operand comes back generic (flat).
+// The readfirstlanes fold away where the compiler can prove the value uniform, and keep the constraint legal where it cannot.
+__device__ __forceinline__ unsigned long long pin_uniform(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    unsigned long long u = ((unsigned long long)hi << 32) | lo;
+    asm volatile("" : "+s"(u));
+    return u;
+}
+
 // Tuning knobs (jmid_set_tuning).  They belong to a handle: every entry point of the C ABI installs its handle's
 // set for the duration of the call (TuneScope, thread-local), the launch helpers read it through tune().
 struct Tuning {

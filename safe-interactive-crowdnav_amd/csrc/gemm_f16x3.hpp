@@ -989,8 +989,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f16x3_dma256x256_kernel(GemmHArgs
     auto issue_one = [&](int kt, int i, int stage) {
         half_t* st = lds + stage * DMA3_STAGE + wid_s * 512;
         if ((i == 2 || i == 3) && X2) return;   // F16X2: the A lo images stay out of LDS
-        unsigned long long u = reinterpret_cast<unsigned long long>(src[i] + (size_t)kt * 4096);
-        asm volatile("" : "+s"(u));
+        const unsigned long long u = pin_uniform(reinterpret_cast<unsigned long long>(src[i] + (size_t)kt * 4096));
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                          (__attribute__((address_space(3))) void*)(st + i * 4096), 16, 0, 0);
     };
@@ -1272,8 +1271,7 @@ __global__ __launch_bounds__(64 * WR * WC, (WR * WC == 4 && WM == 2 && NS > 2) ?
     // (the uniform part is pinned in scalar registers - through an integer, a pointer that passes an asm operand comes back generic:
     //  left alone, hipcc hoists base + lane offset out of the K loop as a 64-bit vector and adds the tile stride to THAT per copy)
     auto dma16 = [&](const void* s, void* d) {
-        unsigned long long u = reinterpret_cast<unsigned long long>(s);
-        asm volatile("" : "+s"(u));
+        const unsigned long long u = pin_uniform(reinterpret_cast<unsigned long long>(s));
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                          (__attribute__((address_space(3))) void*)d, 16, 0, 0);
     };

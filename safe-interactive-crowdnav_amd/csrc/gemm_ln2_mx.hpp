@@ -119,8 +119,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     const int wcs = __builtin_amdgcn_readfirstlane(wc);
     unsigned lane_off = (unsigned)lane * 16u;
     auto dma16 = [&](const void* s, void* dd) {
-        unsigned long long u = reinterpret_cast<unsigned long long>(s);
-        asm volatile("" : "+s"(u));
+        const unsigned long long u = pin_uniform(reinterpret_cast<unsigned long long>(s));
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                          (__attribute__((address_space(3))) void*)dd, 16, 0, 0);
     };
@@ -273,9 +272,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     // a scalar-register base per 4 KB of constant offset (the rest fits the instruction's immediate): pinned, or hipcc folds the
     // constants into 64-bit VECTOR addresses again.  (Through an integer: a pointer that passes an asm operand comes back generic.)
     auto sbase = [](const void* p, size_t bytes) {
-        unsigned long long v = reinterpret_cast<unsigned long long>(p) + bytes;
-        asm volatile("" : "+s"(v));
-        return reinterpret_cast<gchar*>(v);
+        return reinterpret_cast<gchar*>(pin_uniform(reinterpret_cast<unsigned long long>(p) + bytes));
     };
     const size_t tile0 = pan0 * 4096 + (size_t)(m0 & 127) * 32;      // elements
     gchar* xh_b[WN][WM / 2];      // [u >> 1][i >> 1]

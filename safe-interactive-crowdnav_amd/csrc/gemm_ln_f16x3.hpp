@@ -363,8 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ln128_f16x3_kernel(GemmLnArgs g, 
     const int wcs = __builtin_amdgcn_readfirstlane(wid);
     unsigned lane_off = (unsigned)lane * 16u;      // (re-pinned per pair of steps below)
     auto dma16 = [&](const void* sp, void* dd) {
-        unsigned long long u = reinterpret_cast<unsigned long long>(sp);
-        asm volatile("" : "+s"(u));
+        const unsigned long long u = pin_uniform(reinterpret_cast<unsigned long long>(sp));
         __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                          (__attribute__((address_space(3))) void*)dd, 16, 0, 0);
     };

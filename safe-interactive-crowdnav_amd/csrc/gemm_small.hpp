@@ -367,8 +367,7 @@ __device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char*
 #pragma unroll
         for (int r = 0; r < C::NR; ++r) {
             const bool is8 = MX && r >= I8;
-            unsigned long long u = reinterpret_cast<unsigned long long>(src[r] + (is8 ? (size_t)st_idx * KB * w8_kstride : (size_t)st_idx * KB * 16384));
-            asm volatile("" : "+s"(u));          // (through an integer: a pointer that passes an asm operand comes back generic)
+            const unsigned long long u = pin_uniform(reinterpret_cast<unsigned long long>(src[r] + (is8 ? (size_t)st_idx * KB * w8_kstride : (size_t)st_idx * KB * 16384)));
             __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
                                              (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 0);
         }
@@ -527,7 +526,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
     args_now_each(g, ntm, ntn, gw, flags, mper, mgw);      // (four dependent scalar-cache misses in front of the first copy otherwise)
 #ifdef JMID_SMALL_TRACE
     unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;     // (loaded before the ring starts: vmcnt stays the ring's)
-    asm volatile("" : "+s"(sm_trace_p));
+    sm_trace_p = reinterpret_cast<unsigned long long*>(pin_uniform(reinterpret_cast<unsigned long long>(sm_trace_p)));
     if (SM_ABL(64)) return;          // ablation: the launch alone
 #endif
     SM_STAMP(0);
