@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         if (kt + 1 < ntiles) {
             tile_body(kt, S0{}, std::true_type{});
             tile_body(kt + 1, S1{}, std::false_type{});
-        } else {
+        } else if (kt < ntiles) {      // (an empty key range - more splits than key tiles, a forced "attn_nsplit" - runs no tile)
             tile_body(kt, S0{}, std::false_type{});
         }
     }
