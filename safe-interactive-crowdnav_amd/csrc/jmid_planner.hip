@@ -392,14 +392,23 @@ int auto_chunk(const jmid_ctx* h, int E, int tokens_per_episode) {
 std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
     int c = h->chunk_eps > 0 ? std::min(E, h->chunk_eps) : auto_chunk(h, E, tokens_per_episode);
     if (h->chunk_eps <= 0 && h->lanes >= 2 && E >= 2 && tune().graph != 1) {     // (a captured loop is a one-chunk call)
-        // Two chunks in flight want two chunks.  A batch that fits one chunk is split in two halves: its kernels do not fill the
-        // chip, and two half-size launches side by side finish 5-13 % sooner than one (4 / 8 / 16 / 32 / 48 episodes: 23.3 ->
-        // 22.2, 36.0 -> 31.8, 60.9 -> 58.0, 111.3 -> 97.2, 140.5 -> 132.5 ms per call; tools/small_batch_lanes.py).  In
-        // JMID_PREC_F16MX larger batches run in half-size chunks too (2 x 26 episodes in flight instead of 51 + 51: -1.2 ... -2.6 %
-        // on 104 / 256 / 512 episodes; F16X2 -0.4 %, F16X3 +0.9 %: left alone; tools/chunk26_check.py).  The split-KV factor of a
-        // call does not depend on its chunk plan (run_network), so neither do the results.
-        if (E <= c) c = (E + 1) / 2;
-        else if (h->mx) c = (c + 1) / 2;
+        // Two chunks in flight want an EVEN number of chunks of equal size.  A batch that fits one chunk is split in two halves: its
+        // kernels do not fill the chip, and two half-size launches side by side finish 5-13 % sooner than one (4 / 8 / 16 / 32 / 48
+        // episodes: 23.3 -> 22.2, 36.0 -> 31.8, 60.9 -> 58.0, 111.3 -> 97.2, 140.5 -> 132.5 ms per call; tools/small_batch_lanes.py).
+        // A larger batch runs as the smallest even number of chunks that fit, balanced: 256 episodes = 4 x 43 + 2 x 42 instead of
+        // 52 + 4 x 51 (an odd count leaves the last chunk alone on the chip) or, in JMID_PREC_F16MX until round 4, 10 x 26 -
+        // with the leaner kernels of that round's last session the half-size chunks lost their edge: 256 episodes 564 -> 540 ms,
+        // 512: 1142 -> 1086, 160: 356 -> 347, 104: 230 -> 224 (F16MX); F16X2 / F16X3 within 0.4 % either way (tools/chunk_fine.py).
+        // The split-KV factor of a call does not depend on its chunk plan (run_network), so neither do the results.
+        if (E <= c) {
+            c = (E + 1) / 2;
+        } else {
+            int n = (E + c - 1) / c;
+            n += n & 1;
+            std::vector<int> sizes(n, E / n);
+            for (int i = 0; i < E % n; ++i) sizes[i] += 1;
+            return sizes;
+        }
     }
     std::vector<int> sizes(E / c, c);
     const int tail = E % c;

@@ -3,7 +3,7 @@ LDS-DMA GEMM / attention kernels, fused GEMM + LayerNorm, split-KV attention + c
 
   * cfg3: 256 episodes x N=5 x K=20 x H=12, 50 DDIM steps - at least one episode of EVERY chunk of the call is held
     against the oracle (first / last episode of each chunk, incl. the one-episode tail a forced chunk of 51 leaves),
-    and the whole 256-episode result is bit-identical for every chunking (automatic 52+4x51, 51 -> 5x51+1, 17, 64).
+    and the whole 256-episode result is bit-identical for every chunking (automatic 4x43+2x42, 51 -> 5x51+1, 17, 64).
   * cfg4: one dense scene N=25, K=64 -> ONE attention sequence of 19 200 tokens (600 q-tile workgroups: the
     efficiency branch of attn_pick_nsplit + attn_combine_kernel at 19 200 keys), 5 DDIM steps against the oracle.
 
@@ -54,8 +54,9 @@ def cfg3():
     p0 = torch.from_numpy(syn["p0"])
     x_T = torch.stack([torch.randn([K * A, T, 2], generator=torch.Generator().manual_seed(e)) for e in range(E)])
     ctx = eng.encode(x_st.cuda(), nbr.cuda(), em.cuda()).view(E, A, -1)
-    # one episode on each side of every chunk boundary of the automatic plan (52 + 4 x 51) and of the forced plan
-    # 5 x 51 + 1: every chunk of either plan holds at least one checked episode, the one-episode tail included
+    # one episode on each side of every chunk boundary of the one-lane plan (52 + 4 x 51) and of the forced plan 5 x 51 + 1: every
+    # chunk of either plan - and of the automatic two-lane plan 4 x 43 + 2 x 42 - holds at least one checked episode, the
+    # one-episode tail included
     picks = [0, 50, 51, 52, 102, 103, 153, 154, 204, 205, 255]
     _cpu_threads()
     ref = {}
@@ -76,7 +77,7 @@ def test_cfg3_every_chunk_matches_oracle_and_chunking_is_bit_invariant(cfg3, pre
     eng, picks = cfg3["eng"], cfg3["picks"]
     outs = {}
     try:
-        for chunk in (0, 51, 17, 64):        # 52 + 4 x 51 | 5 x 51 + 1 (one-episode tail) | 15 x 17 + 1 | 4 x 64
+        for chunk in (0, 51, 17, 64):        # 4 x 43 + 2 x 42 | 5 x 51 + 1 (one-episode tail) | 15 x 17 + 1 | 4 x 64
             eng.set_chunk_episodes(chunk)
             _, pos = eng.denoise(cfg3["x_T"], cfg3["ctx"], cfg3["p0"], dt=0.25, precision=precision, want_vel=False)
             outs[chunk] = pos.cpu().numpy()
@@ -166,8 +167,8 @@ def cfg5():
     p0, gt = torch.from_numpy(syn["p0"]), torch.from_numpy(syn["gt"])
     x_T = torch.stack([torch.randn([K * A, T, 2], generator=torch.Generator().manual_seed(rank * E + e)) for e in range(E)])
     ctx = eng.encode(x_st.cuda(), nbr.cuda(), em.cuda()).view(E, A, -1)
-    # one episode inside each chunk of every plan the modes use (512 = 2 x 52 + 8 x 51 one lane; half-size chunks of 26 in
-    # F16MX: every 26-episode stretch holds a pick) + the last episode
+    # one episode inside each chunk of every plan in use (512 = 2 x 52 + 8 x 51 one lane; 8 x 43 + 4 x 42 two lanes: every
+    # 26-episode stretch holds a pick) + the last episode
     picks = list(range(12, 512, 25)) + [511]
     _cpu_threads()
     ref = {}
