@@ -107,8 +107,14 @@ __device__ __forceinline__ void args_now_each(const T&... t) { (args_now(t), ...
 // A wave-uniform 64-bit value (an address) pinned in a scalar register pair.  LDS-DMA copies and epilogue accesses address memory as
 // scalar base + 32-bit lane offset; left alone, hipcc re-associates base + offset into a per-lane 64-bit vector address (a 64-bit vector
 // add per access, two registers per pointer kept).  Through an integer: a pointer that passes an asm operand comes back generic (flat).
-// The readfirstlanes fold away where the compiler can prove the value uniform, and keep the constraint legal where it cannot.
+// The value must be PROVABLY uniform (kernel arguments, blockIdx, readfirstlane results): anything else fails to compile ("illegal
+// VGPR to SGPR copy"), which is the check one wants.  pin_uniform_rfl: the same behind explicit v_readfirstlane, for values the
+// compiler cannot prove uniform (they cost vector registers: the F16X3 256 x 256 GEMM spilled 17 with it).
 __device__ __forceinline__ unsigned long long pin_uniform(unsigned long long v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ unsigned long long pin_uniform_rfl(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     unsigned long long u = ((unsigned long long)hi << 32) | lo;
     asm volatile("" : "+s"(u));

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
     args_now_each(g, ntm, ntn, gw, flags, mper, mgw);      // (four dependent scalar-cache misses in front of the first copy otherwise)
 #ifdef JMID_SMALL_TRACE
     unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;     // (loaded before the ring starts: vmcnt stays the ring's)
-    sm_trace_p = reinterpret_cast<unsigned long long*>(pin_uniform(reinterpret_cast<unsigned long long>(sm_trace_p)));
+    sm_trace_p = reinterpret_cast<unsigned long long*>(pin_uniform_rfl(reinterpret_cast<unsigned long long>(sm_trace_p)));
     if (SM_ABL(64)) return;          // ablation: the launch alone
 #endif
     SM_STAMP(0);
