@@ -16,11 +16,16 @@ throughput target and the roofline are quoted on; the single-scene case (configs
 and reported under "single_scene".
 
 Precision modes.  `value` is the mode named by --precision (default f16mx: fp16 activation x split-fp16 weight with the
-weight-lo correction term as one bf8 x bf8 MFMA per k64, the mode the drop-in predictor class `HumanTrajectoryForecasterSim`
-runs by default; >= the bf16 BASELINE.json names).  Every mode listed in --modes (default "f16mx,f16x2,f16x3": f16x2 = the
+weight-lo correction term as one bf8 x bf8 MFMA per k64; >= the bf16 BASELINE.json names; an OPT-IN of the drop-in predictor
+class `HumanTrajectoryForecasterSim`, whose own default is the fp32-class mode f16x3 - the line carries both:
+`config.precision` and `config.class_default_precision`, and `modes.f16x3` is the class default's number).  Every mode listed in --modes (default "f16mx,f16x2,f16x3": f16x2 = the
 same products with the correction term in fp16, f16x3 = fp32-class three-term products) gets THE SAME measurement - W warm-up steps, one untimed profiling step, K timed steps between
 barriers, parity against the oracle on the same episodes - and is reported under `modes[<name>]` with the same keys;
-the top-level keys are a copy of modes[--precision].  Prints ONE JSON line on rank 0.
+the top-level keys are a copy of modes[--precision].
+
+Output.  Rank 0 prints ONE COMPACT JSON line (< 4 KB: the contract keys, `roofline`, `cpu_baseline`, `parity`, one short row per
+mode) as the last line of stdout; everything else (notes, sources, per-kernel tables, forecaster_e2e, worker scaling, the full
+per-mode blocks) goes to the file named by `detail` in that line (--detail, default bench_detail.json next to this script).
 """
 import argparse
 import hashlib
@@ -127,6 +132,94 @@ def sustained_mfma_tflops():
         return {"tflops": tf, "shader_clock_mhz": mhz}
     except Exception:
         return None
+
+
+DTYPE_SHORT = {"f32": "f32", "f16x3": "f32-class (fp16 hi+lo split operands, 3 MFMAs per product, fp32 accumulate)",
+               "f16x2": "fp16 activations x split-fp16 weights (2 MFMAs per product), fp32 accumulate",
+               "f16mx": "fp16 activations x split-fp16 weights (weight-lo term as one bf8 MFMA per k64), fp32 accumulate"}
+COMPACT_LIMIT = 4000            # bytes; the driver parses the last stdout line and lost the 20 KB one of round 4
+
+
+def _r(v, nd=4):
+    return round(float(v), nd) if isinstance(v, (int, float)) and not isinstance(v, bool) else v
+
+
+def compact_line(full, detail_path):
+    """The ONE stdout line: contract keys + roofline + cpu_baseline + parity + one short row per mode.  `full` is the long result
+    (written to `detail_path`); nothing here is computed, only selected."""
+    from safe_interactive_crowdnav_amd.forecaster import DEFAULTS as CLASS_DEFAULTS
+    cfg = full["config"]
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline") if k in full}
+    out["dtype"] = DTYPE_SHORT.get(cfg["precision"], full["dtype"])
+    out["data"] = full["data"]
+    out["config"] = {"workload": cfg["workload_short"], "episodes_per_gpu": cfg["episodes_per_gpu"],
+                     "total_episodes": cfg["total_episodes"], "humans": cfg["humans"], "samples": cfg["samples"],
+                     "horizon": cfg["horizon"], "denoise_steps": cfg["denoise_steps"], "net": cfg["net"],
+                     "precision": cfg["precision"], "class_default_precision": CLASS_DEFAULTS["precision"],
+                     "lanes": cfg["lanes"], "dist_backend": cfg["dist_backend"]}
+    out["ranks_seen"] = full.get("ranks_seen")
+    out["gather_ms"] = full.get("gather_ms")
+    pr = full.get("per_rank_ms_per_step")
+    if pr:
+        out["per_rank_ms_per_step"] = {"min": pr["min"], "max": pr["max"]}
+
+    def roof_of(r):
+        if not r:
+            return None
+        mb = r.get("mfma_busy") or {}
+        ts = r.get("traffic_source") or {}
+        return {"bound": r["bound"], "kernel": r["kernel"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                "frac": r["frac"], "frac_of_sustained": r.get("frac_of_sustained"), "traffic": _r(r.get("traffic"), 0),
+                "traffic_measured_in_run": ts.get("measured_in_run"), "flops_per_launch": r.get("flops_per_launch"),
+                "avg_launch_ms": r["avg_launch_ms"], "launches": r["launches"],
+                "mfma_busy": _r(mb.get("dominant_kernel")), "mfma_busy_whole_call": _r(mb.get("whole_call")),
+                "path_achieved": r.get("path_achieved"), "path_frac": r.get("path_frac"),
+                "sustained_peak": r.get("peak_sustained_random_operands")}
+    if full.get("roofline"):
+        out["roofline"] = roof_of(full["roofline"])
+    if full.get("hbm"):
+        h = full["hbm"]
+        out["hbm"] = {"bytes_per_trajectory": h["bytes_per_trajectory"], "GBps": h["GBps"], "peak_GBps": h["peak_GBps"],
+                      "frac": h["frac"], "measured_in_run": (h.get("source") or {}).get("measured_in_run")}
+    if full.get("cpu_baseline"):
+        c = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                               "processes": c["processes"], "threads_per_process": c["threads_per_process"],
+                               "hardware_threads": c["hardware_threads"], "host_physical_cores": c["host_physical_cores"],
+                               "sample": c["sample_short"], "note": c["cores_short"]}
+    if full.get("parity"):
+        q = full["parity"]
+        out["parity"] = {"mean_ADE_vs_oracle_m": _r(q["mean_ADE_vs_oracle_m"], 9), "gate_m": q["gate_m"], "pass": q["pass"],
+                         "episodes": q["episodes"], "precision": q["precision"]}
+    modes = {}
+    for m, v in full.get("modes", {}).items():
+        row = {"value": v["value"], "ms_per_step": v["ms_per_step"]}
+        if v.get("roofline"):
+            row["roofline_frac"] = v["roofline"]["frac"]
+            row["avg_launch_ms"] = v["roofline"]["avg_launch_ms"]
+        if v.get("parity"):
+            row["mean_ADE_vs_oracle_m"] = _r(v["parity"]["mean_ADE_vs_oracle_m"], 9)
+            row["pass"] = v["parity"]["pass"]
+        modes[m] = row
+    out["modes"] = modes
+    if full.get("single_scene"):
+        ss = full["single_scene"]
+        out["single_scene"] = {"workload": "cfg2: 1 scene", "ms_per_call": ss["ms_per_call"], "traj_per_s": ss["traj_per_s"],
+                               "modes": {m: t["ms_per_call"] for m, t in ss["modes"].items()}}
+    if full.get("sweep_metrics"):
+        out["sweep_episodes"] = full["sweep_metrics"]["episodes"]
+    out["detail"] = os.path.relpath(detail_path, REPO) if os.path.abspath(detail_path).startswith(REPO) else detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    for drop in ("single_scene", "hbm", "per_rank_ms_per_step"):          # never exceed the limit: shed the optional blocks
+        if len(line) <= COMPACT_LIMIT:
+            break
+        out.pop(drop, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    json.loads(line)
+    return line
+
 
 
 _T0 = time.perf_counter()
@@ -304,6 +397,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not re-run one 51-episode call under rocprofv3 --pmc after the timed region (roofline.traffic / mfma_busy "
                          "then come from the committed profiles/ summary, labelled as such) and do not run the sustained-MFMA probe")
+    ap.add_argument("--detail", default=os.path.join(REPO, "bench_detail.json"),
+                    help="file the full (long) result goes to; the stdout line stays compact and names this path")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run every collective even with one rank (exercises the RCCL calls "
                          "of the N > 1 path on a one-GPU box)")
@@ -580,6 +675,9 @@ def main():
                                 f"cfg5-style strong scaling: {total_eps} episodes in total, block-partitioned over {world} GPU(s) "
                                 f"({E} on rank 0)") + f" x N={N} x K={K} x H={H}, {steps50} DDIM steps, "
                                f"{args.net.upper()} (encoder_dim 256, 3 layers), random-init weights",
+                   "workload_short": (f"{args.workload}: {E} episodes/GPU" if scaling == "weak" else
+                                      f"strong: {total_eps} episodes over {world} GPU(s)") +
+                                     f" x N={N} x K={K} x H={H}, {steps50} DDIM steps, {args.net.upper()}",
                    "episodes_per_gpu": E, "total_episodes": total_eps, "humans": N, "samples": K, "horizon": H, "denoise_steps": steps50,
                    "net": args.net, "precision": args.precision, "lanes": args.lanes, "scenes": args.scenes,
                    "dist_backend": args.dist_backend if use_dist else None},
@@ -702,6 +800,10 @@ def main():
                                "cores_note": "cores = processes x threads_per_process actually used by the timed sample (the best "
                                              "of the measured splits); host_physical_cores / hardware_threads = what the host has",
                                "worker_scaling_jobs_per_s": {str(k): v for k, v in scaling.items()},
+                               "sample_short": f"{ne} episodes ({ne * A * K} trajectories) of the same workload, {cpu_s:.1f} s wall",
+                               "cores_short": (f"oracle/jmid_oracle.py (torch-CPU fp32): best measured split {nproc} processes x {threads} "
+                                               f"threads; more workers side by side did not raise the rate on this host "
+                                               f"(tried {sorted(scaling)}: {nproc} was fastest)"),
                                "sample": f"{ne} episodes of the same workload ({ne * A * K} trajectories, {cpu_s:.1f} s wall; "
                                          f"oracle/jmid_oracle.py, torch-CPU fp32, {nproc} processes x {threads} threads)"}
         for m in modes:
@@ -709,7 +811,14 @@ def main():
             results[m]["parity"] = {"mean_ADE_vs_oracle_m": ade, "gate_m": 1e-4, "episodes": ne, "pass": ade <= 1e-4,
                                     "episode_ids": pick, "precision": m}
         out["parity"] = results[args.precision]["parity"]
-    print(json.dumps(out))
+    with open(args.detail, "w") as fh:
+        json.dump(out, fh, indent=1)
+    log(f"full result -> {args.detail} ({os.path.getsize(args.detail)} bytes)")
+    for m in modes:
+        rr = results[m].get("roofline") or {}
+        log(f"[{m}] {results[m]['value']} traj/s, {results[m]['ms_per_step']} ms/step, {rr.get('kernel')} {rr.get('avg_launch_ms')} ms/launch "
+            f"= {rr.get('frac')} of peak, parity {results[m].get('parity', {}).get('mean_ADE_vs_oracle_m')}")
+    print(compact_line(out, args.detail), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -255,6 +255,9 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
 /* X <- LayerNorm(X + Y) * gamma + beta, eps = 1e-5 (post-norm residual of nn.TransformerEncoderLayer). */
 int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float* Y, const float* gamma,
                            const float* beta);
+/* The chunk plan run_network would use for a call of E episodes of `tokens_per_episode` tokens (host logic only, no device):
+ * writes at most `cap` chunk sizes to `sizes`, returns the number of chunks (or a negative JMID_E* code). */
+int jmid_dbg_plan_chunks(int net_kind, int nhead, int lanes, int chunk_episodes, int E, int tokens_per_episode, int* sizes, int cap);
 #endif /* JMID_DIAGNOSTICS */
 
 #pragma GCC visibility pop

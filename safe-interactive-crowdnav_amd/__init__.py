@@ -11,6 +11,7 @@ __version__ = "0.1.0"
 
 
 REFERENCE_MODULE = "sicnav_diffusion.JMID.mid_sim_wrapper"
+_STAND_INS = []          # names of the empty parent packages install() registered (uninstall() removes them again)
 
 
 def install(**defaults):
@@ -41,10 +42,15 @@ def install(**defaults):
         if mod is None:
             try:
                 mod = importlib.import_module(name)
-            except Exception:          # the reference tree is not on sys.path: a stand-in package
+            except ModuleNotFoundError as ex:
+                # only "this very package is not importable" (the reference tree is not on sys.path) gets a stand-in; a reference
+                # package whose own __init__ fails (a missing einops / acados dependency) must surface, not be masked
+                if ex.name != name:
+                    raise
                 mod = types.ModuleType(name)
                 mod.__path__ = []
                 sys.modules[name] = mod
+                _STAND_INS.append(name)
         if parent is not None and not hasattr(parent, parts[i - 1]):
             setattr(parent, parts[i - 1], mod)
         parent = mod
@@ -64,3 +70,12 @@ def uninstall():
         parent = sys.modules.get(REFERENCE_MODULE.rsplit(".", 1)[0])
         if parent is not None and getattr(parent, "mid_sim_wrapper", None) is forecaster:
             delattr(parent, "mid_sim_wrapper")
+    while _STAND_INS:                  # the empty parents of a tree-less install: the real packages must be importable afterwards
+        name = _STAND_INS.pop()
+        mod = sys.modules.get(name)
+        if mod is not None and getattr(mod, "__path__", None) == []:
+            del sys.modules[name]
+            head, _, leaf = name.rpartition(".")
+            par = sys.modules.get(head) if head else None
+            if par is not None and getattr(par, leaf, None) is mod:
+                delattr(par, leaf)

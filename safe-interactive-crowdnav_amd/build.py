@@ -14,13 +14,22 @@ LIB_DIAG = os.path.join(CSRC, "libjmid_hip_diag.so")
 SOURCES = ["jmid_abi.hip", "jmid_weights.hip", "jmid_planner.hip", "jmid_profile.hip", "jmid_diag.hip"]
 
 
-def _newest_source_mtime() -> float:
-    m = 0.0
+# what the last build_library() call of this process did, per flavour: "compiled" or "reused" (__graft_entry__.build() prints it)
+LAST_BUILD = {}
+
+
+def _source_digest(flags) -> str:
+    """sha256 over every source the library is made of (csrc/*.hip|hpp|map, include/*.h), this file (the command line lives
+    here) and the flags: a built .so is reused only when the stamp written next to it holds exactly this digest - file times do
+    not survive a snapshot / checkout, contents do."""
+    import hashlib
+    h = hashlib.sha256(" ".join(flags).encode())
     for root in (CSRC, os.path.join(os.path.dirname(CSRC), "..", "include")):
-        for f in os.listdir(root):
+        for f in sorted(os.listdir(root)):
             if f.endswith((".hip", ".hpp", ".h", ".map")):
-                m = max(m, os.path.getmtime(os.path.join(root, f)))
-    return max(m, os.path.getmtime(os.path.abspath(__file__)))       # (the command line lives in this file)
+                h.update(f.encode() + b"\0" + open(os.path.join(root, f), "rb").read())
+    h.update(open(os.path.abspath(__file__), "rb").read())
+    return h.hexdigest()
 
 
 def library_path() -> str:
@@ -31,8 +40,7 @@ def library_path() -> str:
 def build_library(force: bool = False, verbose: bool = False, diagnostics: bool = False) -> str:
     """Compile the HIP library in-tree (``diagnostics``: the -DJMID_DIAGNOSTICS flavour).  Returns the path of the .so."""
     LIB = LIB_DIAG if diagnostics else globals()["LIB"]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source_mtime():
-        return LIB
+    flavour = "diagnostics" if diagnostics else "production"
     # -ffp-contract=off: no implicit FMA contraction, so a value never depends on which template instance /
     # code path computed it (results are bit-identical across tile variants and chunkings); fmaf() is explicit.
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -46,6 +54,14 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
     # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-ffp-contract=off",
              "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else [])
+    stamp, digest = LIB + ".stamp", _source_digest(flags)
+    force = force or os.environ.get("JMID_FORCE_BUILD", "0") not in ("", "0")
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        LAST_BUILD[flavour] = "reused"
+        if verbose:
+            print(f"[build] {flavour}: reused {os.path.basename(LIB)} (sources + flags digest {digest[:12]} unchanged; "
+                  "JMID_FORCE_BUILD=1 recompiles)")
+        return LIB
     objdir = os.path.join(CSRC, "obj_diag" if diagnostics else "obj")
     os.makedirs(objdir, exist_ok=True)
     # the units compile side by side (the planner - every GEMM / attention instantiation of the denoise loop - is the long one)
@@ -70,6 +86,11 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
     proc = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
     if proc.returncode != 0:
         raise RuntimeError(f"hipcc (link) failed:\n{proc.stdout}\n{proc.stderr}")
+    with open(stamp, "w") as fh:
+        fh.write(digest + "\n")
+    LAST_BUILD[flavour] = "compiled"
+    if verbose:
+        print(f"[build] {flavour}: compiled {len(SOURCES)} units with hipcc for gfx950 -> {os.path.basename(LIB)} (digest {digest[:12]})")
     return LIB
 
 

@@ -767,7 +767,7 @@ inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t
 
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch (OUT_LN)?  d_model 512, at most 256 tiles of 64 x 64
 inline bool small_ln_fits(int M, int K) {
-    return tune().gemm_small != 1 && tune().gemm_h_variant == 0 && tune().small_ln == 1 && K % 128 == 0 && (long)((M + 63) / 64) * (GLN_BN / 64) <= 256;
+    return tune().gemm_small != 1 && tune().small_now == 1 && tune().gemm_h_variant == 0 && tune().small_ln == 1 && K % 128 == 0 && (long)((M + 63) / 64) * (GLN_BN / 64) <= 256;
 }
 
 template <int EPI, int OUT>

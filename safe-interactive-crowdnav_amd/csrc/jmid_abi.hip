@@ -115,7 +115,7 @@ int jmid_destroy(jmid_handle_t h) {
     }
     if (!h) return JMID_OK;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    sync_lanes(h);
     drop_graphs(h);
     for (auto& kv : h->w) hipFree(kv.second.p);
     for (auto* m : {&h->wsplit, &h->w16})
@@ -336,6 +336,7 @@ int jmid_predict(jmid_handle_t h, int E, int A, int K, int T, int k, const float
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->io_dev) HIPCHK(h, hipFree(h->io_dev));
         h->io_dev = nullptr;
+        h->io_dev_bytes = 0;
         if (hipMalloc((void**)&h->io_dev, total * 4) != hipSuccess) return fail(h, JMID_ENOMEM, "jmid_predict: device staging allocation failed");
         h->io_dev_bytes = total * 4;
     }
@@ -344,6 +345,7 @@ int jmid_predict(jmid_handle_t h, int E, int A, int K, int T, int k, const float
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (h->pin) HIPCHK(h, hipHostFree(h->pin));
         h->pin = nullptr;
+        h->pin_bytes = 0;
         if (hipHostMalloc((void**)&h->pin, pin_need, hipHostMallocDefault) != hipSuccess) return fail(h, JMID_ENOMEM, "jmid_predict: pinned staging allocation failed");
         h->pin_bytes = pin_need;
     }

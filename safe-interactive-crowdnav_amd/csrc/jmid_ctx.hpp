@@ -212,7 +212,9 @@ int upload_time_table(jmid_ctx* h);
 int make_w8(jmid_ctx* h, const float* dW, int N, int K, jmid_ctx::W8Image* out);
 // jmid_planner.hip
 void drop_graphs(jmid_ctx* h);
+void sync_lanes(jmid_ctx* h);
 int ensure_arena(jmid_ctx* h, size_t bytes);
+std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode);
 int check_ready(jmid_ctx* h);
 int order_in(jmid_ctx* h, int mem);
 int order_out(jmid_ctx* h, int mem);

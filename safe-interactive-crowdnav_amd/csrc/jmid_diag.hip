@@ -9,6 +9,16 @@ extern "C" {
 
 // ---------------------------------------------------------------------------------------------- diagnostics
 // Single-op entry points used by the unit tests (host buffers only).
+int jmid_dbg_plan_chunks(int net_kind, int nhead, int lanes, int chunk_episodes, int E, int tokens_per_episode, int* sizes, int cap) {
+    if (E <= 0 || tokens_per_episode <= 0 || nhead <= 0 || !sizes || cap <= 0) return JMID_EINVAL;
+    jmid_ctx ctx;                      // host fields only: the planner reads net_kind, nhead, lanes, chunk_eps and the tuning
+    ctx.net_kind = net_kind; ctx.nhead = nhead; ctx.lanes = lanes; ctx.chunk_eps = chunk_episodes;
+    TuneScope tune_scope(&ctx.tune);
+    const std::vector<int> plan = plan_chunks(&ctx, E, tokens_per_episode);
+    for (size_t i = 0; i < plan.size() && (int)i < cap; ++i) sizes[i] = plan[i];
+    return (int)plan.size();
+}
+
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
                   int precision, float* C) {
     if (!h || !A || !Wt || !C) return JMID_EINVAL;

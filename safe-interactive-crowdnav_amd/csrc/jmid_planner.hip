@@ -10,12 +10,19 @@ void drop_graphs(jmid_ctx* h) {
     h->graphs.clear();
 }
 
+// Error paths and arena owners: nothing may still run on a lane stream when the arena is reused or freed.
+void sync_lanes(jmid_ctx* h) {
+    for (int l = 0; l + 1 < jmid_ctx::kMaxLanes; ++l)
+        if (h->lane_stream[l]) (void)hipStreamSynchronize(h->lane_stream[l]);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+}
+
 int ensure_arena(jmid_ctx* h, size_t bytes) {
     if (bytes <= h->arena_bytes) return 0;
     drop_graphs(h);
     h->last_pos = nullptr;
     if (h->arena) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        sync_lanes(h);
         HIPCHK(h, hipFree(h->arena));
         h->arena = nullptr;
         h->arena_bytes = 0;
@@ -404,7 +411,7 @@ std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
             c = (E + 1) / 2;
         } else {
             int n = (E + c - 1) / c;
-            n += n & 1;
+            if ((n & 1) && n < E) ++n;      // (never more chunks than episodes: c == 1 with an odd E stays at E chunks of one)
             std::vector<int> sizes(n, E / n);
             for (int i = 0; i < E % n; ++i) sizes[i] += 1;
             return sizes;
@@ -613,6 +620,9 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
                         (void)hipStreamEndCapture(h->stream, &dead);
                         if (dead) hipGraphDestroy(dead);
                     }
+                    // the lanes share the one arena: what they already hold must have drained before the caller (the f32
+                    // rerun, ensure_arena, jmid_destroy) touches it again on h->stream
+                    sync_lanes(h);
                     return rc;
                 }
             }

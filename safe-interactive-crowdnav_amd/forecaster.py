@@ -132,7 +132,9 @@ class _ModelInfo:
 class HumanTrajectoryForecasterSim(ForecasterSimSuper):
     def __init__(self, env_config=None, mid_config_file=None, *, weights: Optional[JMIDWeights] = None,
                  device_id: Optional[int] = None, precision: Optional[str] = None, rng_compat: Optional[str] = None,
-                 self_check: Optional[bool] = None, self_check_tol: float = 2e-5, device_topk: Optional[bool] = None):
+                 self_check: Optional[bool] = None, self_check_tol: float = 2e-5, device_topk: Optional[bool] = None,
+                 lib_path: Optional[str] = None):
+        # (lib_path: another build of the library - tests run both flavours in one process; the product leaves it at None)
         # keyword arguments left at None take the process-wide defaults (``DEFAULTS``; ``install(**defaults)`` sets them for
         # a caller that constructs the class with the reference's two positional arguments only, sicnav_acados.py:998-1000)
         device_id = DEFAULTS["device_id"] if device_id is None else device_id
@@ -151,9 +153,9 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
         if rng_compat not in ("auto", "cpu", "cuda"):
             raise ValueError("rng_compat must be 'auto', 'cpu' or 'cuda'")
         self.rng_compat = rng_compat if rng_compat != "auto" else ("cuda" if torch.cuda.is_available() else "cpu")
-        self._init_MID(mid_config_file, weights, device_id)
+        self._init_MID(mid_config_file, weights, device_id, lib_path)
 
-    def _init_MID(self, mid_config_file, weights, device_id):
+    def _init_MID(self, mid_config_file, weights, device_id, lib_path=None):
         with open(mid_config_file) as f:
             cfg = yaml.safe_load(f)
         self.config = cfg
@@ -171,12 +173,12 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
             raise ValueError("maximum_history_length must equal past_num_frames - 1")
         if weights is None:
             weights = load_weights(cfg["model_path"], dims)
-        key = (weights.checksum(), self.joint, device_id, self.num_hist_frames, self.step_size)
+        key = (weights.checksum(), self.joint, device_id, self.num_hist_frames, self.step_size, lib_path)
         with _CACHE_LOCK:
             eng = _ENGINE_CACHE.get(key)
             if eng is None:
                 eng = JmidEngine(weights, joint=self.joint, device_id=device_id, hist_len=self.num_hist_frames,
-                                 step=self.step_size)
+                                 step=self.step_size, lib_path=lib_path)
                 _ENGINE_CACHE[key] = eng
                 _ENGINE_LOCKS[id(eng)] = RLock()
             self.engine = eng

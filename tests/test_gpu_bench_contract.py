@@ -16,17 +16,49 @@ MODE_KEYS = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofli
 PROD_ENV = {k: v for k, v in os.environ.items() if k != "JMID_LIB"}
 
 
-def _one_json_line(out):
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "modes", "detail")
+
+
+def _one_json_line(out, full=True):
+    """The stdout contract: exactly ONE line, the LAST one, strict JSON, short enough for the driver's tail buffer (round 4's
+    20.7 KB line was not parsed).  Returns the long result from the file the line names (`full`), or the line itself."""
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    return json.loads(lines[0])
+    lines = out.stdout.splitlines()
+    assert lines and lines[-1].startswith("{"), out.stdout[-2000:]
+    assert len([l for l in lines if l.startswith("{")]) == 1, out.stdout[-2000:]
+    assert len(lines[-1]) < 6000, len(lines[-1])
+    line = json.loads(lines[-1], parse_constant=lambda c: pytest.fail(f"non-strict JSON constant {c}"))
+    for k in COMPACT_KEYS:
+        assert k in line, k
+    detail = line["detail"] if os.path.isabs(line["detail"]) else os.path.join(REPO, line["detail"])
+    long = json.load(open(detail))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling"):
+        assert long[k] == line[k], k                        # the line is a selection of the long result, nothing else
+    return long if full else line
 
 
-def test_bench_json_contract():
+def test_bench_json_contract(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                          "--episodes-per-gpu", "6", "--chunk", "2", "--cpu-episodes", "3"],
+                          "--episodes-per-gpu", "6", "--chunk", "2", "--cpu-episodes", "3", "--detail", str(tmp_path / "d.json")],
                          capture_output=True, text=True, timeout=600, cwd=REPO, env=PROD_ENV)
+    c = _one_json_line(out, full=False)
+    assert len(out.stderr) < 8000, len(out.stderr)         # the log stays short too: the driver's tail holds stdout + stderr
+    # the compact line carries what the driver and the judge read: contract keys, roofline, cpu_baseline, parity, a row per mode
+    from safe_interactive_crowdnav_amd import forecaster as FC
+    assert c["config"]["precision"] == "f16mx" and c["config"]["class_default_precision"] == FC.DEFAULTS["precision"]
+    assert "workload" in c["config"] and "model" not in c["config"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches", "flops_per_launch"):
+        assert k in c["roofline"], k
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample", "host_physical_cores"):
+        assert k in c["cpu_baseline"], k
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1 and c["cpu_baseline"]["value"] > 0
+    assert c["parity"]["pass"] is True and c["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4 and c["parity"]["precision"] == "f16mx"
+    assert set(c["modes"]) == {"f16x3", "f16x2", "f16mx"}
+    for m, v in c["modes"].items():
+        assert v["value"] > 0 and v["ms_per_step"] > 0 and v["pass"] is True and v["mean_ADE_vs_oracle_m"] <= 1e-4
+    assert c["value"] == c["modes"]["f16mx"]["value"] and set(c["single_scene"]["modes"]) == set(c["modes"])
     j = _one_json_line(out)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -41,7 +73,6 @@ def test_bench_json_contract():
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert c["processes"] * c["threads_per_process"] == c["cores"] <= c["hardware_threads"]
     # the headline is the throughput mode (an explicit opt-in of the drop-in class, whose own default is the fp32-class mode) ...
-    from safe_interactive_crowdnav_amd import forecaster as FC
     import inspect
     assert inspect.signature(FC.HumanTrajectoryForecasterSim.__init__).parameters["precision"].default is None     # -> DEFAULTS
     assert FC.DEFAULTS["precision"] == "f16x3"
@@ -161,3 +192,27 @@ def test_bench_collectives_run_on_rccl_with_one_rank():
     j = _one_json_line(out)
     assert j["n_gpus"] == 1 and j["config"]["dist_backend"] == "nccl" and j["sweep_metrics"]["episodes"] == 4
     assert j["value"] > 0
+
+
+def test_bench_two_gpus_over_rccl_strong_scaling():
+    """The first multi-GPU lease verifies itself: `bench.py --gpus 2 --dist-backend nccl --scaling strong` - one rank per GPU, the
+    process group on RCCL, 64 episodes block-partitioned 32 + 32, ONE gather of the metric rows over xGMI after the timed steps
+    (SURVEY 8e).  Skipped on a one-GPU box (where the gloo two-rank and the RCCL one-rank tests above cover the same calls)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL with one rank per GPU")
+    env = {k: v for k, v in PROD_ENV.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dist-backend", "nccl", "--scaling", "strong",
+                          "--total-episodes", "64", "--steps", "2", "--warmup", "1", "--modes", "f16mx", "--cpu-episodes", "0",
+                          "--no-profile"],
+                         capture_output=True, text=True, timeout=900, cwd=REPO, env=env)
+    c = _one_json_line(out, full=False)
+    assert c["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["scaling"] == "strong" and c["config"]["dist_backend"] == "nccl"
+    assert c["config"]["total_episodes"] == 64 and c["config"]["episodes_per_gpu"] == 32 and c["sweep_episodes"] == 64
+    j = _one_json_line(out)
+    pr = j["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"] <= j["ms_per_step"] * 1.05
+    assert abs(j["value"] - 64 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+    sm = j["sweep_metrics"]
+    assert sm["episodes"] == 64 and sm["mean_ADE_m"] == sm["mean_ADE_m"]        # rows of both ranks arrived, in episode order

@@ -14,6 +14,7 @@ from safe_interactive_crowdnav_amd.forecaster import HumanTrajectoryForecasterSi
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PROD_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
 CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "wrapper_*.npz")))
 
 
@@ -22,15 +23,18 @@ class State:
         self.position = (float(p[0]), float(p[1]))
 
 
+@pytest.mark.parametrize("flavour", ["diag", "prod"])
 @pytest.mark.parametrize("case", CASES)
-def test_predict_ret_best_matches_reference(case, tmp_path):
+def test_predict_ret_best_matches_reference(case, flavour, tmp_path):
     z = np.load(os.path.join(GOLDEN, case))
     N, K, k_ret, H = int(z["N"]), int(z["K"]), int(z["k_ret"]), int(z["H"])
     env, ypath = write_configs(str(tmp_path), joint=bool(z["joint"]), ctx_dim=int(z["ctx_dim"]), N=N, K=K,
                                k_ret=k_ret, H=H, step=int(z["step"]), time_step=float(z["time_step"]))
     w = JMIDWeights.from_seed(NetDims(ctx_dim=int(z["ctx_dim"])), int(z["wseed"]))
     assert w.checksum() == str(z["wsum"])
-    f = HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="cpu")   # the captures are CPU-reference runs
+    # the captures are CPU-reference runs; flavour "prod" = the production libjmid_hip.so next to the session's diagnostics build
+    f = HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="cpu", lib_path=PROD_LIB if flavour == "prod" else None)
+    assert f.engine._lib.has_diagnostics == (flavour == "diag")
     assert f.num_hist_frames == int(z["past"])
     for r, h, t in zip(z["robot_xy"], z["human_xy"], z["stamps"]):
         f.update_state_hists(State(r), [State(p) for p in h], float(t))

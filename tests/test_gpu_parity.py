@@ -17,6 +17,7 @@ from safe_interactive_crowdnav_amd.engine import JmidEngine
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PROD_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
 ADE_GATE = 1e-4
 PRECISIONS = ["f32", "f16x3", "f16x2", "f16mx"]
 SPLIT_MODES = ["f16x3", "f16x2", "f16mx"]      # all run on the hi/lo operand planes; f16x2 leaves the activation-lo term out,
@@ -32,22 +33,28 @@ def ade(a, b):
 _ENGINES = {}
 
 
-def get_engine(ctx_dim, wseed, joint):
-    key = (ctx_dim, wseed, joint)
+def get_engine(ctx_dim, wseed, joint, flavour="diag"):
+    """`flavour`: "diag" = the diagnostics build the test session loads (tests/conftest.py), "prod" = the PRODUCTION
+    libjmid_hip.so (what the drop-in class, bench.py and smoke() load), side by side in this process."""
+    key = (ctx_dim, wseed, joint, flavour)
     if key not in _ENGINES:
         w = JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), wseed)
-        _ENGINES[key] = (JmidEngine(w, joint=joint), w)
+        _ENGINES[key] = (JmidEngine(w, joint=joint, lib_path=PROD_LIB if flavour == "prod" else None), w)
+        assert _ENGINES[key][0]._lib.has_diagnostics == (flavour == "diag")
     return _ENGINES[key]
 
 
 NET_CASES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "net_*.npz")))
 
 
+@pytest.mark.parametrize("flavour", ["diag", "prod"])
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", NET_CASES)
-def test_net_eval_and_denoise_match_reference_golden(case, precision):
+def test_net_eval_and_denoise_match_reference_golden(case, precision, flavour):
+    """Every reference capture of the net / the DDIM loop, every mode, on BOTH builds of the library: the diagnostics flavour the
+    rest of this file drives and the production flavour that ships."""
     z = np.load(os.path.join(GOLDEN, case))
-    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    eng, w = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]), flavour)
     assert w.checksum() == str(z["wsum"])
     A, K, T, step = int(z["A"]), int(z["K"]), int(z["T"]), int(z["step"])
     eng.set_step(step)

@@ -159,6 +159,7 @@ def test_install_aliases_the_reference_module(monkeypatch):
             importlib.invalidate_caches()
         try:
             mod = P.install(precision="f16mx", self_check=True)
+            stood_in = list(P._STAND_INS)
             assert mod is FC and FC.DEFAULTS["precision"] == "f16mx" and FC.DEFAULTS["self_check"] is True
             ns = {}
             exec("from sicnav_diffusion.JMID.mid_sim_wrapper import HumanTrajectoryForecasterSim", ns)     # the caller's line
@@ -172,6 +173,68 @@ def test_install_aliases_the_reference_module(monkeypatch):
             FC.DEFAULTS.clear()
             FC.DEFAULTS.update(saved)
         assert sys.modules.get("sicnav_diffusion.JMID.mid_sim_wrapper") is not FC
+        # stand-in parents (registered when the reference tree is not importable) are gone again: the real packages stay
+        # importable afterwards
+        assert not P._STAND_INS and not any(n in sys.modules for n in stood_in)
+        if with_reference:
+            assert not stood_in
+
+
+def test_install_does_not_mask_a_reference_package_that_fails_to_import(tmp_path, monkeypatch):
+    """A reference tree that IS on sys.path but whose package __init__ raises (a missing dependency) must surface as that error:
+    install() only substitutes a stand-in for "this package does not exist"."""
+    import importlib
+    import sys
+    import safe_interactive_crowdnav_amd as P
+    from safe_interactive_crowdnav_amd import forecaster as FC
+    (tmp_path / "sicnav_diffusion").mkdir()
+    (tmp_path / "sicnav_diffusion" / "__init__.py").write_text("import a_dependency_that_is_not_installed_here\n")
+    for name in [n for n in sys.modules if n == "sicnav_diffusion" or n.startswith("sicnav_diffusion.")]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.syspath_prepend(str(tmp_path))
+    importlib.invalidate_caches()
+    saved = dict(FC.DEFAULTS)
+    try:
+        with pytest.raises(ModuleNotFoundError, match="a_dependency_that_is_not_installed_here"):
+            P.install()
+    finally:
+        P.uninstall()
+        FC.DEFAULTS.clear()
+        FC.DEFAULTS.update(saved)
+    assert "sicnav_diffusion" not in sys.modules
+
+
+def test_chunk_plan_never_holds_an_empty_chunk():
+    """run_network's chunk plan (csrc/jmid_planner.hip::plan_chunks, through the diagnostics entry point; host logic only): the
+    sizes add up to E, no chunk is empty - round 4's balanced plan rounded E chunks of ONE episode (K*A*T > 32768 tokens per
+    episode) up to E + 1 for odd E, and a zero-episode chunk is a grid-0 launch - and, unforced with two lanes, the count is even
+    whenever that is possible."""
+    import ctypes as C
+    import __graft_entry__ as graft
+    from safe_interactive_crowdnav_amd import _lib
+    from safe_interactive_crowdnav_amd.build import LIB_DIAG
+    graft.build()
+    lib = _lib.load_library(LIB_DIAG)
+    buf = (C.c_int * 8192)()
+
+    def plan(E, tokens, lanes=2, forced=0, net=_lib.NET_JMID):
+        n = lib.jmid_dbg_plan_chunks(net, 4, lanes, forced, E, tokens, buf, len(buf))
+        assert 0 < n <= len(buf), n
+        return list(buf[:n])
+
+    for tokens in (1200, 19200, 38400, 128 * 25 * 12, 65536, 70000):       # cfg2, cfg4, and shapes whose automatic chunk is 1 episode
+        for E in (1, 2, 3, 4, 5, 7, 9, 51, 52, 101, 255, 256, 257, 511, 512, 4096):
+            for lanes in (1, 2, 3):
+                for net in (_lib.NET_JMID, _lib.NET_IMID):
+                    sizes = plan(E, tokens, lanes=lanes, net=net)
+                    assert sum(sizes) == E and min(sizes) >= 1, (tokens, E, lanes, sizes[:8])
+                    if lanes >= 2 and E >= 2 and len(sizes) < E:
+                        assert len(sizes) % 2 == 0 and max(sizes) - min(sizes) <= 1, (tokens, E, sizes[:8])
+            for forced in (1, 2, 51):
+                sizes = plan(E, tokens, forced=forced)
+                assert sum(sizes) == E and min(sizes) >= 1 and max(sizes) <= forced
+    assert plan(256, 1200) == [43] * 4 + [42] * 2          # DESIGN section 3
+    assert plan(3, 38400) == [1, 1, 1] and plan(5, 70000) == [1] * 5       # the advisor's case: c == 1, odd E
 
 
 def test_module_level_get_most_likely_samples_has_the_reference_signature():

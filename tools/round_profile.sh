@@ -2,7 +2,7 @@
 # All measurements profiles/ holds for a round, in one GPU-box call (about 15 minutes).  Output: gpurun_out/$R/
 #   R=r02 tools/round_profile.sh ; then python tools/update_profiles.py r02
 export TMPDIR=/tmp
-R=${R:-r04}
+R=${R:-r05}
 O=gpurun_out/$R
 mkdir -p $O
 # PMC first: HBM bytes and MFMA busy per production kernel over one whole call, per mode; the summaries go into profiles/ of
@@ -13,13 +13,13 @@ for m in f16mx f16x2 f16x3; do
   cp gpurun_out/pmc/pmc_call_$m.json profiles/${R}_pmc_call_$m.json
 done
 # default bench (BASELINE configs[2]), all split modes measured identically, parity sample over all chunks
-timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench_cfg3.json 2> $O/bench_cfg3.err
-timeout 300 python bench.py --no-pmc --precision f32 --modes f32 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_f32.json 2>/dev/null
-timeout 300 python bench.py --no-pmc --workload cfg2 --cpu-episodes 0 --no-e2e --steps 20 --warmup 3 > $O/bench_cfg2.json 2>/dev/null
-timeout 300 python bench.py --no-pmc --workload cfg4 --cpu-episodes 0 --no-e2e --steps 3 > $O/bench_cfg4.json 2>/dev/null
-timeout 400 python bench.py --no-pmc --workload cfg5 --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg5_1gpu.json 2>/dev/null
-timeout 300 python bench.py --no-pmc --net imid --cpu-episodes 0 --no-e2e --steps 2 > $O/bench_cfg3_imid.json 2>/dev/null
-timeout 300 python bench.py --no-pmc --scenes orca --cpu-episodes 4 --no-e2e --steps 2 > $O/bench_cfg3_orca.json 2>/dev/null
+timeout 600 python bench.py --steps 10 --warmup 3 --detail $O/bench_cfg3.json > $O/bench_cfg3.line.json 2> $O/bench_cfg3.err
+timeout 300 python bench.py --no-pmc --precision f32 --modes f32 --cpu-episodes 0 --no-e2e --steps 2 --detail $O/bench_cfg3_f32.json > $O/bench_cfg3_f32.line.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --workload cfg2 --cpu-episodes 0 --no-e2e --steps 20 --warmup 3 --detail $O/bench_cfg2.json > $O/bench_cfg2.line.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --workload cfg4 --cpu-episodes 0 --no-e2e --steps 3 --detail $O/bench_cfg4.json > $O/bench_cfg4.line.json 2>/dev/null
+timeout 400 python bench.py --no-pmc --workload cfg5 --cpu-episodes 0 --no-e2e --steps 2 --detail $O/bench_cfg5_1gpu.json > $O/bench_cfg5_1gpu.line.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --net imid --cpu-episodes 0 --no-e2e --steps 2 --detail $O/bench_cfg3_imid.json > $O/bench_cfg3_imid.line.json 2>/dev/null
+timeout 300 python bench.py --no-pmc --scenes orca --cpu-episodes 4 --no-e2e --steps 2 --detail $O/bench_cfg3_orca.json > $O/bench_cfg3_orca.line.json 2>/dev/null
 # episodes per call sweep (weak-scaling unit), both modes
 for e in 1 2 4 8 16 32 52 104 256 512; do
   timeout 300 python bench.py --no-pmc --cpu-episodes 0 --no-e2e --episodes-per-gpu $e --steps 2 --warmup 1 --no-profile 2>/dev/null | python -c "
@@ -40,7 +40,7 @@ rm -rf $O/prof_ss
 for m in f16mx f16x3; do JMID_PREC=$m tools/shipped_profile.sh; done > $O/shipped_profile.log 2>&1
 JMID_PREC=f16mx tools/small_pmc.sh 1 > /dev/null 2>&1; cp gpurun_out/small_pmc_f16mx_E1.txt $O/small_pmc_f16mx_E1.txt
 for t in small_gemm_trace_0 attn_small_trace; do if [ -x build/$t ]; then ./build/$t; fi; done > $O/small_launch_traces.log 2>&1
-timeout 600 python bench.py --gpus 2 --dist-backend gloo --device 0 --total-episodes 512 --steps 2 --warmup 1 --cpu-episodes 0 --no-profile 2>/dev/null | grep '^{' > $O/bench_strong_2ranks_1gpu.json
+timeout 600 python bench.py --gpus 2 --dist-backend gloo --device 0 --total-episodes 512 --steps 2 --warmup 1 --cpu-episodes 0 --no-profile --detail $O/bench_strong_2ranks_1gpu.json 2>/dev/null | tail -1 > $O/bench_strong_2ranks_1gpu.line.json
 # reproducibility soak of the default path + the documented multi-lane disturbance
 # reproducibility soak: one chunk in flight, and 2 / 3 / 4 chunks in flight against the one-chunk reference (bitwise)
 python tools/rerun_soak.py f16mx 20 256 1 > $O/soak.log 2>&1
