@@ -896,16 +896,23 @@ inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }
 
-#ifdef JMID_DIAGNOSTICS
-// experiment (knob "attn_q64" = 1, diagnostics flavour only): F16MX launches without a key split on the one-wave-per-SIMD kernel with two
+#ifdef JMID_EXPERIMENTS
+// experiment (knob "attn_q64" = 1, -DJMID_EXPERIMENTS builds only): F16MX launches without a key split on the one-wave-per-SIMD kernel with two
 // query blocks per wave (attn_q64.hpp, included at the end of this file) - bit-identical, measured 7-14 % slower than the kernel below
 inline bool attn_q64_applies(const AttnHArgs& a, int nseq);
 inline hipError_t launch_attn_q64(const AttnHArgs& a_in, int nseq, hipStream_t st);
 #endif
 
+#ifdef JMID_EXPERIMENTS
+// experiment (knob "attn_pp" = 1): the 8-wave ping-pong form of the head_dim-128 kernel (attn_pp.hpp, included at the end of this
+// file; bit-identical, measured no faster - docs/NOTEBOOK.md section 10)
+inline bool attn_pp_applies(const AttnHArgs& a, int nseq);
+inline void launch_attn_pp(AttnHArgs a, int nseq, hipStream_t st);
+#endif
+
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
     AttnHArgs a = a_in;
-#ifdef JMID_DIAGNOSTICS
+#ifdef JMID_EXPERIMENTS
     if (head_dim == 128 && tune().attn_h_variant != 1 && attn_q64_applies(a, nseq)) return launch_attn_q64(a, nseq, st);
 #endif
     if (head_dim == 128 && tune().attn_h_variant != 1) {
@@ -919,6 +926,11 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
         // the mode is a template parameter (a run-time flag in the key-tile loop costs F16X3 ~4 %).  F16X2 / F16MX: one fp16 plane
         // of P unless "attn_mx" = 1; F16MX with bf8 K images: the logits' correction terms as bf8 MFMAs
         const bool p1 = tune().attn_mx != 1;
+#ifdef JMID_EXPERIMENTS
+        if (attn_pp_applies(a, nseq)) {
+            launch_attn_pp(a, nseq, st);
+        } else
+#endif
         if (a.x2 && a.K8h) {
             if (p1 && tune().attn_pf != 2) launch_attn_dma<true, true, false, true, true>(a, grid1, nqt, st);
             else if (p1) launch_attn_dma<true, true, false, true>(a, grid1, nqt, st);
@@ -950,6 +962,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 
 }  // namespace jmid
 
-#ifdef JMID_DIAGNOSTICS
+#ifdef JMID_EXPERIMENTS
+#include "attn_pp.hpp"
 #include "attn_q64.hpp"
 #endif

@@ -140,6 +140,7 @@ struct Tuning {
     int tail_rows = 0;       // its row tile: 0 auto, 32, 64
     int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
     int attn_q64 = 0;        // experiment (diagnostics): 1 = F16MX attention launches without a key split on the one-wave-per-SIMD kernel (attn_q64.hpp: bit-identical, measured slower)
+    int attn_pp = 0;         // head_dim-128 attention as the 8-wave ping-pong kernel (attn_pp.hpp; bit-identical): 0 = automatic, 1 = always, 2 = never
     int h1_stage = 0;        // F16MX linear1 in the 256 x 256 / 128 x 256 shapes: 0 / 1 = tile out through LDS in whole lines (h1_staged_store), 2 = the element-wise epilogue
     int out_traj = 0;        // output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories, 1 = always, 2 = one wave per token
     int attn_mx = 0;         // head_dim 128: F16MX 0 = bf8 logit corrections + one fp16 plane of P, 1 = P_hi + P_lo (F16X2 too), 2 = F16X2's attention, 3 = as 0 with Q_lo as an fp16 plane (A/B; same bits)

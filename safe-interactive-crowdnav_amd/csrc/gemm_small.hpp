@@ -618,6 +618,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
 #endif
 }
 
+#ifdef JMID_EXPERIMENTS
 // concat4 (ConcatSquash 256 -> 128) + output layer + DDIM / DDPM update + the next step's embedding in ONE small launch: N = 128 is
 // one 64 x 128 tile, i.e. the workgroup owns complete Y4 rows - the only GEMM of the net whose consumer can follow in the same
 // workgroup without another workgroup's data.  The gated Y4 tile stays in LDS (the ring's place), then every wave walks its share
@@ -702,6 +703,7 @@ inline hipError_t launch_gemm_small_out(const GemmHArgs& g, const OutArgs& oa, c
     if (g.x2) return launch_gemm_small_out_mode<SM_X2>(g, oa, nxt, embed_next, T, st);
     return launch_gemm_small_out_mode<SM_X3>(g, oa, nxt, embed_next, T, st);
 }
+#endif  // JMID_EXPERIMENTS
 
 // bytes all eight XCDs pull from the Infinity Cache with pn column groups: every XCD its column group's share of W and the A rows
 // of its part of the M range

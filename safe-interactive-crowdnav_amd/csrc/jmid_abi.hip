@@ -428,22 +428,35 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"vt_stage", &Tuning::vt_stage, 0, 3},                 // V^T of the 256x256 QKV kernel through LDS: 0 / 1 on, 2 off
         {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
+#ifdef JMID_EXPERIMENTS
         {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
+#endif
         {"attn_mx", &Tuning::attn_mx, 0, 3},
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"attn_pf", &Tuning::attn_pf, 0, 2},
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"h1_stage", &Tuning::h1_stage, 0, 2},
+#ifdef JMID_EXPERIMENTS
         {"attn_q64", &Tuning::attn_q64, 0, 1},
+#endif
+#ifdef JMID_EXPERIMENTS
+        {"attn_pp", &Tuning::attn_pp, 0, 2},
+#endif
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
+#ifdef JMID_EXPERIMENTS
         {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches
+#endif
         {"small_lanes", &Tuning::small_lanes, 0, 2},
+#ifdef JMID_EXPERIMENTS
         {"small_out", &Tuning::small_out, 0, 2},
+#endif
         {"small_qk", &Tuning::small_qk, 0, 2},
         {"small_pn", &Tuning::small_pn, 0, 8},                 // column groups of its XCD tile order: 0 auto
+#ifdef JMID_EXPERIMENTS
         {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
+#endif
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
         {"gemm_abl", &Tuning::gemm_abl, 0, 1 << 30},

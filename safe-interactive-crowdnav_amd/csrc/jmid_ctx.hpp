@@ -29,7 +29,9 @@
 #include "gemm_small.hpp"
 #include "gemm_f32.hpp"
 #include "kde.hpp"
-#include "tail_f16x3.hpp"
+#ifdef JMID_EXPERIMENTS
+#include "tail_f16x3.hpp"      // fused tail of the net: measured slower (docs/NOTEBOOK.md); compiled with -DJMID_EXPERIMENTS only
+#endif
 
 using namespace jmid;
 

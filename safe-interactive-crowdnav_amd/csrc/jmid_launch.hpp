@@ -23,6 +23,7 @@ int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
     return 0;
 }
 
+#ifdef JMID_EXPERIMENTS
 // out_proj / linear2 + residual + LayerNorm as ONE small launch (gemm_small.hpp, OUT_LN); g carries the GEMM, the ln_* fields the tail
 inline int run_gemm_ln_small(jmid_ctx* h, int cls, GemmHArgs& g) {
     g.range_flag = h->range_flag;
@@ -31,6 +32,7 @@ inline int run_gemm_ln_small(jmid_ctx* h, int cls, GemmHArgs& g) {
     HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LN>(g, 2, h->stream)));
     return 0;
 }
+#endif
 
 // JMID_PREC_F16MX: hand the GEMM the fp8 image of this weight's lo plane (the kernels that have no fp8 path ignore it)
 inline void set_w8(jmid_ctx* h, GemmHArgs& g, const std::string& name) {

@@ -248,11 +248,14 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
                 set_w8(h, g, p + ".self_attn.out_proj.weight");
                 g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+#ifdef JMID_EXPERIMENTS
                 if (ln_small && small_ln_fits(M, g.K)) {
                     g.ln_gamma = W(h, p + ".norm1.weight"); g.ln_beta = W(h, p + ".norm1.bias"); g.ln_xh = sb.Xh; g.ln_xl = sb.Xl;
                     g.ln_xl8 = Xl8; g.ln_cnt = sb.ln_cnt; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
                     if (int rc = run_gemm_ln_small(h, KC_GEMM_OUT, g)) return rc;
-                } else {
+                } else
+#endif
+                {
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
                                         sb.Xl, mxv2, 0))
@@ -286,11 +289,14 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
                 set_w8(h, g, p + ".linear2.weight");
                 g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
+#ifdef JMID_EXPERIMENTS
                 if (ln_small && small_ln_fits(M, g.K)) {
                     g.ln_gamma = W(h, p + ".norm2.weight"); g.ln_beta = W(h, p + ".norm2.bias"); g.ln_xh = sb.Xh; g.ln_xl = sb.Xl;
                     g.ln_xl8 = Xl8; g.ln_cnt = sb.ln_cnt; g.ln_eps = 1e-5f; g.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
                     if (int rc = run_gemm_ln_small(h, KC_GEMM_FF2, g)) return rc;
-                } else {
+                } else
+#endif
+                {
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
                                         sb.Xl, mxv2, l + 1 == h->tf_layer))
@@ -302,7 +308,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         // to the three launches below it replaces) at the shipped width.  Opt-in: it saves two launches per step but runs
         // four waves per CU, and measured slower than the three well-occupied kernels at every batch size (one scene
         // 13.65 vs 13.23 ms per call, a 51-episode chunk +1.3 %; tools/single_scene_sweep.py tail_fuse=2,1)
+#ifdef JMID_EXPERIMENTS
         tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse == 1 && !h->mx;   // the fused kernel has no fp8-correction K loop
+#endif
         if (!tail_fused) {
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
@@ -319,7 +327,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         g.goff = h->hl.g4; g.boff = h->hl.b4;
         // a small launch runs concat4 together with everything behind it (gemm_small_out_kernel, below)
         g.x2 = h->x2; g.range_flag = h->range_flag;
+#ifdef JMID_EXPERIMENTS
         out_fused = small_out_fits(g, d);
+#endif
         if (out_fused) g4 = g;
         else if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
         }
@@ -337,6 +347,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.c1 = h->p_c1[step_idx];
             oa.sigma = h->p_sigma[step_idx];
         }
+#ifdef JMID_EXPERIMENTS
         if (out_fused) {
             const bool en = next_step >= 0 && !e_out;
             HIPCHK(h, launch_gemm_small_out(g4, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, T, h->stream));
@@ -350,7 +361,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             const int rows = tune().tail_rows ? tune().tail_rows : (M < 64 * 256 ? 32 : 64);
             HIPCHK(h, launch_tail(ta, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, rows,
                                   h->x2 != 0, h->stream));
-        } else if (d <= 512 && M % T == 0 && tune().out_traj != 2 && (tune().out_traj == 1 || M >= 4096 * 4)) {
+        } else
+#endif
+        if (d <= 512 && M % T == 0 && tune().out_traj != 2 && (tune().out_traj == 1 || M >= 4096 * 4)) {
             // one wave per trajectory (T tokens) - or per piece of one, the largest divisor of T that still leaves >= 4096 waves -
             // once there are enough tokens to fill the chip that way: one scene (100 trajectories) takes 14.0 instead of
             // 12.7 ms per call with whole trajectories, a 51-episode chunk 150.3 instead of 151.2

@@ -1,4 +1,6 @@
 """Single-kernel checks of the HIP library against float64 numpy/torch references (GPU box only)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -119,7 +121,7 @@ def test_f16mx_fused_gemm_layernorm_gen2_matches_float64_and_its_unfused_pair(M,
     """gemm_ln2_mx_kernel (JMID_PREC_F16MX, d_model 512: transposed product, row statistics in the accumulators, byte lo
     plane of the residual stream) against float64, and bit for bit against the GEMM + add_ln2 pair small launches use -
     nn.TransformerEncoderLayer's x = norm(x + sublayer(x)) as built at MID/models/diffusion.py:161-166."""
-    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True, lib_path=EXP_LIB)
     try:
         rng = np.random.default_rng(M + K)
         A = rng.standard_normal((M, K)).astype(np.float32) * np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
@@ -140,12 +142,18 @@ def test_f16mx_fused_gemm_layernorm_gen2_matches_float64_and_its_unfused_pair(M,
     np.testing.assert_array_equal(fused, pair)
 
 
+EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_exp.so")
+needs_experiments = pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="the experiments flavour is not built "
+                                       "(python safe-interactive-crowdnav_amd/build.py experiments)")
+
+
+@needs_experiments
 @pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128)])
 def test_small_launch_gemm_with_layernorm_tail_equals_its_unfused_pair(M, K):
     """gemm_small_kernel<.., OUT_LN> (one scene: out_proj / linear2 + residual + LayerNorm in ONE launch, the rows normalised by
     the last-arriving workgroup of each 64-row tile after an sc1 hand-off) against float64 and bit for bit against the GEMM +
     add_ln2 pair - repeated, so that an unlucky arrival order or a stale line would show (every word is compared)."""
-    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True, lib_path=EXP_LIB)
     try:
         rng = np.random.default_rng(M + K)
         A = rng.standard_normal((M, K)).astype(np.float32) * np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
@@ -166,13 +174,14 @@ def test_small_launch_gemm_with_layernorm_tail_equals_its_unfused_pair(M, K):
     assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
 
 
+@needs_experiments
 @pytest.mark.parametrize("precision", ["f16mx", "f16x2", "f16x3"])
 @pytest.mark.parametrize("A,K,T,steps", [(5, 20, 12, 4), (3, 100, 8, 2), (2, 7, 6, 2), (1, 3, 5, 2)])
 def test_small_launch_tail_in_one_kernel_equals_its_unfused_pair(precision, A, K, T, steps):
     """gemm_small_out_kernel (opt-in knob small_out = 1: concat4 + output layer + DDIM update + next embedding in ONE launch,
     the gated Y4 tile in LDS) against the default chain (concat4's launch + out_ddim_kernel): every word of the velocities and
     the positions, for pieces of 4 / 8 / 2 / 1 tokens (T = 12 / 8 / 6 / 5) and row counts that end inside a 64-row tile."""
-    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 2), joint=True, step=steps)
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 2), joint=True, step=steps, lib_path=EXP_LIB)
     try:
         g = torch.Generator().manual_seed(A * 1000 + K)
         ctx = torch.randn([1, A, 256], generator=g).cuda()

@@ -17,6 +17,9 @@ from safe_interactive_crowdnav_amd.engine import JmidEngine
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_exp.so")
+needs_experiments = pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="the experiments flavour is not built "
+                                       "(python safe-interactive-crowdnav_amd/build.py experiments)")
 PROD_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
 ADE_GATE = 1e-4
 PRECISIONS = ["f32", "f16x3", "f16x2", "f16mx"]
@@ -39,8 +42,8 @@ def get_engine(ctx_dim, wseed, joint, flavour="diag"):
     key = (ctx_dim, wseed, joint, flavour)
     if key not in _ENGINES:
         w = JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), wseed)
-        _ENGINES[key] = (JmidEngine(w, joint=joint, lib_path=PROD_LIB if flavour == "prod" else None), w)
-        assert _ENGINES[key][0]._lib.has_diagnostics == (flavour == "diag")
+        _ENGINES[key] = (JmidEngine(w, joint=joint, lib_path={"prod": PROD_LIB, "exp": EXP_LIB}.get(flavour)), w)
+        assert _ENGINES[key][0]._lib.has_diagnostics == (flavour != "prod")
     return _ENGINES[key]
 
 
@@ -426,12 +429,13 @@ def test_output_kernel_with_fused_next_embedding_is_bit_identical(case, precisio
 @pytest.mark.parametrize("precision", SPLIT_MODES)
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz",
                                   "net_jmid_w256_a7k9t24_s10.npz", "ddpm_jmid_w256_a5k20t12_s10.npz"])
+@needs_experiments
 def test_fused_tail_kernel_is_bit_identical_to_the_three_launches(case, precision):
     """tail_f16x3_kernel (concat3 -> concat4 -> output layer -> DDIM / DDPM update -> next embedding, intermediates in
     LDS) against concat3 GEMM + concat4 GEMM + out_ddim_kernel: same arithmetic in the same order, for both row tiles,
     for the sampling loop and for a single net evaluation (e_theta out, no update)."""
     z = np.load(os.path.join(GOLDEN, case))
-    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]), "exp")
     ddpm = case.startswith("ddpm")
     eng.set_step(int(z["step"]), "ddpm" if ddpm else "ddim")
     kw = {"z": z["z"][:, None]} if ddpm else {}
@@ -510,13 +514,14 @@ def test_linear1_tile_through_lds_is_bit_identical_to_the_elementwise_epilogue()
 
 
 @pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (16, 3, 7, 5), (14, 2, 9, 7)])
+@needs_experiments
 def test_attention_q64_equals_the_two_wave_kernel(E, A, K, T):
     """The one-wave-per-SIMD attention experiment (attn_q64.hpp, knob "attn_q64" = 1: two query blocks per wave, the softmax of tile t
     in the gaps of the matrix instructions of tile t + 1) performs attn_f16x3_dma_kernel's operations in its order: bit-identical
     outputs on S = 1200 (37.5 key tiles, the last wave of a sequence half empty), S = 105 and S = 126 (one 256-query workgroup per
     sequence and head with idle waves, a partial last key tile) - nn.MultiheadAttention inside the encoder layers of
     MID/models/diffusion.py:161-166."""
-    eng, w = get_engine(256, 23, True)
+    eng, w = get_engine(256, 23, True, "exp")
     eng.set_step(4)
     g = torch.Generator().manual_seed(13 + E)
     ctx = torch.randn([E, A, 256], generator=g).cuda()
@@ -536,8 +541,34 @@ def test_attention_q64_equals_the_two_wave_kernel(E, A, K, T):
     assert ade(out[0][:2], ref.numpy()) <= ADE_GATE
 
 
-KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("attn_q64", (1,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
-               ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("tail_fuse", (1,)), ("csl_swap", (2, 3)),
+@needs_experiments
+@pytest.mark.parametrize("precision", SPLIT_MODES)
+@pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (3, 3, 7, 5), (2, 25, 16, 12), (1, 5, 20, 12)])
+def test_attention_pingpong_equals_the_two_wave_kernel(E, A, K, T, precision):
+    """attn_pp_kernel (experiment, knob "attn_pp" = 1: 8-wave workgroups whose two halves alternate between a matrix-instruction segment
+    and a softmax / copy segment across s_barrier, three-stage K / V^T ring; csrc/attn_pp.hpp) issues attn_f16x3_dma_kernel's matrix
+    instructions per accumulator in its order: bit-identical outputs in every split mode, with and without a key split (one scene),
+    on S = 1200, 105, 4800 (dense) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
+    eng, w = get_engine(256, 23, True, "exp")
+    eng.set_step(3)
+    g = torch.Generator().manual_seed(17 + E)
+    ctx = torch.randn([E, A, 256], generator=g).cuda()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    out = {}
+    try:
+        for v in (2, 1):
+            eng.set_tuning("attn_pp", v)
+            out[v] = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
+    finally:
+        eng.set_tuning("attn_pp", 0)
+    np.testing.assert_array_equal(out[1], out[2])
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx[:1].cpu(), x_T[:1].cpu(), sample=K, step=3, joint=True)
+    assert ade(out[1][:1], ref.numpy()) <= ADE_GATE
+
+
+KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
+               ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
                ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,))]
 
