@@ -51,6 +51,23 @@ def test_modes_against_fp64_truth_under_stress(cell):
                 assert not m[mode].get("erange") and m[mode]["ade_vs_fp64_m"] <= 1e-4, (cell, sname, mode, m[mode])
 
 
+@pytest.mark.parametrize("cell", RS.EXTREME_CELLS)
+def test_no_mode_leaves_the_fp16_range_even_at_absurd_weight_scales(cell):
+    """Encoder-layer weights x 16 / x 32 (layer-0 logit spread 300 / 1200 nats - far beyond a trained net; exact fp32 itself is
+    1e-5 ... 1e-4 m from the fp64 truth there): NO mode reports JMID_ERANGE (no expects_erange marker: the autouse fixture fails
+    the test if the exact-fp32 rerun fires), and f16x3 stays inside the gate, as close to the truth as exact fp32 is.  The range
+    cliff the round-4 review asked a per-tensor prescale for does not exist on this net: LayerNorm bounds the residual stream, the
+    weights enter the split planes as W * 2^8 with 2^7 of headroom left, and Q arrives pre-scaled."""
+    rec, _ = _cell(cell)
+    for sname, d in rec["shapes"].items():
+        m = d["modes"]
+        print(cell, sname, {k: ("ERANGE" if v.get("erange") else "%.2e" % v["ade_vs_fp64_m"]) for k, v in m.items()})
+        for mode in RS.MODES:
+            assert not m[mode].get("erange"), (cell, sname, mode)
+        assert m["f16x3"]["ade_vs_fp64_m"] <= 1e-4, (cell, sname, m["f16x3"])
+        assert m["f16x3"]["ade_vs_fp64_m"] <= max(1e-5, 4.0 * m["f32"]["ade_vs_fp64_m"]), (cell, sname, m["f16x3"], m["f32"])
+
+
 @pytest.mark.expects_erange
 @pytest.mark.parametrize("cell", RS.CELLS)
 def test_self_check_downgrades_exactly_where_the_mode_drifts(cell, tmp_path):

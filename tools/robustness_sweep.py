@@ -78,6 +78,9 @@ def make_cell(name, seed=0):
 
 
 CELLS = ("default", "w_x2", "w_x4", "w_x8", "ln_gain", "ln_gain_w_x2", "student_t", "qk_x4", "qk_x8", "qk_x16")
+# far beyond anything a trained net does (layer-0 logit spread 300 / 1200 nats: one-hot attention; exact fp32 itself drifts from fp64):
+# run for ONE question - does an activation leave the fp16 range, i.e. does the JMID_ERANGE -> exact-fp32 rerun (5x the latency) fire?
+EXTREME_CELLS = ("w_x16", "w_x32")
 
 
 def logit_spread(w, ctx, x_T, K):
@@ -158,7 +161,7 @@ def markdown(recs):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
-    ap.add_argument("--cells", default=",".join(CELLS))
+    ap.add_argument("--cells", default=",".join(CELLS + EXTREME_CELLS))
     ap.add_argument("--shapes", default="cfg2,shipped")
     ap.add_argument("--markdown", action="store_true")
     a = ap.parse_args()
