@@ -1,29 +1,43 @@
+// EXPERIMENT (-DJMID_EXPERIMENTS builds, knob "attn_pp" = 1; bit-identical to the shipped kernel, measured NO FASTER - see the end).
+//
 // Head-dim-128 flash attention as an 8-wave PING-PONG: the same arithmetic as attn_f16x3_dma_kernel (attn_f16x3.hpp: transposed
-// formulation, split-fp16 operands, LDS-DMA K / V^T tiles, lazy reference maximum), re-timed.
+// formulation, split-fp16 operands, LDS-DMA K / V^T tiles, lazy reference maximum), re-timed the way the CDNA4 guide describes its
+// tuned 8-wave attention.  The shipped kernel runs two independent 4-wave workgroups per CU; a wave walks QK^T -> softmax -> P.V per
+// key tile in order, and whether its matrix instructions meet the partner wave's softmax or the partner's matrix instructions on
+// their shared SIMD is left to chance (matrix pipes 46 % busy).  Here a workgroup is 8 waves = 256 queries, wave w and wave w + 4
+// share a SIMD, and the key-tile loop is cut into two kinds of segments separated by s_barrier:
 //
-// The two-wave kernel runs two independent 4-wave workgroups per CU; a wave walks QK^T -> softmax -> P.V per key tile in order, and
-// whether its matrix instructions meet the partner wave's softmax or the partner's own matrix instructions on their shared SIMD is
-// left to chance: the matrix pipes are 46 % busy (round 4).  Here a workgroup is 8 waves = 256 queries, wave w and wave w + 4 share a
-// SIMD, and the key-tile loop is cut into two kinds of segments separated by s_barrier:
+//     compute segment   P.V of tile t - 1 and QK^T of tile t: matrix instructions and LDS fragment reads only; the score chain
+//                       (one accumulator, dependent) alternates with the four independent O accumulators
+//     vector  segment   the LDS-DMA copies of later tiles FIRST, softmax of tile t (fp32, lane-local), P packed to fp16, the first
+//                       fragment reads of the coming compute segment, wait for the copies
 //
-//     compute segment   P.V of tile t - 1 and QK^T of tile t: matrix instructions and LDS fragment reads only
-//     vector  segment   softmax of tile t (fp32, lane-local), P packed to fp16, the LDS-DMA copies of later tiles, the first fragment
-//                       reads of the coming compute segment
-//
-// Group 0 (waves 0-3) computes while group 1 (waves 4-7) is in its vector segment and vice versa: a SIMD's matrix pipe always has
-// exactly one wave feeding it, and that wave's stream holds nothing else.  Inside a compute segment the score chain (one accumulator,
-// dependent) alternates with the four independent O accumulators, so no matrix instruction waits for its predecessor.
-//
-//   segment      2t                                  2t + 1
-//   group 0      C: P.V(t-1), QK^T(t)                V: copies K_lo/K8(t+1); softmax(t); pre-read V(t), K(t+1)
-//   group 1      V: copies V(t), K_hi(t+1);          C: P.V(t-1), QK^T(t)
+//   segment      2t                                          2t + 1
+//   group 0      C: P.V(t-1), QK^T(t)                        V: copies (rest of K(t+2)); softmax(t); pre-read V(t), K(t+1)
+//   group 1      V: copies (V(t+1), half of K_hi(t+2));      C: P.V(t-1), QK^T(t)
 //                   softmax(t-1); pre-read V(t-1), K(t)
 //
-// Ring: two stages of K and V^T as before (stage = tile parity).  K(t+1)'s stage last held K(t-1), read for the last time in
-// segment 2t - 1; V(t)'s stage held V(t-2), read for the last time in segment 2t - 1: both copies are legal from segment 2t on and
-// needed from segment 2t + 2 on (K_lo / the bf8 images at the END of a QK^T, so they may be issued one segment later).
-// Per accumulator the matrix instructions are the ones of attn_f16x3_dma_kernel in the same order: results are bit-identical
-// (tools/attn_pp_check.hip, tests/test_gpu_parity.py::test_attention_pingpong_equals_the_two_wave_kernel).
+// Ring: three stages of K and V^T (stage = tile % 3), so that everything a vector segment copies is first read two segments after
+// the barrier that publishes it.  Per accumulator the matrix instructions are the ones of attn_f16x3_dma_kernel in the same order:
+// results are bit-identical in F16MX, F16X2 and F16X3, with and without a key split (tools/attn_pp_check.hip,
+// tests/test_gpu_parity.py::test_attention_pingpong_equals_the_two_wave_kernel).
+//
+// MEASURED (51 sequences of 1 200 tokens, random planes, alternating launches, warm clocks; tools/attn_pp_check.hip):
+//     F16MX 0.272 ms against 0.250 (shipped kernel)    F16X2 0.289 against 0.300    F16X3 0.449 against 0.426
+// and with cycle stamps per kind of segment (-DATT_PP_TRACE; F16MX, cycles per wave and key tile):
+//     compute segment 905-919 (768 of them matrix instructions)   vector segment 960-1 080   wait for the copies 480-500
+//     barrier 510-740   total 3 000-3 160   (shipped kernel, stamped the same way: 2 660)
+// What the stamps say: (1) the segments do what they were built for - a compute segment keeps its SIMD's matrix pipe 84 % busy;
+// (2) the vector segment is as long as the compute segment although it holds ~100 vector instructions: beside a partner that issues
+// matrix instructions back to back a wave gets ~5 of 8 issue slots per 32 cycles (17 v_exp_f32 at four slots + 83 others = 151
+// slots = 966 cycles: the measured number) - the softmax is bound by ISSUE SLOTS, and no placement of it changes their count;
+// (3) an LDS-DMA copy needs ~1 500 cycles from issue to landed under this load (most K / V^T lines come from the Infinity Cache), half
+// a segment more than the vector segment lasts; (4) deferring the wait to the end of the wave's NEXT compute segment - what the third
+// ring stage was built for (-DATT_PP_LATE_WAIT) - makes that compute segment 1 667 cycles long: a wave's LDS reads stall while its own
+// LDS-DMA copies are in flight, so the copies can only be issued by a wave that reads no LDS until they land.  With no copies at all
+// in the loop (-DATT_PP_NO_DMA, wrong results) a tile still takes 2 470-2 600 cycles: two serialised segments of ~960 plus ~250
+// per barrier.  The shipped kernel's 2 660 cycles per tile is within 8 % of what this structure can reach; what would move both is
+// fewer vector instructions per key (docs/NOTEBOOK.md section 10).
 #pragma once
 
 namespace jmid {
@@ -360,9 +374,15 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(AttnHArgs a, int nqt) {
 #else
 #define PP_STAMP(i)
 #endif
-    auto bar = [&](bool landed) {
-#ifdef ATT_PP_EARLY_WAIT
-        landed = !landed;
+    // closes a segment.  `after_compute`: the barrier behind a compute segment (or the prologue).  A wave's copies are waited for at
+    // the end of the VECTOR segment that issued them: deferring the wait to the end of the wave's next compute segment
+    // (-DATT_PP_LATE_WAIT; the ring has the third stage for it) lengthens that compute segment from 905 to 1 667 cycles - a wave's LDS
+    // reads stall while its own LDS-DMA copies are in flight (tools/attn_pp_check.hip -DATT_PP_TRACE, docs/NOTEBOOK.md section 10)
+    auto bar = [&](bool after_compute) {
+#ifdef ATT_PP_LATE_WAIT
+        const bool landed = after_compute;
+#else
+        const bool landed = !after_compute;
 #endif
         if (landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's copies have landed ...
         PP_STAMP(2)
@@ -401,11 +421,10 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(AttnHArgs a, int nqt) {
     // the 40 waves of a (sequence, head)) copies its share of every tile and meets every barrier, nothing else.  The first tile
     // (no P.V yet) is peeled off so that the loop body holds ONE form of each segment: with a run-time "first tile" test in it the
     // compiler merges the two forms by copying the 64 O accumulators at the top of every segment.
-    // Copies are WAITED FOR at the end of the issuing wave's NEXT (compute) segment - two segments of flight instead of one: with the
-    // wait at the end of the issuing vector segment a wave stood 350-500 cycles per tile (tools/attn_pp_check.hip -DATT_PP_TRACE).
     using I2 = std::integral_constant<int, 2>;
     auto run = [&](auto act_c) {
         constexpr bool ACT = decltype(act_c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the prologue's copies
         bar(true);
         if (grp == 0) {
             // group 0, tile t (stage s = t % 3):  C(t) = P.V(t-1) [stage s+2], QK^T(t) [s]
