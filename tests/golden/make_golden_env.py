@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Golden captures for the CrowdSimPlus semantics around the episode generator: static obstacles,
+hallway placement with door sub-goals, wall-constrained actions, step outcomes / rewards / termination - generated from
+the REFERENCE'S OWN LINES.
+
+CrowdSimPlus cannot be imported here (gym and rvo2 are absent).  What it computes in plain Python / NumPy can still be
+executed: this script reads line ranges of /root/reference/crowd_sim_plus/envs at run time, wraps them into functions and
+runs them against stand-in objects (a robot / human record, a config); the reference's own helper modules
+(utils/utils_plus.py, utils/action.py, utils/info_plus.py) are executed as they are.  Only inputs and what those lines
+produced are stored (tests/golden/env_*.npz): nothing of the reference's text is written to the repo.
+
+    crowd_sim_plus.py:322-421    generate_static_obstacles: wall / door segments of every rule, door geometry
+    utils/human_plus.py:19-79    Human.get_g_xy / set_g_xy / set: the door sub-goal of the hallway_static* / bottleneck rules
+    crowd_sim_plus.py:522-607    generate_hallway_human: placement with its draw order, rejection against robot, humans, walls
+    crowd_sim_plus.py:869-989    constrain_agent_action_exact: an action cut short at walls and wall ends
+    crowd_sim_plus.py:1067-1166  step(): collision / frozen / goal / timeout detection and the reward terms
+
+Run in the build container:  python tests/golden/make_golden_env.py
+"""
+import os
+import textwrap
+import types
+
+import numpy as np
+
+REF = "/root/reference/crowd_sim_plus/envs"
+OUT = os.path.dirname(os.path.abspath(__file__))
+RULES = ["hallway", "hallway_static", "hallway_static_with_back", "hallway_bottleneck", "hallway_squeeze", "rectangle", "left_wall"]
+
+
+def ref_lines(path, lo, hi):
+    with open(os.path.join(REF, path)) as f:
+        lines = f.readlines()[lo - 1:hi]
+    return textwrap.dedent("".join(lines))
+
+
+def ref_namespace():
+    """The reference's helper modules, executed (not copied): geometry helpers, action tuples, info records."""
+    ns = dict(np=np, norm=np.linalg.norm)
+    for mod in ("utils/utils_plus.py", "utils/action.py", "utils/info_plus.py"):
+        exec(compile(open(os.path.join(REF, mod)).read(), mod, "exec"), ns)
+    from copy import deepcopy
+    ns["deepcopy"] = deepcopy
+    return ns
+
+
+def make_functions():
+    ns = ref_namespace()
+    # Human: the reference's door-sub-goal methods on a bare record (the real class pulls in the policy factory)
+    human_src = ("class Human:\n"
+                 "    def __init__(self, config, section, fully_observable=False, env=None):\n"
+                 "        self.radius = config.getfloat(section, 'radius')\n"
+                 "        self.v_pref = config.getfloat(section, 'v_pref')\n"
+                 "        self.env = env\n"
+                 "        self.px = self.py = self.gx = self.gy = None\n"
+                 + textwrap.indent(ref_lines("utils/human_plus.py", 19, 79), "    "))
+    exec(human_src, ns)
+    exec("def generate_static_obstacles(self, rule, static_obstacles=None):\n"
+         + textwrap.indent(ref_lines("crowd_sim_plus.py", 329, 421), "    "), ns)
+    exec("def generate_hallway_human(self, rng):\n" + textwrap.indent(ref_lines("crowd_sim_plus.py", 523, 607), "    "), ns)
+    exec("def constrain_agent_action_exact(self, agent, action):\n"
+         + textwrap.indent(ref_lines("crowd_sim_plus.py", 876, 989), "    "), ns)
+    exec("def step_outcome(self, action, human_actions, stat_collision, update):\n"
+         + textwrap.indent(ref_lines("crowd_sim_plus.py", 1067, 1166), "    ")
+         + "\n    return reward, done, info, dmin, collision, frozen_robot, reached_goal, curr_dist_to_goal\n", ns)
+    return ns
+
+
+class Config:
+    def __init__(self, human_radius=0.20, human_v_pref=1.5, policy="orca_plus"):
+        self.d = {("humans", "radius"): human_radius, ("humans", "v_pref"): human_v_pref, ("humans", "policy"): policy}
+
+    def get(self, s, k):
+        return self.d[(s, k)]
+
+    def getfloat(self, s, k):
+        return float(self.d[(s, k)])
+
+
+class Agent:
+    """position / goal / radius record with the holonomic kinematics of utils/agent_plus.py:175-185"""
+    kinematics = "holonomic"
+
+    def __init__(self, px, py, gx, gy, radius, time_step=0.25):
+        self.px, self.py, self.gx, self.gy, self.radius, self.time_step = px, py, gx, gy, radius, time_step
+
+    def compute_position(self, action, dt):
+        return self.px + action.vx * dt, self.py + action.vy * dt
+
+    def get_goal_position(self):
+        return self.gx, self.gy
+
+
+def make_env(ns, rule, circle_radius=1.0, rect_width=1.75, rect_height=4.0, robot_radius=0.25, discomfort=0.2,
+             randomize=True, cfg=None):
+    env = types.SimpleNamespace(circle_radius=circle_radius, rect_width=rect_width, rect_height=rect_height,
+                                robot=Agent(0.0, -circle_radius, 0.0, circle_radius, robot_radius),
+                                config=cfg or Config(), human_observability=None, randomize_attributes=randomize,
+                                rewards={"discomfort_dist": discomfort}, humans=[], sim_env=rule, static_obstacles=[])
+    ns["generate_static_obstacles"](env, rule)
+    return env
+
+
+def door_fields(env):
+    keys = ("door_y_max", "door_y_min", "door_x_mid", "door_y_mid_max", "door_y_mid_min", "door_width")
+    return {k: float(getattr(env, k, np.nan)) for k in keys}
+
+
+def capture_static_obstacles(ns):
+    out = {}
+    for tag, geo in {"shipped": dict(circle_radius=1.0, rect_width=1.75, rect_height=4.0, robot_radius=0.25),
+                     "wide": dict(circle_radius=4.0, rect_width=6.0, rect_height=8.0, robot_radius=0.3)}.items():
+        for rule in RULES:
+            env = make_env(ns, rule, **geo)
+            out[f"{tag}__{rule}__segments"] = np.array(env.static_obstacles, dtype=np.float64).reshape(-1, 2, 2)
+            out[f"{tag}__{rule}__doors"] = np.array(list(door_fields(env).values()))
+        out[f"{tag}__geometry"] = np.array([geo["circle_radius"], geo["rect_width"], geo["rect_height"], geo["robot_radius"]])
+    np.savez(os.path.join(OUT, "env_static_obstacles.npz"), **out)
+    print("static obstacles", len(out))
+
+
+def capture_hallway_placement(ns, tag, rule, n_humans, seed, randomize=True, **geo):
+    env = make_env(ns, rule, randomize=randomize, **geo)
+    rng = np.random.default_rng(seed)
+    for _ in range(n_humans):                       # crowd_sim_plus.py:444-447
+        env.humans.append(ns["generate_hallway_human"](env, rng))
+    hs = env.humans
+    np.savez(os.path.join(OUT, f"env_hallway_placement_{tag}.npz"), rule=rule, n_humans=n_humans, seed=seed, randomize=randomize,
+             geometry=np.array([env.circle_radius, env.rect_width, env.rect_height, env.robot.radius]),
+             human_radius=hs[0].radius, human_v_pref=env.config.getfloat("humans", "v_pref"),
+             discomfort_dist=env.rewards["discomfort_dist"],
+             pos=np.array([[h.px, h.py] for h in hs]), final_goal=np.array([[h.final_gx, h.final_gy] for h in hs]),
+             goal=np.array([[h.gx, h.gy] for h in hs]),            # after set(): the door sub-goal where one applies
+             v_pref=np.array([h.v_pref for h in hs]), theta=np.array([h.theta for h in hs]), rng_next=rng.random(4))
+    print("hallway placement", tag, rule, n_humans)
+
+
+def capture_door_subgoals(ns):
+    """Human.get_g_xy over a grid of positions and goals, every rule."""
+    rng = np.random.default_rng(3)
+    out = {}
+    for rule in RULES:
+        env = make_env(ns, rule)
+        h = ns["Human"](env.config, "humans", env=env)
+        pts, goals, got = [], [], []
+        for _ in range(400):
+            px, py = rng.uniform(-0.9, 0.9), rng.uniform(-4.0, 4.0)
+            gx, gy = rng.uniform(-0.9, 0.9), rng.uniform(-4.0, 4.0)
+            if rng.random() < 0.2:
+                px, py = rng.normal(0.0, 0.3), rng.normal(0.0, 0.3)     # around the door centre: the switch back to the final goal
+            h.final_gx, h.final_gy = gx, gy
+            pts.append((px, py)); goals.append((gx, gy)); got.append(h.get_g_xy(px, py))
+        out[f"{rule}__pos"], out[f"{rule}__final_goal"], out[f"{rule}__goal"] = np.array(pts), np.array(goals), np.array(got)
+    np.savez(os.path.join(OUT, "env_door_subgoals.npz"), **out)
+    print("door sub-goals", len(out))
+
+
+def capture_constrained_actions(ns, tag, rule, n, seed, radius=0.21, time_step=0.25, **geo):
+    """constrain_agent_action_exact for n random (position, action) pairs; a share of them placed within a step of a wall or a
+    wall end so that every branch runs (free, mid-segment, end point, already touching, heading straight at an end)."""
+    env = make_env(ns, rule, **geo)
+    segs = np.array(env.static_obstacles, dtype=np.float64).reshape(-1, 2, 2)
+    rng = np.random.default_rng(seed)
+    A = ns["ActionXY"]
+    pos, act, got = [], [], []
+    while len(pos) < n:
+        kind = rng.integers(0, 5)
+        s = segs[rng.integers(0, len(segs))]
+        d = s[1] - s[0]
+        nrm = np.array([-d[1], d[0]]) / np.linalg.norm(d)
+        if kind == 0:          # anywhere
+            p = np.array([rng.uniform(-env.rect_width, env.rect_width), rng.uniform(-env.rect_height, env.rect_height)])
+            v = rng.uniform(-1.5, 1.5, 2)
+        elif kind == 1:        # next to the middle of a wall, moving at it
+            p = s[0] + rng.uniform(0.1, 0.9) * d + nrm * rng.choice([-1, 1]) * rng.uniform(radius + 1e-6, radius + 0.3)
+            v = rng.uniform(-1.5, 1.5, 2)
+        elif kind == 2:        # next to a wall end
+            e = s[rng.integers(0, 2)]
+            ang = rng.uniform(0, 2 * np.pi)
+            p = e + rng.uniform(radius + 1e-6, radius + 0.35) * np.array([np.cos(ang), np.sin(ang)])
+            v = rng.uniform(-1.5, 1.5, 2)
+        elif kind == 3:        # heading straight at a wall end
+            e = s[rng.integers(0, 2)]
+            ang = rng.uniform(0, 2 * np.pi)
+            p = e + rng.uniform(radius + 0.01, radius + 0.3) * np.array([np.cos(ang), np.sin(ang)])
+            v = (e - p) / np.linalg.norm(e - p) * rng.uniform(0.3, 1.5)
+        else:                  # touching a wall already (what the previous constrained step leaves behind: radius + 1e-7)
+            p = s[0] + rng.uniform(0.1, 0.9) * d + nrm * rng.choice([-1, 1]) * (radius + 1e-7)
+            v = rng.uniform(-1.5, 1.5, 2)
+        # the reference never starts inside a wall: skip positions closer than the radius to any segment
+        if min(ns["point_to_segment_dist"](q[0][0], q[0][1], q[1][0], q[1][1], p[0], p[1]) for q in segs) < radius:
+            continue
+        agent = Agent(float(p[0]), float(p[1]), 0.0, 0.0, radius, time_step)
+        try:
+            c = ns["constrain_agent_action_exact"](env, agent, A(float(v[0]), float(v[1])))
+        except AssertionError:         # (the reference asserts on its own degenerate triangles: not a case to pin)
+            continue
+        pos.append(p); act.append(v); got.append((c.vx, c.vy))
+    np.savez(os.path.join(OUT, f"env_constrain_{tag}.npz"), rule=rule, radius=radius, time_step=time_step, segments=segs,
+             geometry=np.array([env.circle_radius, env.rect_width, env.rect_height, env.robot.radius]),
+             pos=np.array(pos), action=np.array(act), constrained=np.array(got))
+    changed = int((np.abs(np.array(got) - np.array(act)).max(axis=1) > 0).sum())
+    print("constrained actions", tag, rule, n, "changed:", changed)
+
+
+INFO_KEYS = ("ReachGoal", "Timeout", "Collision", "WallCollision", "Frozen", "Danger", "Progress", "AngularSmoothness", "LinearSmoothness")
+
+
+def capture_step_outcomes(ns, tag, n, seed, rewards, detailed):
+    """The outcome block of step() for n random situations of one robot and three humans."""
+    rng = np.random.default_rng(seed)
+    A = ns["ActionXY"]
+    rec = {k: [] for k in ("robot", "robot_action", "humans", "human_actions", "human_radius", "global_time", "stat_collision",
+                           "prev_dist", "prev_angular", "prev_linear", "reward", "done", "dmin", "collision", "frozen", "reached",
+                           "curr_dist", "info_vals", "info_present", "next_prev_dist", "next_prev_angular", "next_prev_linear")}
+    time_limit, time_step = 30.0, 0.25
+    for i in range(n):
+        kind = rng.integers(0, 6)
+        goal = np.array([0.0, 1.0])
+        p = rng.uniform(-1.5, 1.5, 2)
+        v = rng.uniform(-1.0, 1.0, 2)
+        if kind == 1:      # about to reach the goal
+            p = goal - v * time_step + rng.normal(0, 0.1, 2)
+        if kind == 2:      # frozen
+            v = rng.normal(0, 0.02, 2)
+        hp = rng.uniform(-2.0, 2.0, (3, 2))
+        hv = rng.uniform(-1.0, 1.0, (3, 2))
+        hr = rng.uniform(0.18, 0.3, 3)
+        if kind == 3:      # a human ends the step on top of the robot
+            hp[1] = p + v * time_step - hv[1] * time_step + rng.normal(0, 0.15, 2)
+        if kind == 4:      # inside the discomfort distance
+            ang = rng.uniform(0, 2 * np.pi)
+            hp[2] = p + v * time_step - hv[2] * time_step + (0.25 + hr[2] + rng.uniform(0.0, 0.25)) * np.array([np.cos(ang), np.sin(ang)])
+        gt = float(rng.choice([rng.uniform(0, 29.0), 30.0, 30.25])) if kind == 5 else float(rng.uniform(0, 29.0))
+        robot = Agent(float(p[0]), float(p[1]), float(goal[0]), float(goal[1]), 0.25, time_step)
+        humans = [Agent(float(hp[j, 0]), float(hp[j, 1]), 0.0, 0.0, float(hr[j]), time_step) for j in range(3)]
+        first = rng.random() < 0.2
+        env = types.SimpleNamespace(robot=robot, humans=humans, time_step=time_step, global_time=gt, time_limit=time_limit,
+                                    rewards=dict(rewards), detailed_reward_return=detailed, robot_goal_pos=goal.copy(),
+                                    robot_prev_dist_to_goal=float(np.linalg.norm(goal - p) + rng.normal(0, 0.05)),
+                                    prev_action_angular=None if first else float(rng.uniform(-np.pi, np.pi)),
+                                    prev_action_linear=None if first else float(rng.uniform(0, 1.0)))
+        stat = bool(rng.random() < 0.15)
+        pd, pa, pl = env.robot_prev_dist_to_goal, env.prev_action_angular, env.prev_action_linear
+        r, done, info, dmin, coll, frozen, reached, cd = ns["step_outcome"](
+            env, A(float(v[0]), float(v[1])), [A(float(hv[j, 0]), float(hv[j, 1])) for j in range(3)], stat, True)
+        rec["robot"].append([p[0], p[1], goal[0], goal[1], 0.25]); rec["robot_action"].append(v)
+        rec["humans"].append(hp); rec["human_actions"].append(hv); rec["human_radius"].append(hr)
+        rec["global_time"].append(gt); rec["stat_collision"].append(stat)
+        rec["prev_dist"].append(pd); rec["prev_angular"].append(np.nan if pa is None else pa)
+        rec["prev_linear"].append(np.nan if pl is None else pl)
+        rec["reward"].append(r); rec["done"].append(done); rec["dmin"].append(dmin); rec["collision"].append(coll)
+        rec["frozen"].append(bool(frozen)); rec["reached"].append(bool(reached)); rec["curr_dist"].append(cd)
+        rec["info_vals"].append([float(info[k].val) if k in info else 0.0 for k in INFO_KEYS])
+        rec["info_present"].append([k in info and (k in ("Progress",) or float(info[k].val) != 0.0 or k in ("AngularSmoothness", "LinearSmoothness")) for k in INFO_KEYS])
+        rec["next_prev_dist"].append(env.robot_prev_dist_to_goal)
+        rec["next_prev_angular"].append(np.nan if env.prev_action_angular is None else env.prev_action_angular)
+        rec["next_prev_linear"].append(np.nan if env.prev_action_linear is None else env.prev_action_linear)
+    np.savez(os.path.join(OUT, f"env_step_outcomes_{tag}.npz"), time_limit=time_limit, time_step=time_step, detailed=detailed,
+             reward_keys=np.array(sorted(rewards)), reward_vals=np.array([float(rewards[k]) for k in sorted(rewards)]),
+             info_keys=np.array(INFO_KEYS), **{k: np.array(v) for k, v in rec.items()})
+    print("step outcomes", tag, n, "done:", int(np.sum(rec["done"])), "collisions:", int(np.sum(rec["collision"])),
+          "reached:", int(np.sum(rec["reached"])), "frozen:", int(np.sum(rec["frozen"])))
+
+
+if __name__ == "__main__":
+    ns = make_functions()
+    capture_static_obstacles(ns)
+    capture_door_subgoals(ns)
+    capture_hallway_placement(ns, "shipped_n3", "hallway", 3, 31)                       # env.config: hallway, 3 humans
+    capture_hallway_placement(ns, "static_n5", "hallway_static", 5, 32)                 # door sub-goals enter the goal test
+    capture_hallway_placement(ns, "bottleneck_n8", "hallway_bottleneck", 8, 33)         # crowded: the effective height grows
+    capture_hallway_placement(ns, "squeeze_n4_fixed", "hallway_squeeze", 4, 34, randomize=False)
+    capture_constrained_actions(ns, "hallway", "hallway", 300, 41)
+    capture_constrained_actions(ns, "static", "hallway_static", 500, 42)
+    capture_constrained_actions(ns, "squeeze", "hallway_squeeze", 300, 43)
+    capture_constrained_actions(ns, "rectangle", "rectangle", 200, 44, circle_radius=4.0, rect_width=6.0, rect_height=8.0)
+    # the shipped [reward] section (env.config:66-71) as configure() leaves it for non-RL testing (crowd_sim_plus.py:110-128)
+    shipped = {"success_reward": 1.0, "collision_penalty": -0.25, "freezing_penalty": -0.125, "discomfort_dist": 0.2,
+               "discomfort_penalty_factor": 0.5, "discomfort": True, "timeout": -1.0, "wall_collision_penalty": -1.0}
+    capture_step_outcomes(ns, "shipped", 400, 51, shipped, False)
+    full = dict(shipped, progress_factor=0.1, angular_smoothness_factor=-0.01, linear_smoothness_factor=-0.02)
+    capture_step_outcomes(ns, "all_terms", 400, 52, full, True)
