@@ -159,3 +159,192 @@ def new_velocity(pos: Vec, vel: Vec, radius: float, pref: Vec, max_speed: float,
     if fail < len(lines):
         result = linear_program3(lines, fail, max_speed, result)
     return result
+
+
+# ------------------------------------------------------------------------------------------------ static obstacles
+# RVO2's obstacle half-planes (``Agent::computeNewVelocity``, first loop) for the walls ``ORCAPlus.predict`` hands to rvo2
+# (``crowd_sim_plus/envs/policy/orca_plus.py:52-55``: one ``addObstacle(line)`` per wall segment, then ``processObstacles()``).
+# A two-vertex obstacle is a closed polygon of two vertices: the directed edges A -> B and B -> A, both vertices convex; an agent
+# sees the edge it is on the RIGHT of.  PARITY UNPINNED like everything else in this file (rvo2 is absent).  Not restated: the
+# k-d tree of ``processObstacles``, which only accelerates the neighbour query - and may cut an edge in two at a splitting line,
+# which adds a (convex, collinear) vertex in the middle of a wall; the half-planes of the two halves describe the same wall.
+
+def _sub(a: Vec, b: Vec) -> Vec:
+    return (a[0] - b[0], a[1] - b[1])
+
+
+def _normalize(a: Vec) -> Vec:
+    n = math.sqrt(dot(a, a))
+    return (a[0] / n, a[1] / n)
+
+
+def _dist_sq_point_segment(a: Vec, b: Vec, c: Vec) -> float:
+    ab = _sub(b, a)
+    r = dot(_sub(c, a), ab) / dot(ab, ab)
+    if r < 0.0:
+        return dot(_sub(c, a), _sub(c, a))
+    if r > 1.0:
+        return dot(_sub(c, b), _sub(c, b))
+    q = (a[0] + r * ab[0], a[1] + r * ab[1])
+    return dot(_sub(c, q), _sub(c, q))
+
+
+def obstacle_neighbors(pos: Vec, radius: float, max_speed: float, segments: Sequence[Tuple[Vec, Vec]], time_horizon_obst: float):
+    """The directed edges (p1, p2) an agent considers: closer than time_horizon_obst * max_speed + radius, agent on their right
+    side; nearest first (``computeObstacleNeighbors`` / ``insertObstacleNeighbor``)."""
+    range_sq = (time_horizon_obst * max_speed + radius) ** 2
+    out = []
+    for a, b in segments:
+        for p1, p2 in ((a, b), (b, a)):
+            left_of = det(_sub(p1, pos), _sub(p2, p1))
+            if left_of < 0.0 and left_of * left_of / dot(_sub(p2, p1), _sub(p2, p1)) < range_sq:
+                d = _dist_sq_point_segment(p1, p2, pos)
+                if d < range_sq:
+                    out.append((d, p1, p2))
+    out.sort(key=lambda t: t[0])          # (stable: equal distances keep the insertion order, as insertObstacleNeighbor does)
+    return [(p1, p2) for _, p1, p2 in out]
+
+
+def obstacle_orca_lines(pos: Vec, vel: Vec, radius: float, max_speed: float, segments: Sequence[Tuple[Vec, Vec]],
+                        time_horizon_obst: float) -> List[Line]:
+    """Half-planes that keep the agent clear of the walls for ``time_horizon_obst`` seconds."""
+    inv_t = 1.0 / time_horizon_obst
+    lines: List[Line] = []
+    for p1, p2 in obstacle_neighbors(pos, radius, max_speed, segments, time_horizon_obst):
+        # vertex 1 = p1 (edge direction u1 = p1 -> p2), vertex 2 = p2 (its own edge runs back: u2 = p2 -> p1); both convex;
+        # vertex 1's previous vertex is vertex 2
+        u1 = _normalize(_sub(p2, p1))
+        u2 = (-u1[0], -u1[1])
+        o1, o2 = p1, p2
+        rp1, rp2 = _sub(o1, pos), _sub(o2, pos)
+        covered = False
+        for lp, ld in lines:
+            if det(_sub((inv_t * rp1[0], inv_t * rp1[1]), lp), ld) - inv_t * radius >= -RVO_EPSILON and \
+                    det(_sub((inv_t * rp2[0], inv_t * rp2[1]), lp), ld) - inv_t * radius >= -RVO_EPSILON:
+                covered = True
+                break
+        if covered:
+            continue
+        d1, d2, r_sq = dot(rp1, rp1), dot(rp2, rp2), radius * radius
+        ov = _sub(o2, o1)
+        s = dot((-rp1[0], -rp1[1]), ov) / dot(ov, ov)
+        q = (-rp1[0] - s * ov[0], -rp1[1] - s * ov[1])
+        d_line = dot(q, q)
+        if s < 0.0 and d1 <= r_sq:                       # collision with the left vertex
+            lines.append(((0.0, 0.0), _normalize((-rp1[1], rp1[0]))))
+            continue
+        if s > 1.0 and d2 <= r_sq:                       # collision with the right vertex (unless its own edge takes care of it)
+            if det(rp2, u2) >= 0.0:
+                lines.append(((0.0, 0.0), _normalize((-rp2[1], rp2[0]))))
+            continue
+        if 0.0 <= s < 1.0 and d_line <= r_sq:            # collision with the segment
+            lines.append(((0.0, 0.0), (-u1[0], -u1[1])))
+            continue
+        same = False                                      # both legs from one vertex (the edge is seen obliquely)
+        if s < 0.0 and d_line <= r_sq:
+            o2, rp2, d2, same = o1, rp1, d1, True
+            leg = math.sqrt(d1 - r_sq)
+            left = ((rp1[0] * leg - rp1[1] * radius) / d1, (rp1[0] * radius + rp1[1] * leg) / d1)
+            right = ((rp1[0] * leg + rp1[1] * radius) / d1, (-rp1[0] * radius + rp1[1] * leg) / d1)
+            u_right_vertex = u1                           # "obstacle2" IS obstacle1 now: its direction is u1
+        elif s > 1.0 and d_line <= r_sq:
+            o1, rp1, d1, same = o2, rp2, d2, True
+            leg = math.sqrt(d2 - r_sq)
+            left = ((rp2[0] * leg - rp2[1] * radius) / d2, (rp2[0] * radius + rp2[1] * leg) / d2)
+            right = ((rp2[0] * leg + rp2[1] * radius) / d2, (-rp2[0] * radius + rp2[1] * leg) / d2)
+            u_right_vertex = u2
+        else:
+            leg1, leg2 = math.sqrt(d1 - r_sq), math.sqrt(d2 - r_sq)
+            left = ((rp1[0] * leg1 - rp1[1] * radius) / d1, (rp1[0] * radius + rp1[1] * leg1) / d1)
+            right = ((rp2[0] * leg2 + rp2[1] * radius) / d2, (-rp2[0] * radius + rp2[1] * leg2) / d2)
+            u_right_vertex = u2
+        # "obstacle1" after the oblique cases: its direction and its previous vertex's direction
+        if same and o1 is p2:
+            u_o1, u_prev = u2, u1                         # vertex 2: edge back to p1; previous vertex is vertex 1
+        else:
+            u_o1, u_prev = u1, u2
+        left_foreign = right_foreign = False
+        if det(left, (-u_prev[0], -u_prev[1])) >= 0.0:    # the left leg points into the neighbouring edge: take that edge's line
+            left, left_foreign = (-u_prev[0], -u_prev[1]), True
+        if det(right, u_right_vertex) <= 0.0:
+            right, right_foreign = u_right_vertex, True
+        lc = (inv_t * (o1[0] - pos[0]), inv_t * (o1[1] - pos[1]))
+        rc = (inv_t * (o2[0] - pos[0]), inv_t * (o2[1] - pos[1]))
+        cv = _sub(rc, lc)
+        t = 0.5 if same else dot(_sub(vel, lc), cv) / dot(cv, cv)
+        t_left, t_right = dot(_sub(vel, lc), left), dot(_sub(vel, rc), right)
+        if (t < 0.0 and t_left < 0.0) or (same and t_left < 0.0 and t_right < 0.0):
+            uw = _normalize(_sub(vel, lc))
+            lines.append(((lc[0] + radius * inv_t * uw[0], lc[1] + radius * inv_t * uw[1]), (uw[1], -uw[0])))
+            continue
+        if t > 1.0 and t_right < 0.0:
+            uw = _normalize(_sub(vel, rc))
+            lines.append(((rc[0] + radius * inv_t * uw[0], rc[1] + radius * inv_t * uw[1]), (uw[1], -uw[0])))
+            continue
+        inf = float("inf")
+        if t < 0.0 or t > 1.0 or same:
+            dsq_cut = inf
+        else:
+            c = _sub(vel, (lc[0] + t * cv[0], lc[1] + t * cv[1]))
+            dsq_cut = dot(c, c)
+        if t_left < 0.0:
+            dsq_left = inf
+        else:
+            c = _sub(vel, (lc[0] + t_left * left[0], lc[1] + t_left * left[1]))
+            dsq_left = dot(c, c)
+        if t_right < 0.0:
+            dsq_right = inf
+        else:
+            c = _sub(vel, (rc[0] + t_right * right[0], rc[1] + t_right * right[1]))
+            dsq_right = dot(c, c)
+        if dsq_cut <= dsq_left and dsq_cut <= dsq_right:
+            d = (-u_o1[0], -u_o1[1])
+            lines.append(((lc[0] + radius * inv_t * -d[1], lc[1] + radius * inv_t * d[0]), d))
+        elif dsq_left <= dsq_right:
+            if not left_foreign:
+                lines.append(((lc[0] + radius * inv_t * -left[1], lc[1] + radius * inv_t * left[0]), left))
+        else:
+            if not right_foreign:
+                d = (-right[0], -right[1])
+                lines.append(((rc[0] + radius * inv_t * -d[1], rc[1] + radius * inv_t * d[0]), d))
+    return lines
+
+
+def linear_program3_obst(lines: Sequence[Line], num_obst: int, begin_line: int, radius: float, result: Vec) -> Vec:
+    """``linearProgram3`` with obstacle half-planes: the first ``num_obst`` lines stay hard constraints of every projected program."""
+    distance = 0.0
+    for i in range(begin_line, len(lines)):
+        pi, di = lines[i]
+        if det(di, (pi[0] - result[0], pi[1] - result[1])) > distance:
+            proj: List[Line] = list(lines[:num_obst])
+            for j in range(num_obst, i):
+                pj, dj = lines[j]
+                determinant = det(di, dj)
+                if abs(determinant) <= RVO_EPSILON:
+                    if dot(di, dj) > 0.0:
+                        continue
+                    point = (0.5 * (pi[0] + pj[0]), 0.5 * (pi[1] + pj[1]))
+                else:
+                    t = det(dj, (pi[0] - pj[0], pi[1] - pj[1])) / determinant
+                    point = (pi[0] + t * di[0], pi[1] + t * di[1])
+                dd = (dj[0] - di[0], dj[1] - di[1])
+                n = math.sqrt(dot(dd, dd))
+                proj.append((point, (dd[0] / n, dd[1] / n)))
+            fail, r = linear_program2(proj, radius, (-di[1], di[0]), True)
+            if fail >= len(proj):
+                result = r
+            distance = det(di, (pi[0] - result[0], pi[1] - result[1]))
+    return result
+
+
+def new_velocity_with_obstacles(pos: Vec, vel: Vec, radius: float, pref: Vec, max_speed: float,
+                                others: Sequence[Tuple[Vec, Vec, float]], segments: Sequence[Tuple[Vec, Vec]],
+                                time_horizon: float = 2.0, time_horizon_obst: float = 0.5, time_step: float = 0.25):
+    """One agent's ORCA velocity among other agents and walls (``Agent::computeNewVelocity``).  -> (velocity, number of obstacle lines)"""
+    lines = obstacle_orca_lines(pos, vel, radius, max_speed, segments, time_horizon_obst)
+    n_obst = len(lines)
+    lines = lines + orca_lines(pos, vel, radius, others, time_horizon, time_step)
+    fail, result = linear_program2(lines, max_speed, pref, False)
+    if fail < len(lines):
+        result = linear_program3_obst(lines, n_obst, fail, max_speed, result)
+    return result, n_obst

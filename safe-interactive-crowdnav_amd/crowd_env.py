@@ -12,7 +12,7 @@ simulator and the MPC live):
   ``place_hallway_humans``    ``generate_hallway_human``            ``crowd_sim_plus.py:522-607``   placement, with the draw order
   ``constrain_actions``       ``constrain_agent_action_exact``      ``crowd_sim_plus.py:869-989``   an action cut short at a wall
   ``step_outcomes``           the outcome block of ``step()``       ``crowd_sim_plus.py:1067-1166`` flags, reward terms, done
-  ``orca_plus_parameters``    what ``ORCAPlus.predict`` hands rvo2  ``policy/orca_plus.py:46-84``
+  ``orca_plus_parameters``    what ``ORCAPlus.predict`` hands rvo2  ``policy/orca_plus.py:43-84``
   ``obstacle_orca_lines``     RVO2's obstacle half-planes           RVO2 Library 2.0.2 ``Agent::computeNewVelocity``
 
 PARITY.  Everything in the first six rows is plain Python / NumPy in the reference and is pinned by fixtures that
@@ -429,3 +429,271 @@ def step_outcomes(robot_pos, robot_action, robot_goal, robot_radius, human_pos, 
     return dict(collision=collision, dmin=dmin, frozen=frozen, reached_goal=reached, timeout=timeout, done=done, reward=reward,
                 curr_dist_to_goal=curr_dist, info=info, next_prev_dist=next_dist, next_prev_angular=next_ang,
                 next_prev_linear=next_lin)
+
+
+# ------------------------------------------------------------------------------------------------ ORCA with walls (orca_plus)
+RVO_EPSILON = 0.00001
+
+
+def _det(a, b):
+    return a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]
+
+
+def _dot(a, b):
+    return a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]
+
+
+def orca_plus_parameters(pos, goal, radius, v_pref, safety_space: float = 0.05, time_step: float = 0.25) -> Dict[str, np.ndarray]:
+    """What ``ORCAPlus.predict`` hands to rvo2 for an agent's step (``policy/orca_plus.py:43-84``; parameters of ``orca.py:56-67``,
+    radius and safety space from ``[humans]`` through ``ORCAPlus.configure``): the inflated radius, the ego's speed limit (its
+    v_pref), the preferred velocity - goal minus position, capped at v_pref - 1e-3 (NOT at 1 as plain ORCA does) - and the scalars.
+    Arrays of any leading shape.  Pinned by ``tests/golden/env_orca_plus_calls_*.npz``."""
+    to_goal = np.asarray(goal, np.float64) - np.asarray(pos, np.float64)
+    speed = _norm(to_goal)
+    cap = np.asarray(v_pref, np.float64) - 1e-3
+    with np.errstate(invalid="ignore", divide="ignore"):
+        pref = np.where((speed > cap)[..., None], to_goal / speed[..., None] * cap[..., None], to_goal)
+    return dict(radius=np.asarray(radius, np.float64) + 0.01 + safety_space, max_speed=np.asarray(v_pref, np.float64), pref=pref,
+                neighbor_dist=10.0, max_neighbors=10, time_horizon=2.0, time_horizon_obst=0.5, time_step=time_step,
+                default_radius=0.20, default_max_speed=1.0)
+
+
+def obstacle_orca_lines(pos, vel, radius, max_speed, segments, time_horizon_obst: float = 0.5):
+    """RVO2's obstacle half-planes (``Agent::computeNewVelocity``, first loop; RVO2 Library 2.0.2) for B agents against L wall
+    segments, each wall a two-vertex obstacle as ``orca_plus.py:52-55`` adds them: pos, vel [B, 2], radius, max_speed [B] ->
+    (point, direction) [B, 2 L, 2] and ``valid`` [B, 2 L], the accepted lines compacted to the left in RVO2's order (nearest
+    edge first; an edge whose velocity obstacle earlier lines already cover adds none).  UNPINNED (rvo2 is absent); equals the
+    scalar restatement ``oracle/orca_oracle.py::obstacle_orca_lines`` (tests/test_crowd_env.py)."""
+    pos, vel = np.asarray(pos, np.float64), np.asarray(vel, np.float64)
+    B = pos.shape[0]
+    segments = np.asarray(segments, np.float64).reshape(-1, 2, 2)
+    L2 = 2 * len(segments)
+    P_out, D_out, valid = np.zeros((B, L2, 2)), np.tile(np.array([1.0, 0.0]), (B, L2, 1)), np.zeros((B, L2), dtype=bool)
+    if B == 0 or L2 == 0:
+        return P_out, D_out, valid
+    radius = np.broadcast_to(np.asarray(radius, np.float64), (B,))[:, None]
+    max_speed = np.broadcast_to(np.asarray(max_speed, np.float64), (B,))[:, None]
+    # directed edges: A -> B of every wall, then B -> A
+    p1 = np.concatenate([segments[:, 0], segments[:, 1]])[None]          # [1, 2L, 2]
+    p2 = np.concatenate([segments[:, 1], segments[:, 0]])[None]
+    ov = p2 - p1
+    ov_sq = _dot(ov, ov)
+    u1 = ov / np.sqrt(ov_sq)[..., None]
+    u2 = -u1
+    x = pos[:, None, :]
+    v = vel[:, None, :]
+    inv_t = 1.0 / time_horizon_obst
+    r_sq = radius * radius
+    rp1, rp2 = p1 - x, p2 - x                                              # [B, 2L, 2]
+    # ---- neighbours: agent on the right of the edge, edge within reach; nearest first
+    range_sq = (time_horizon_obst * max_speed + radius) ** 2
+    left_of = _det(rp1, ov)
+    rr = _dot(-rp1, ov) / ov_sq
+    q = np.where((rr < 0.0)[..., None], -rp1, np.where((rr > 1.0)[..., None], -rp2, -rp1 - rr[..., None] * ov))
+    dseg = _dot(q, q)
+    nb = (left_of < 0.0) & (left_of * left_of / ov_sq < range_sq) & (dseg < range_sq)
+    # ---- the half-plane every edge WOULD contribute (all branches, masked)
+    d1, d2 = _dot(rp1, rp1), _dot(rp2, rp2)
+    s = rr
+    ql = -rp1 - s[..., None] * ov
+    d_line = _dot(ql, ql)
+    perp = lambda a: np.stack([-a[..., 1], a[..., 0]], axis=-1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        unit = lambda a: a / np.sqrt(_dot(a, a))[..., None]
+        c1 = (s < 0.0) & (d1 <= r_sq)
+        c2 = ~c1 & (s > 1.0) & (d2 <= r_sq)
+        c3 = ~c1 & ~c2 & (s >= 0.0) & (s < 1.0) & (d_line <= r_sq)
+        coll = c1 | c2 | c3
+        coll_dir = np.where(c1[..., None], unit(perp(rp1)), np.where(c2[..., None], unit(perp(rp2)), -u1))
+        coll_emit = c1 | c3 | (c2 & (_det(rp2, u2) >= 0.0))
+        obl_l = ~coll & (s < 0.0) & (d_line <= r_sq)
+        obl_r = ~coll & (s > 1.0) & (d_line <= r_sq)
+        same = obl_l | obl_r
+        leg = lambda rp, dd, sign: np.stack([rp[..., 0] * np.sqrt(dd - r_sq) - sign * rp[..., 1] * radius,
+                                             sign * rp[..., 0] * radius + rp[..., 1] * np.sqrt(dd - r_sq)], axis=-1) / dd[..., None]
+        left1, right1 = leg(rp1, d1, 1.0), leg(rp1, d1, -1.0)
+        left2, right2 = leg(rp2, d2, 1.0), leg(rp2, d2, -1.0)
+        left = np.where(obl_r[..., None], left2, left1)
+        right = np.where(obl_l[..., None], right1, right2)
+        o1rel = np.where(obl_r[..., None], rp2, rp1)                     # "obstacle1" - position, after the oblique cases
+        o2rel = np.where(obl_l[..., None], rp1, rp2)
+        u_right_vertex = np.where(obl_l[..., None], u1, u2)
+        u_o1 = np.where(obl_r[..., None], u2, u1)
+        u_prev = np.where(obl_r[..., None], u1, u2)
+        left_foreign = _det(left, -u_prev) >= 0.0
+        left = np.where(left_foreign[..., None], -u_prev, left)
+        right_foreign = _det(right, u_right_vertex) <= 0.0
+        right = np.where(right_foreign[..., None], u_right_vertex, right)
+        lc, rc = inv_t * o1rel, inv_t * o2rel
+        cv = rc - lc
+        t = np.where(same, 0.5, _dot(v - lc, cv) / _dot(cv, cv))
+        t_left, t_right = _dot(v - lc, left), _dot(v - rc, right)
+        g1 = ((t < 0.0) & (t_left < 0.0)) | (same & (t_left < 0.0) & (t_right < 0.0))
+        g2 = ~g1 & (t > 1.0) & (t_right < 0.0)
+        uw1, uw2 = unit(v - lc), unit(v - rc)
+        inf = np.inf
+        c = v - (lc + t[..., None] * cv)
+        dsq_cut = np.where((t < 0.0) | (t > 1.0) | same, inf, _dot(c, c))
+        c = v - (lc + t_left[..., None] * left)
+        dsq_left = np.where(t_left < 0.0, inf, _dot(c, c))
+        c = v - (rc + t_right[..., None] * right)
+        dsq_right = np.where(t_right < 0.0, inf, _dot(c, c))
+        on_cut = ~g1 & ~g2 & (dsq_cut <= dsq_left) & (dsq_cut <= dsq_right)
+        on_left = ~g1 & ~g2 & ~on_cut & (dsq_left <= dsq_right)
+        on_right = ~g1 & ~g2 & ~on_cut & ~on_left
+        gen_dir = np.where(g1[..., None], np.stack([uw1[..., 1], -uw1[..., 0]], -1),
+                  np.where(g2[..., None], np.stack([uw2[..., 1], -uw2[..., 0]], -1),
+                  np.where(on_cut[..., None], -u_o1, np.where(on_left[..., None], left, -right))))
+        off = radius[..., None] * inv_t
+        gen_pt = np.where(g1[..., None], lc + off * uw1,
+                 np.where(g2[..., None], rc + off * uw2,
+                 np.where((on_cut | on_left)[..., None], lc + off * perp(gen_dir), rc + off * perp(gen_dir))))
+        gen_emit = g1 | g2 | on_cut | (on_left & ~left_foreign) | (on_right & ~right_foreign)
+    cand_pt = np.where(coll[..., None], 0.0, gen_pt)
+    cand_dir = np.where(coll[..., None], coll_dir, gen_dir)
+    cand_emit = np.where(coll, coll_emit, gen_emit)
+    # ---- RVO2's order: nearest edge first; an edge already covered by the accepted lines adds nothing
+    key = np.where(nb, dseg, np.inf)
+    order = np.argsort(key, axis=1, kind="stable")
+    count = np.zeros(B, dtype=np.int64)
+    rows = np.arange(B)
+    slot = np.arange(L2)[None, :]
+    for k in range(L2):
+        e = order[:, k]
+        live = nb[rows, e]
+        if not live.any():
+            break
+        a1, a2 = inv_t * rp1[rows, e], inv_t * rp2[rows, e]                # [B, 2]
+        ok1 = _det(a1[:, None, :] - P_out, D_out) - inv_t * radius >= -RVO_EPSILON
+        ok2 = _det(a2[:, None, :] - P_out, D_out) - inv_t * radius >= -RVO_EPSILON
+        covered = (ok1 & ok2 & (slot < count[:, None])).any(axis=1)
+        take = live & ~covered & cand_emit[rows, e]
+        dst = np.where(take, count, 0)
+        P_out[rows[take], dst[take]] = cand_pt[rows[take], e[take]]
+        D_out[rows[take], dst[take]] = cand_dir[rows[take], e[take]]
+        valid[rows[take], dst[take]] = True
+        count = count + take
+    return P_out, D_out, valid
+
+
+def orca_plus_velocities(pos, vel, radius, pref, max_speed, segments, time_horizon: float = 2.0, time_horizon_obst: float = 0.5,
+                         time_step: float = 0.25, neighbor_dist: float = 10.0, max_neighbors: int = 10) -> np.ndarray:
+    """New ORCA velocity of EVERY agent of every episode among the other agents of its episode AND the walls, each as the ego of
+    its own program (``ORCAPlus.predict``): pos, vel, pref [E, n, 2]; radius, max_speed [E, n] (radius already inflated);
+    segments [L, 2, 2] shared by all episodes.  Obstacle half-planes come first and stay hard constraints when the program is
+    infeasible (``linearProgram3`` with ``numObstLines``).  -> [E, n, 2]."""
+    from . import episodes as EP
+    E, n, _ = pos.shape
+    B = E * n
+    ego = lambda a: a.reshape((B,) + a.shape[2:])
+    Po, Do, vo = obstacle_orca_lines(ego(pos), ego(vel), ego(radius), ego(max_speed), segments, time_horizon_obst)
+    if n > 1:
+        others = np.array([[j for j in range(n) if j != i] for i in range(n)], dtype=np.int64).reshape(n, n - 1)
+        oth = lambda a: a[:, others].reshape((B, n - 1) + a.shape[2:])
+        Pa, Da, dsq = EP.orca_lines(ego(pos), ego(vel), ego(radius), oth(pos), oth(vel), oth(radius), time_horizon, time_step,
+                                    with_dist=True)
+        va = (dsq < neighbor_dist * neighbor_dist) & (np.arange(n - 1)[None, :] < max_neighbors)
+    else:
+        Pa, Da, va = np.zeros((B, 0, 2)), np.zeros((B, 0, 2)), np.zeros((B, 0), dtype=bool)
+    P, D, active = np.concatenate([Po, Pa], 1), np.concatenate([Do, Da], 1), np.concatenate([vo, va], 1)
+    is_obst = np.concatenate([vo, np.zeros_like(va)], 1)
+    off = ~active            # slots that hold no line: a half-plane every velocity satisfies (the programs skip inactive lines)
+    D = np.where(off[..., None], np.array([1.0, 0.0]), D)
+    P = np.where(off[..., None], np.array([0.0, -1e9]), P)
+    allrows = np.ones(B, dtype=bool)
+    failed, fail_idx, result = EP._lp2(P, D, active, ego(max_speed), ego(pref), False, allrows)
+    if failed.any():
+        result = EP._lp3(P, D, fail_idx, ego(max_speed), result, failed, is_obst=is_obst)
+    return result.reshape(E, n, 2)
+
+
+# ------------------------------------------------------------------------------------------------ hallway episodes
+@dataclass
+class HallwayConfig:
+    """The fields of ``sicnav_diffusion/configs/env.config`` a hallway episode reads (shipped values)."""
+    rule: str = "hallway"                   # [sim] test_sim
+    geometry: Geometry = Geometry()         # [sim] circle_radius, rect_width, rect_height; [robot] radius
+    time_step: float = 0.25                 # [env] time_step
+    time_limit: float = 30.0                # [env] time_limit
+    starts_moving: int = 10                 # [sim] starts_moving: steps the humans walk before the robot's clock starts
+    human_radius: float = 0.20              # [humans] radius
+    human_v_pref: float = 1.5               # [humans] v_pref (drawn from U(0.5, 1.5) with randomize_attributes)
+    safety_space: float = 0.05              # [humans] safety_space
+    robot_v_pref: float = 1.0               # [robot] v_pref
+    randomize_attributes: bool = True       # [env] randomize_attributes
+    discomfort_dist: float = 0.2            # [reward] discomfort_dist
+
+
+def hallway_starts(E: int, N: int, seed: int, cfg: HallwayConfig) -> Dict[str, np.ndarray]:
+    """Start record of E hallway episodes (``reset``, ``crowd_sim_plus.py:660-672``: robot at (0, -R) heading for (0, R), then the
+    walls of the rule, then N humans by ``generate_hallway_human``), every episode on its own generator
+    ``episodes.episode_rng(seed, e)``.  Index 0 of the agent axis is the robot."""
+    from .episodes import episode_rng
+    R = cfg.geometry.circle_radius
+    pos, goal = np.zeros((E, N + 1, 2)), np.zeros((E, N + 1, 2))
+    rad = np.full((E, N + 1), cfg.human_radius)
+    vp = np.full((E, N + 1), cfg.human_v_pref)
+    pos[:, 0], goal[:, 0] = (0.0, -R), (0.0, R)
+    rad[:, 0], vp[:, 0] = cfg.geometry.robot_radius, cfg.robot_v_pref
+    for e in range(E):
+        h = place_hallway_humans(N, episode_rng(seed, e), cfg.rule, cfg.geometry, cfg.human_radius, cfg.human_v_pref,
+                                 cfg.randomize_attributes, cfg.discomfort_dist)
+        pos[e, 1:], goal[e, 1:], vp[e, 1:] = h["pos"], h["final_goal"], h["v_pref"]
+    return dict(pos=pos, goal=goal, radius=rad, v_pref=vp)
+
+
+def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[HallwayConfig] = None, robot: str = "orca"
+                     ) -> Dict[str, np.ndarray]:
+    """E independent episodes of a hallway rule with N ORCA humans that see the walls (``orca_plus``), ``steps`` simulator steps
+    after the ``starts_moving`` steps the reference lets the humans walk while the robot stands (``crowd_sim_plus.py:707-721``).
+
+    Per step, as ``CrowdSimPlus.step``: every human's goal is its door sub-goal where one applies, its ORCA velocity among the
+    others and the walls is cut short at the walls (``constrain_agent_action_exact``), then all agents move.  The reference's
+    robot is driven by the MPC (out of scope); here ``robot`` = "orca" (an ORCA agent like the humans, v_pref 1), "still", or an
+    array [E, steps, 2] of commanded velocities (wall-constrained like everybody's).  Returns what ``simulate_circle_crossing``
+    returns (positions from the moment the robot's clock starts, frame 0 = global time 0) plus per step the outcome block
+    (``step_outcomes`` with the shipped rewards): ``collision``, ``dmin``, ``reached_goal``, ``timeout``, ``done``, ``reward`` [E, steps]
+    and the step at which each episode ended (``end_step``, -1 = still running)."""
+    cfg = cfg or HallwayConfig()
+    segs, doors = static_obstacles(cfg.rule, cfg.geometry)
+    st = hallway_starts(E, N, seed, cfg)
+    pos, final_goal, radius, v_pref = st["pos"].copy(), st["goal"], st["radius"], st["v_pref"]
+    vel = np.zeros_like(pos)
+    dt = cfg.time_step
+    rewards = shipped_rewards()
+    total = cfg.starts_moving + steps
+    traj, vels = np.zeros((E, steps + 1, N + 1, 2)), np.zeros((E, steps + 1, N + 1, 2))
+    out = {k: np.zeros((E, steps), dtype=t) for k, t in (("collision", bool), ("dmin", float), ("reached_goal", bool), ("timeout", bool),
+                                                          ("done", bool), ("reward", float), ("wall_collision", bool))}
+    end_step = np.full(E, -1)
+    for s in range(total):
+        live = s >= cfg.starts_moving
+        goal = final_goal.copy()
+        goal[:, 1:] = door_subgoal(pos[:, 1:], final_goal[:, 1:], cfg.rule, doors, len(segs))
+        par = orca_plus_parameters(pos, goal, radius, v_pref, cfg.safety_space, dt)
+        new_vel = orca_plus_velocities(pos, vel, par["radius"], par["pref"], par["max_speed"], segs, par["time_horizon"],
+                                       par["time_horizon_obst"], dt, par["neighbor_dist"], par["max_neighbors"])
+        if not live or (isinstance(robot, str) and robot == "still"):
+            new_vel[:, 0] = 0.0                                       # the dummy start: ActionXY(0, 0) for the robot
+        elif not isinstance(robot, str):
+            new_vel[:, 0] = np.asarray(robot, np.float64)[:, s - cfg.starts_moving]
+        wanted = new_vel.copy()
+        new_vel = constrain_actions(pos.reshape(-1, 2), new_vel.reshape(-1, 2), radius.reshape(-1), dt, segs).reshape(E, N + 1, 2)
+        if live:
+            k = s - cfg.starts_moving
+            if k == 0:
+                traj[:, 0], vels[:, 0] = pos, vel
+                prev_dist = _norm(final_goal[:, 0] - pos[:, 0])
+            o = step_outcomes(pos[:, 0], new_vel[:, 0], final_goal[:, 0], radius[:, 0], pos[:, 1:], new_vel[:, 1:], radius[:, 1:],
+                              k * dt, cfg.time_limit, dt, rewards, stat_collision=(wanted[:, 0] != new_vel[:, 0])[:, 0],
+                              prev_dist_to_goal=prev_dist)
+            for key in ("collision", "dmin", "reached_goal", "timeout", "done", "reward"):
+                out[key][:, k] = o[key]
+            out["wall_collision"][:, k] = (wanted[:, 0] != new_vel[:, 0])[:, 0]
+            end_step = np.where((end_step < 0) & o["done"], k, end_step)
+        vel = new_vel
+        pos = pos + vel * dt
+        if live:
+            traj[:, s - cfg.starts_moving + 1], vels[:, s - cfg.starts_moving + 1] = pos, vel
+    return dict(human_xy=traj[:, :, 1:], robot_xy=traj[:, :, 0], human_vel=vels[:, :, 1:], stamps=np.arange(steps + 1) * dt,
+                goal=final_goal, radius=radius, v_pref=v_pref, segments=segs, end_step=end_step, **out)

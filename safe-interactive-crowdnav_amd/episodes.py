@@ -21,8 +21,8 @@ reference tree and from this image, so no output of its ORCA solver exists to co
 checked (``tests/test_episodes.py``): equality with a scalar, one-agent-at-a-time restatement of the published
 algorithm kept with the test infrastructure, optimality against a brute-force search of the velocity disc,
 collision-freeness and goal progress of the generated crowds.  The shipped scenarios of the reference (``hallway*``, ``env.config:16-17``)
-additionally need RVO2's obstacle ORCA lines, door sub-goals and wall-constrained actions
-(``crowd_sim_plus.py:869-990``); those are not built - only the obstacle-free circle crossing is.
+- walls, RVO2's obstacle ORCA lines, door sub-goals, wall-constrained actions, and what a ``step()`` decides (collision, goal,
+timeout, rewards) - live in ``crowd_env.py`` (``simulate_hallway``), which reuses the linear programs of this module.
 """
 from __future__ import annotations
 
@@ -139,8 +139,10 @@ def _lp2(P, D, active, radius, opt, direction_opt: bool, mask):
     return failed, fail_idx, result
 
 
-def _lp3(P, D, begin, radius, result, mask):
-    """linearProgram3: for rows whose program is infeasible, the velocity that violates the half-planes least."""
+def _lp3(P, D, begin, radius, result, mask, is_obst=None):
+    """linearProgram3: for rows whose program is infeasible, the velocity that violates the half-planes least.  ``is_obst`` [B, L]
+    marks obstacle half-planes (crowd_env.orca_plus_velocities): they enter every projected program unchanged - hard constraints,
+    as RVO2 keeps its first ``numObstLines`` lines."""
     B, L, _ = P.shape
     distance = np.zeros(B)
     idx = np.arange(L)
@@ -158,6 +160,10 @@ def _lp3(P, D, begin, radius, result, mask):
             point = np.where(par[..., None], 0.5 * (pi[:, None, :] + P), pi[:, None, :] + t[..., None] * di[:, None, :])
             dd = D - di[:, None, :]
             dd = dd / np.sqrt(_dot(dd, dd))[..., None]
+        if is_obst is not None:
+            act = np.where(is_obst, True, act & ~is_obst)
+            point = np.where(is_obst[..., None], P, point)
+            dd = np.where(is_obst[..., None], D, dd)
         point = np.where(act[..., None], point, 0.0)
         dd = np.where(act[..., None], dd, 0.0)
         opt = np.stack([-di[:, 1], di[:, 0]], axis=-1)

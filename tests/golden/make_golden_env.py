@@ -263,8 +263,80 @@ def capture_step_outcomes(ns, tag, n, seed, rewards, detailed):
           "reached:", int(np.sum(rec["reached"])), "frozen:", int(np.sum(rec["frozen"])))
 
 
+class RecordingSim:
+    """stand-in for rvo2.PyRVOSimulator: records what ORCAPlus.predict hands to it"""
+    def __init__(self, log, *args):
+        self.log = log
+        log["simulator"] = args
+        log["agents"], log["pref"], log["obstacles"], log["processed"] = [], {}, [], 0
+
+    def addObstacle(self, line):
+        self.log["obstacles"].append([tuple(line[0]), tuple(line[1])])
+
+    def processObstacles(self):
+        self.log["processed"] += 1
+
+    def addAgent(self, position, *args):
+        self.log["agents"].append((tuple(position),) + args)
+
+    def setAgentPrefVelocity(self, i, v):
+        self.log["pref"][i] = tuple(float(x) for x in v)
+
+    def getNumAgents(self):
+        return len(self.log["agents"])
+
+    def doStep(self):
+        pass
+
+    def getAgentVelocity(self, i):
+        return (0.0, 0.0)
+
+
+def capture_orca_plus_calls(ns, tag, rule, n_humans, seed, time_step=0.25, near_goal=False):
+    """What ORCAPlus.predict (policy/orca_plus.py:43-84) hands to rvo2 for one human's step: the walls, the simulator and agent
+    parameters (radius + 0.01 + the humans' safety space), the preferred velocity (capped at v_pref - 1e-3)."""
+    rng = np.random.default_rng(seed)
+    log = {}
+    rvo2 = types.SimpleNamespace(PyRVOSimulator=lambda *a: RecordingSim(log, *a))
+    policy = types.SimpleNamespace(time_step=time_step, sim=None)
+    exec(ref_lines("policy/orca.py", 56, 67), dict(self=policy))                    # ORCA.__init__'s parameters
+    # ORCAPlus.configure(config, 'humans') (orca_plus.py:15-27, called from Human.__init__): radius and safety space of [humans]
+    cfg = types.SimpleNamespace(getfloat=lambda s, k: {("env", "time_step"): time_step, ("humans", "radius"): 0.20,
+                                                       ("humans", "safety_space"): 0.05}[(s, k)])
+    src = "def configure(self, config, section='orca_plus'):\n" + textwrap.indent(ref_lines("policy/orca_plus.py", 16, 27), "    ")
+    cns = dict(logging=__import__("logging"))
+    exec(src, cns)
+    cns["configure"](policy, cfg, "humans")
+    env = make_env(ns, rule)
+    mk = lambda: types.SimpleNamespace(px=rng.uniform(-0.6, 0.6), py=rng.uniform(-3, 3), vx=rng.uniform(-1, 1), vy=rng.uniform(-1, 1),
+                                       gx=rng.uniform(-0.6, 0.6), gy=rng.uniform(-3, 3), radius=0.20, v_pref=rng.uniform(0.5, 1.5))
+    ego = mk()
+    if near_goal:
+        ego.gx, ego.gy = ego.px + 0.2, ego.py - 0.3
+    others = [mk() for _ in range(n_humans)]
+    for a in [ego] + others:
+        a.position, a.velocity = (a.px, a.py), (a.vx, a.vy)
+    state = types.SimpleNamespace(self_state=ego, human_states=others, static_obs=[[tuple(q[0]), tuple(q[1])] for q in env.static_obstacles])
+    src = "def predict(self, state):\n" + textwrap.indent(ref_lines("policy/orca_plus.py", 43, 84), "    ")
+    pns = dict(np=np, rvo2=rvo2, ActionXY=lambda vx, vy: (vx, vy))
+    exec(src, pns)
+    pns["predict"](policy, state)
+    agents = log["agents"]
+    np.savez(os.path.join(OUT, f"env_orca_plus_calls_{tag}.npz"), rule=rule, n_humans=n_humans, time_step=time_step,
+             ego=np.array([ego.px, ego.py, ego.vx, ego.vy, ego.gx, ego.gy, ego.radius, ego.v_pref]),
+             others=np.array([[o.px, o.py, o.vx, o.vy, o.radius, o.v_pref] for o in others]),
+             simulator=np.array(log["simulator"], dtype=np.float64), obstacles=np.array(log["obstacles"], dtype=np.float64).reshape(-1, 2, 2),
+             processed=log["processed"], agent_pos=np.array([a[0] for a in agents]),
+             agent_params=np.array([a[1:7] for a in agents], dtype=np.float64), agent_vel=np.array([a[7] for a in agents]),
+             pref=np.array([log["pref"][i] for i in range(len(agents))]), safety_space=policy.safety_space, policy_radius=policy.radius)
+    print("orca_plus calls", tag, rule, len(agents), len(log["obstacles"]))
+
+
 if __name__ == "__main__":
     ns = make_functions()
+    capture_orca_plus_calls(ns, "hallway_n3", "hallway", 3, 61)
+    capture_orca_plus_calls(ns, "static_n5", "hallway_static", 5, 62)
+    capture_orca_plus_calls(ns, "near_goal", "hallway_bottleneck", 2, 63, near_goal=True)
     capture_static_obstacles(ns)
     capture_door_subgoals(ns)
     capture_hallway_placement(ns, "shipped_n3", "hallway", 3, 31)                       # env.config: hallway, 3 humans
