@@ -463,7 +463,7 @@ def obstacle_orca_lines(pos, vel, radius, max_speed, segments, time_horizon_obst
     segments, each wall a two-vertex obstacle as ``orca_plus.py:52-55`` adds them: pos, vel [B, 2], radius, max_speed [B] ->
     (point, direction) [B, 2 L, 2] and ``valid`` [B, 2 L], the accepted lines compacted to the left in RVO2's order (nearest
     edge first; an edge whose velocity obstacle earlier lines already cover adds none).  UNPINNED (rvo2 is absent); equals the
-    scalar restatement ``oracle/orca_oracle.py::obstacle_orca_lines`` (tests/test_crowd_env.py)."""
+    scalar, one-agent-at-a-time restatement kept with the test infrastructure (tests/test_crowd_env.py)."""
     pos, vel = np.asarray(pos, np.float64), np.asarray(vel, np.float64)
     B = pos.shape[0]
     segments = np.asarray(segments, np.float64).reshape(-1, 2, 2)
