@@ -12,16 +12,21 @@ simulator and the MPC live):
   ``place_hallway_humans``    ``generate_hallway_human``            ``crowd_sim_plus.py:522-607``   placement, with the draw order
   ``constrain_actions``       ``constrain_agent_action_exact``      ``crowd_sim_plus.py:869-989``   an action cut short at a wall
   ``step_outcomes``           the outcome block of ``step()``       ``crowd_sim_plus.py:1067-1166`` flags, reward terms, done
+  ``sfm_velocities``          ``SFM.predict``                       ``policy/social_force.py:38-95`` social-force humans
   ``orca_plus_parameters``    what ``ORCAPlus.predict`` hands rvo2  ``policy/orca_plus.py:43-84``
   ``obstacle_orca_lines``     RVO2's obstacle half-planes           RVO2 Library 2.0.2 ``Agent::computeNewVelocity``
+  ``simulate_hallway``        ``reset`` + ``step`` x n              ``crowd_sim_plus.py:609-721, 1025-1258``   E episodes at once
 
-PARITY.  Everything in the first six rows is plain Python / NumPy in the reference and is pinned by fixtures that
+PARITY.  Everything in the first eight rows is plain Python / NumPy in the reference and is pinned by fixtures that
 ``tests/golden/make_golden_env.py`` generates by executing the reference's own lines against stand-in objects
-(``tests/golden/env_*.npz``; ``tests/test_crowd_env.py``).  ``obstacle_orca_lines`` restates the C++ of rvo2, an un-vendored
-dependency that is absent from the reference tree and from this image: like the agent-agent half-planes of ``episodes.py`` it
-is UNPINNED, checked against a scalar restatement kept with the test infrastructure, by brute force and through properties
-(no agent of a generated crowd ever enters a wall).  Holonomic agents only (``ActionXY``): the humans always are, the robot
-of the shipped configuration is.  The social-force humans (``policy/social_force.py``) are not built.
+(``tests/golden/env_*.npz``; ``tests/test_crowd_env.py``).  With the social-force humans (``human_policy="sfm"``) an episode holds
+nothing else: whole episodes of ``simulate_hallway`` - placement, observations, forces, wall constraint, door sub-goals, outcome
+block, position updates - land on the positions the reference's lines produce step by step (``env_rollout_sfm_*.npz``, 40-50
+steps, <= 1e-10 m).  With the shipped ``orca_plus`` humans the velocities come out of rvo2, an un-vendored C++ dependency that is
+absent from the reference tree and from this image: ``obstacle_orca_lines`` (like the agent-agent half-planes and the linear
+programs of ``episodes.py``) restates its published algorithm and is UNPINNED, checked against a scalar restatement kept with the
+test infrastructure, by brute force and through properties (no agent of a generated crowd ever enters a wall).  Holonomic agents
+only (``ActionXY``): the humans always are, the robot of the shipped configuration is.
 """
 from __future__ import annotations
 
@@ -607,6 +612,62 @@ def orca_plus_velocities(pos, vel, radius, pref, max_speed, segments, time_horiz
     return result.reshape(E, n, 2)
 
 
+# ------------------------------------------------------------------------------------------------ social-force humans (sfm)
+@dataclass(frozen=True)
+class SFMParams:
+    """``[humans]`` of env.config as ``SFM.configure(config, 'humans')`` reads it (``policy/social_force.py:21-36``)."""
+    radius: float = 0.20
+    A: float = 3.0
+    B: float = 0.18
+    KI: float = 1.0
+    A_static: float = 2.0
+    B_static: float = 0.025
+    A_bottleneck: float = 6.0
+    B_bottleneck: float = 0.12
+
+
+def sfm_velocities(pos, vel, goal, radius, v_pref, others_pos, others_radius, segments, time_step: float = 0.25,
+                   params: SFMParams = SFMParams(), bottleneck: bool = False) -> np.ndarray:
+    """``SFM.predict`` (``policy/social_force.py:38-95``) for B agents at once: a pull towards the goal at the preferred speed
+    (relaxation rate KI), an exponential push away from every other agent (``others_pos`` [B, m, 2], ``others_radius`` [B, m], in
+    the order the reference sums them: the other humans, then the robot) and from the closest point of every wall (in the order
+    of the rule's segments; from the third segment on with the bottleneck constants when ``bottleneck``), integrated over one
+    step and clipped to the preferred speed.  pos, vel, goal [B, 2]; radius, v_pref [B] -> [B, 2].  The sums run in the
+    reference's order, term by term.  Pinned by ``tests/golden/env_sfm_calls_*.npz`` and, through whole episodes, by
+    ``tests/golden/env_rollout_sfm_*.npz``."""
+    pos, vel, goal = (np.asarray(a, np.float64) for a in (pos, vel, goal))
+    radius, v_pref = np.asarray(radius, np.float64), np.asarray(v_pref, np.float64)
+    others_pos, others_radius = np.asarray(others_pos, np.float64), np.asarray(others_radius, np.float64)
+    segments = np.asarray(segments, np.float64).reshape(-1, 2, 2)
+    dx, dy = goal[:, 0] - pos[:, 0], goal[:, 1] - pos[:, 1]
+    dist = np.sqrt(dx ** 2 + dy ** 2)
+    dist = np.where(dist < 1e-6, 1.0, dist)
+    dvx = params.KI * ((dx / dist) * v_pref - vel[:, 0])
+    dvy = params.KI * ((dy / dist) * v_pref - vel[:, 1])
+    ivx, ivy = np.zeros(len(pos)), np.zeros(len(pos))
+    for j in range(others_pos.shape[1]):
+        adj = np.abs(params.radius - others_radius[:, j]) + 0.01
+        ox, oy = pos[:, 0] - others_pos[:, j, 0], pos[:, 1] - others_pos[:, j, 1]
+        d = np.sqrt(ox ** 2 + oy ** 2)
+        ivx = ivx + params.A * np.exp((radius + others_radius[:, j] + adj - d) / params.B) * (ox / d)
+        ivy = ivy + params.A * np.exp((radius + others_radius[:, j] + adj - d) / params.B) * (oy / d)
+    for idx, sg in enumerate(segments):
+        a_s, b_s = (params.A_bottleneck, params.B_bottleneck) if (bottleneck and idx >= 2) else (params.A_static, params.B_static)
+        px, py = sg[1, 0] - sg[0, 0], sg[1, 1] - sg[0, 1]
+        u = ((pos[:, 0] - sg[0, 0]) * px + (pos[:, 1] - sg[0, 1]) * py) / (px * px + py * py)
+        u = np.where(u > 1, 1.0, np.where(u < 0, 0.0, u))
+        ox, oy = pos[:, 0] - (sg[0, 0] + u * px), pos[:, 1] - (sg[0, 1] + u * py)
+        d = np.sqrt(ox ** 2 + oy ** 2)
+        ivx = ivx + a_s * np.exp((radius + 0.01 - d) / b_s) * (ox / d)
+        ivy = ivy + a_s * np.exp((radius + 0.01 - d) / b_s) * (oy / d)
+    nvx = vel[:, 0] + (dvx + ivx) * time_step
+    nvy = vel[:, 1] + (dvy + ivy) * time_step
+    nrm = _norm(np.stack([nvx, nvy], axis=-1))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        clip = nrm > v_pref
+        return np.stack([np.where(clip, nvx / nrm * v_pref, nvx), np.where(clip, nvy / nrm * v_pref, nvy)], axis=-1)
+
+
 # ------------------------------------------------------------------------------------------------ hallway episodes
 @dataclass
 class HallwayConfig:
@@ -622,6 +683,8 @@ class HallwayConfig:
     robot_v_pref: float = 1.0               # [robot] v_pref
     randomize_attributes: bool = True       # [env] randomize_attributes
     discomfort_dist: float = 0.2            # [reward] discomfort_dist
+    human_policy: str = "orca_plus"         # [humans] policy: "orca_plus" (shipped; rvo2's solve is unpinned) or "sfm" (pinned end to end)
+    sfm: SFMParams = SFMParams()            # [humans] A, B, KI, A_static, ... (the sfm policy's constants)
 
 
 def hallway_starts(E: int, N: int, seed: int, cfg: HallwayConfig) -> Dict[str, np.ndarray]:
@@ -642,22 +705,30 @@ def hallway_starts(E: int, N: int, seed: int, cfg: HallwayConfig) -> Dict[str, n
     return dict(pos=pos, goal=goal, radius=rad, v_pref=vp)
 
 
-def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[HallwayConfig] = None, robot: str = "orca"
-                     ) -> Dict[str, np.ndarray]:
+def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[HallwayConfig] = None, robot="orca",
+                     starts: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
     """E independent episodes of a hallway rule with N ORCA humans that see the walls (``orca_plus``), ``steps`` simulator steps
     after the ``starts_moving`` steps the reference lets the humans walk while the robot stands (``crowd_sim_plus.py:707-721``).
 
     Per step, as ``CrowdSimPlus.step``: every human's goal is its door sub-goal where one applies, its ORCA velocity among the
-    others and the walls is cut short at the walls (``constrain_agent_action_exact``), then all agents move.  The reference's
-    robot is driven by the MPC (out of scope); here ``robot`` = "orca" (an ORCA agent like the humans, v_pref 1), "still", or an
-    array [E, steps, 2] of commanded velocities (wall-constrained like everybody's).  Returns what ``simulate_circle_crossing``
+    others and the walls (``cfg.human_policy`` = "orca_plus") or its social-force velocity (= "sfm": every term in the reference's
+    own arithmetic - whole episodes reproduce the reference's lines, ``tests/golden/env_rollout_sfm_*.npz``) is cut short at the
+    walls (``constrain_agent_action_exact``), then all agents move.  The reference's robot is driven by the MPC (out of scope);
+    here ``robot`` = "orca" (an ORCA agent like the orca_plus humans, v_pref 1), "goal" (straight at its goal at v_pref), "still",
+    or an array [E, steps, 2] of commanded velocities (wall-constrained like everybody's).  ``starts``: a start record in the
+    place of ``hallway_starts`` (pos, goal [E, N + 1, 2], radius, v_pref [E, N + 1]).  Returns what ``simulate_circle_crossing``
     returns (positions from the moment the robot's clock starts, frame 0 = global time 0) plus per step the outcome block
     (``step_outcomes`` with the shipped rewards): ``collision``, ``dmin``, ``reached_goal``, ``timeout``, ``done``, ``reward`` [E, steps]
     and the step at which each episode ended (``end_step``, -1 = still running)."""
     cfg = cfg or HallwayConfig()
     segs, doors = static_obstacles(cfg.rule, cfg.geometry)
-    st = hallway_starts(E, N, seed, cfg)
-    pos, final_goal, radius, v_pref = st["pos"].copy(), st["goal"], st["radius"], st["v_pref"]
+    st = starts if starts is not None else hallway_starts(E, N, seed, cfg)
+    pos, final_goal, radius, v_pref = np.array(st["pos"], np.float64), st["goal"], st["radius"], st["v_pref"]
+    if cfg.human_policy not in ("orca_plus", "sfm"):
+        raise ValueError("human_policy must be 'orca_plus' or 'sfm'")
+    robot_mode = robot if isinstance(robot, str) else "given"
+    if robot_mode not in ("orca", "goal", "still", "given"):
+        raise ValueError("robot must be 'orca', 'goal', 'still' or an array of commanded velocities")
     vel = np.zeros_like(pos)
     dt = cfg.time_step
     rewards = shipped_rewards()
@@ -670,13 +741,28 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
         live = s >= cfg.starts_moving
         goal = final_goal.copy()
         goal[:, 1:] = door_subgoal(pos[:, 1:], final_goal[:, 1:], cfg.rule, doors, len(segs))
-        par = orca_plus_parameters(pos, goal, radius, v_pref, cfg.safety_space, dt)
-        new_vel = orca_plus_velocities(pos, vel, par["radius"], par["pref"], par["max_speed"], segs, par["time_horizon"],
-                                       par["time_horizon_obst"], dt, par["neighbor_dist"], par["max_neighbors"])
-        if not live or (isinstance(robot, str) and robot == "still"):
+        new_vel = np.zeros_like(vel)
+        if cfg.human_policy == "orca_plus" or (live and robot_mode == "orca"):
+            par = orca_plus_parameters(pos, goal, radius, v_pref, cfg.safety_space, dt)
+            orca = orca_plus_velocities(pos, vel, par["radius"], par["pref"], par["max_speed"], segs, par["time_horizon"],
+                                        par["time_horizon_obst"], dt, par["neighbor_dist"], par["max_neighbors"])
+            new_vel[:, 0] = orca[:, 0]
+            if cfg.human_policy == "orca_plus":
+                new_vel[:, 1:] = orca[:, 1:]
+        if cfg.human_policy == "sfm":
+            # every human's observation: the other humans in list order, then the robot (crowd_sim_plus.py:1044-1052)
+            idx = np.array([[j for j in range(1, N + 1) if j != i] + [0] for i in range(1, N + 1)], dtype=np.int64).reshape(N, N)
+            flat = lambda a: a.reshape((E * N,) + a.shape[2:])
+            new_vel[:, 1:] = sfm_velocities(flat(pos[:, 1:]), flat(vel[:, 1:]), flat(goal[:, 1:]), flat(radius[:, 1:]), flat(v_pref[:, 1:]),
+                                            flat(pos[:, idx]), flat(radius[:, idx]), segs, dt, cfg.sfm,
+                                            cfg.rule == "hallway_bottleneck").reshape(E, N, 2)
+        if not live or robot_mode == "still":
             new_vel[:, 0] = 0.0                                       # the dummy start: ActionXY(0, 0) for the robot
-        elif not isinstance(robot, str):
+        elif robot_mode == "given":
             new_vel[:, 0] = np.asarray(robot, np.float64)[:, s - cfg.starts_moving]
+        elif robot_mode == "goal":
+            d = final_goal[:, 0] - pos[:, 0]
+            new_vel[:, 0] = d / np.maximum(_norm(d), 1e-9)[:, None] * v_pref[:, 0:1]
         wanted = new_vel.copy()
         new_vel = constrain_actions(pos.reshape(-1, 2), new_vel.reshape(-1, 2), radius.reshape(-1), dt, segs).reshape(E, N + 1, 2)
         if live:

@@ -332,8 +332,106 @@ def capture_orca_plus_calls(ns, tag, rule, n_humans, seed, time_step=0.25, near_
     print("orca_plus calls", tag, rule, len(agents), len(log["obstacles"]))
 
 
+SFM_PARAMS = dict(radius=0.20, A=3.0, B=0.18, KI=1.0, A_static=2.0, B_static=0.025, A_bottleneck=6.0, B_bottleneck=0.12)   # env.config [humans]
+
+
+def sfm_predict(ns):
+    """SFM.predict (policy/social_force.py:39-95), the reference's lines as a function of (policy record, state)."""
+    if "sfm_predict" not in ns:
+        exec("def sfm_predict(self, state):\n" + textwrap.indent(ref_lines("policy/social_force.py", 39, 95), "    "), ns)
+    return ns["sfm_predict"]
+
+
+def capture_sfm_calls(ns, tag, rule, n, seed, n_others=3, time_step=0.25):
+    """n single calls of SFM.predict: one human among n_others agents (the last of them the robot, radius 0.25) and the walls of the rule."""
+    env = make_env(ns, rule)
+    rng = np.random.default_rng(seed)
+    pol = types.SimpleNamespace(time_step=time_step, is_bottleneck=(rule == "hallway_bottleneck"), **SFM_PARAMS)
+    predict = sfm_predict(ns)
+    rec = {k: [] for k in ("ego", "others", "action")}
+    for _ in range(n):
+        mk = lambda r: types.SimpleNamespace(px=rng.uniform(-0.6, 0.6), py=rng.uniform(-2.5, 2.5), vx=rng.uniform(-1, 1), vy=rng.uniform(-1, 1),
+                                             gx=rng.uniform(-0.6, 0.6), gy=rng.uniform(-3, 3), radius=r, v_pref=rng.uniform(0.5, 1.5))
+        ego = mk(0.20)
+        others = [mk(0.20) for _ in range(n_others - 1)] + [mk(0.25)]
+        if rng.random() < 0.1:
+            ego.gx, ego.gy = ego.px, ego.py                                  # standing on its goal: the 1e-6 guard
+        state = types.SimpleNamespace(self_state=ego, human_states=others, static_obs=[[tuple(q[0]), tuple(q[1])] for q in env.static_obstacles])
+        a = predict(pol, state)
+        rec["ego"].append([ego.px, ego.py, ego.vx, ego.vy, ego.gx, ego.gy, ego.radius, ego.v_pref])
+        rec["others"].append([[o.px, o.py, o.vx, o.vy, o.radius] for o in others])
+        rec["action"].append([a.vx, a.vy])
+    np.savez(os.path.join(OUT, f"env_sfm_calls_{tag}.npz"), rule=rule, time_step=time_step, params=np.array(list(SFM_PARAMS.values())),
+             param_keys=np.array(list(SFM_PARAMS)), **{k: np.array(v) for k, v in rec.items()})
+    print("sfm calls", tag, rule, n)
+
+
+def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, time_step=0.25):
+    """A whole episode with social-force humans, step by step with the reference's own lines: placement (generate_hallway_human),
+    per step every human's observation (the other humans, then the robot: crowd_sim_plus.py:1044-1052), SFM.predict, the wall
+    constraint, the outcome block, the position update and the door sub-goal (Agent.step / Human.step).  The robot stands for the
+    first `starts_moving` steps (the dummy start, :707-721) and then heads for its goal at its preferred speed (scripted: the
+    reference's robot is the MPC)."""
+    env = make_env(ns, rule, cfg=Config(policy="sfm"))
+    env.time_step, env.global_time, env.time_limit, env.detailed_reward_return = time_step, -starts_moving * time_step, 30.0, False
+    env.rewards = {"success_reward": 1.0, "collision_penalty": -0.25, "freezing_penalty": -0.125, "discomfort_dist": 0.2,
+                   "discomfort_penalty_factor": 0.5, "discomfort": True, "timeout": -1.0, "wall_collision_penalty": -1.0}
+    rng = np.random.default_rng(seed)
+    for _ in range(n_humans):
+        env.humans.append(ns["generate_hallway_human"](env, rng))
+    A = ns["ActionXY"]
+    for h in env.humans:
+        h.time_step, h.vx, h.vy, h.kinematics = time_step, 0.0, 0.0, "holonomic"
+        h.compute_position = (lambda self: (lambda action, dt: (self.px + action.vx * dt, self.py + action.vy * dt)))(h)
+    robot = env.robot
+    robot.vx = robot.vy = 0.0
+    robot.v_pref = 1.0
+    env.robot_goal_pos = np.array([robot.gx, robot.gy])
+    env.robot_prev_dist_to_goal = 0
+    env.prev_action_angular = env.prev_action_linear = None
+    pol = types.SimpleNamespace(time_step=time_step, is_bottleneck=(rule == "hallway_bottleneck"), **SFM_PARAMS)
+    predict = sfm_predict(ns)
+    obs = lambda a: types.SimpleNamespace(px=a.px, py=a.py, vx=a.vx, vy=a.vy, radius=a.radius)
+    full = lambda a: types.SimpleNamespace(px=a.px, py=a.py, vx=a.vx, vy=a.vy, radius=a.radius, gx=a.gx, gy=a.gy, v_pref=a.v_pref)
+    start = dict(pos=np.array([[h.px, h.py] for h in env.humans]), final_goal=np.array([[h.final_gx, h.final_gy] for h in env.humans]),
+                 v_pref=np.array([h.v_pref for h in env.humans]))
+    traj, racts, outs = [], [], []
+    for s in range(starts_moving + steps):
+        human_actions = []
+        for h in env.humans:                                                            # crowd_sim_plus.py:1044-1056
+            ob = [obs(o) for o in env.humans if o is not h] + [obs(robot)]
+            state = types.SimpleNamespace(self_state=full(h), human_states=ob, static_obs=env.static_obstacles)
+            human_actions.append(ns["constrain_agent_action_exact"](env, h, predict(pol, state)))
+        if s < starts_moving:
+            want = A(0.0, 0.0)
+        else:
+            d = np.array([robot.gx - robot.px, robot.gy - robot.py])
+            want = A(*(d / max(np.linalg.norm(d), 1e-9) * robot.v_pref))
+        act = ns["constrain_agent_action_exact"](env, robot, want)
+        stat = act.vx != want.vx
+        r, done, info, dmin, coll, frozen, reached, cd = ns["step_outcome"](env, act, human_actions, stat, True)
+        outs.append([r, float(done), dmin, float(coll), float(reached)])
+        racts.append([want.vx, want.vy])
+        robot.px, robot.py = robot.compute_position(act, time_step)                     # Agent.step
+        robot.vx, robot.vy = act.vx, act.vy
+        for h, a in zip(env.humans, human_actions):                                     # Human.step
+            h.px, h.py = h.px + a.vx * time_step, h.py + a.vy * time_step
+            h.vx, h.vy = a.vx, a.vy
+            h.set_g_xy(h.px, h.py)
+        env.global_time += time_step
+        traj.append([[robot.px, robot.py]] + [[h.px, h.py] for h in env.humans])
+    np.savez(os.path.join(OUT, f"env_rollout_sfm_{tag}.npz"), rule=rule, n_humans=n_humans, seed=seed, steps=steps, starts_moving=starts_moving,
+             time_step=time_step, traj=np.array(traj), robot_wanted=np.array(racts), outcomes=np.array(outs), **start)
+    print("sfm rollout", tag, rule, n_humans, "steps", steps, "robot end", traj[-1][0])
+
+
 if __name__ == "__main__":
     ns = make_functions()
+    capture_sfm_calls(ns, "hallway", "hallway", 300, 71)
+    capture_sfm_calls(ns, "bottleneck", "hallway_bottleneck", 300, 72, n_others=4)
+    capture_sfm_rollout(ns, "hallway_n3", "hallway", 3, 81, 30)
+    capture_sfm_rollout(ns, "static_n4", "hallway_static", 4, 82, 40)
+    capture_sfm_rollout(ns, "bottleneck_n3", "hallway_bottleneck", 3, 83, 30)
     capture_orca_plus_calls(ns, "hallway_n3", "hallway", 3, 61)
     capture_orca_plus_calls(ns, "static_n5", "hallway_static", 5, 62)
     capture_orca_plus_calls(ns, "near_goal", "hallway_bottleneck", 2, 63, near_goal=True)
