@@ -687,11 +687,21 @@ class HallwayConfig:
     sfm: SFMParams = SFMParams()            # [humans] A, B, KI, A_static, ... (the sfm policy's constants)
 
 
-def hallway_starts(E: int, N: int, seed: int, cfg: HallwayConfig) -> Dict[str, np.ndarray]:
+def reference_case_seed(phase: str, case: int, val_size: int = 100, test_size: int = 500) -> int:
+    """The seed ``reset`` gives the generator of test case ``case`` of a phase (``crowd_sim_plus.py:656-663``: counter_offset =
+    {train: val_size + test_size, val: 0, test: val_size} + the case counter; sizes from env.config ``[env] val_size, test_size``)."""
+    return {"train": val_size + test_size, "val": 0, "test": val_size}[phase] + int(case)
+
+
+def hallway_starts(E: int, N: int, seed: int, cfg: HallwayConfig, reference_cases: Optional[str] = None) -> Dict[str, np.ndarray]:
     """Start record of E hallway episodes (``reset``, ``crowd_sim_plus.py:660-672``: robot at (0, -R) heading for (0, R), then the
-    walls of the rule, then N humans by ``generate_hallway_human``), every episode on its own generator
-    ``episodes.episode_rng(seed, e)``.  Index 0 of the agent axis is the robot."""
+    walls of the rule, then N humans by ``generate_hallway_human``), every episode on its own generator: by default
+    ``episodes.episode_rng(seed, e)``; with ``reference_cases`` = "test" / "val" / "train" episode e IS the reference's case
+    ``seed + e`` of that phase - ``np.random.default_rng(reference_case_seed(phase, seed + e))``, the crowd ``reset(phase,
+    test_case=seed + e)`` places.  Index 0 of the agent axis is the robot."""
     from .episodes import episode_rng
+    if reference_cases is not None:
+        episode_rng = lambda sd, e: np.random.default_rng(reference_case_seed(reference_cases, sd + e))      # noqa: E731
     R = cfg.geometry.circle_radius
     pos, goal = np.zeros((E, N + 1, 2)), np.zeros((E, N + 1, 2))
     rad = np.full((E, N + 1), cfg.human_radius)
