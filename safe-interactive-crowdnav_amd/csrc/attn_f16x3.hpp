@@ -524,7 +524,15 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
 #pragma unroll
         for (int r = 0; r < 16; ++r) sm[r] = 0.f;
         constexpr int PFD = 3;        // PF: fragment reads PFD steps ahead (4: no better)
-        f16x8 vpre[PFD];      // the first V^T fragments, requested before the softmax
+        // ATT_ISSUE_AT (tools/attn_issue_probe.hip only; 0 = what ships): where the copies of tile kt + 1 go out.  0: one per QK^T step, behind
+        // that step's matrix instruction.  1: all of them between the last QK^T instruction and the softmax.  2: the same, after ALL eight V^T
+        // fragments of this tile have been read into registers - the wave touches LDS again only after its wait at the top of the next tile
+#ifdef ATT_ISSUE_AT
+        constexpr int IA = (MX && PF && P1 && X2) ? ATT_ISSUE_AT : 0;
+#else
+        constexpr int IA = 0;
+#endif
+        f16x8 vpre[IA >= 2 ? 2 * NT : PFD];      // the first V^T fragments, requested before the softmax
         if (MX && PF) {
             // PF: fragment reads three steps ahead (one MFMA per step covers 32 cycles of an LDS round trip of > 64), the bf8 K
             // fragments requested inside the fp16 loop, the first V^T fragments before the softmax
@@ -547,10 +555,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                     k8f[blk][1][0] = k8read(1, blk, 0); k8f[blk][1][1] = k8read(1, blk, 1);
                 }
                 sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qh[ks], sm, 0, 0, 0);
-                if (more && !(abl & 16)) issue_one(kt + 1, ks, 1 - STG);
+                if (IA == 0 && more && !(abl & 16)) issue_one(kt + 1, ks, 1 - STG);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (P1) {
+            if (P1 && IA < 2) {
 #pragma unroll
                 for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i & 3) * 1024 + vbase[i >> 2]);
             }
@@ -563,6 +571,16 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 sm = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kl8, q8h[blk], sm, 1, 1, 0, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (IA >= 2) {      // (behind the bf8 instructions: their K fragments are dead, 32 registers are free)
+#pragma unroll
+                for (int i = 0; i < 2 * NT; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i & 3) * 1024 + vbase[i >> 2]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (IA >= 1 && more) {
+                if (IA == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers before the first copy goes out (3: no wait)
+                issue(kt + 1, 1 - STG);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         } else if (MX) {
             // fp16 part: K_hi . Q_hi, fragments read one step ahead; the next tile's DMA instructions go out one per step
             f16x8 kh_c = *reinterpret_cast<const f16x8*>(Kh + kbase + (((0 + hi) ^ kx) << 3));
@@ -681,7 +699,8 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             for (int i = 0; i < PFD; ++i) vf[i] = vpre[i];
 #pragma unroll
             for (int i = 0; i < 2 * NT; ++i) {
-                if (i + PFD < 2 * NT) vf[i + PFD] = *reinterpret_cast<const f16x8*>(Vh + ((i + PFD) & 3) * 1024 + vbase[(i + PFD) >> 2]);
+                if (IA >= 2) vf[i] = vpre[i];
+                else if (i + PFD < 2 * NT) vf[i + PFD] = *reinterpret_cast<const f16x8*>(Vh + ((i + PFD) & 3) * 1024 + vbase[(i + PFD) >> 2]);
                 ot[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[i], ph[i >> 2], ot[i & 3], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }

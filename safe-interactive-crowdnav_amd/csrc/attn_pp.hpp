@@ -33,8 +33,8 @@
 // slots = 966 cycles: the measured number) - the softmax is bound by ISSUE SLOTS, and no placement of it changes their count;
 // (3) an LDS-DMA copy needs ~1 500 cycles from issue to landed under this load (most K / V^T lines come from the Infinity Cache), half
 // a segment more than the vector segment lasts; (4) deferring the wait to the end of the wave's NEXT compute segment - what the third
-// ring stage was built for (-DATT_PP_LATE_WAIT) - makes that compute segment 1 667 cycles long: a wave's LDS reads stall while its own
-// LDS-DMA copies are in flight, so the copies can only be issued by a wave that reads no LDS until they land.  With no copies at all
+// ring stage was built for (-DATT_PP_LATE_WAIT) - makes that compute segment 1 667 cycles long: the wait for the copies' remaining
+// flight sits inside it then (not stalled fragment reads: tools/attn_issue_probe.hip on the two-wave kernel).  With no copies at all
 // in the loop (-DATT_PP_NO_DMA, wrong results) a tile still takes 2 470-2 600 cycles: two serialised segments of ~960 plus ~250
 // per barrier.  The shipped kernel's 2 660 cycles per tile is within 8 % of what this structure can reach; what would move both is
 // fewer vector instructions per key (docs/NOTEBOOK.md section 10).
@@ -376,8 +376,8 @@ __global__ __launch_bounds__(512, 1) void attn_pp_kernel(AttnHArgs a, int nqt) {
 #endif
     // closes a segment.  `after_compute`: the barrier behind a compute segment (or the prologue).  A wave's copies are waited for at
     // the end of the VECTOR segment that issued them: deferring the wait to the end of the wave's next compute segment
-    // (-DATT_PP_LATE_WAIT; the ring has the third stage for it) lengthens that compute segment from 905 to 1 667 cycles - a wave's LDS
-    // reads stall while its own LDS-DMA copies are in flight (tools/attn_pp_check.hip -DATT_PP_TRACE, docs/NOTEBOOK.md section 10)
+    // (-DATT_PP_LATE_WAIT; the ring has the third stage for it) lengthens that compute segment from 905 to 1 667 cycles - the rest
+    // of the copies' ~1 500-cycle flight is then paid there (tools/attn_pp_check.hip -DATT_PP_TRACE, docs/NOTEBOOK.md section 10)
     auto bar = [&](bool after_compute) {
 #ifdef ATT_PP_LATE_WAIT
         const bool landed = after_compute;
