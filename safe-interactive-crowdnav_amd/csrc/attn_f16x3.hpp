@@ -911,8 +911,8 @@ inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t 
     static DevSeen seen;
     const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1, PF>;
     if (auto once_ = first_use_on_device(seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ATT_DMA_LDS);
-    hipLaunchKernelGGL(kern, grid, dim3(256), ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, grid, dim3(256), tune().attn_one_wg ? 160 * 1024 : ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }
 
 #ifdef JMID_EXPERIMENTS
@@ -927,6 +927,13 @@ inline hipError_t launch_attn_q64(const AttnHArgs& a_in, int nseq, hipStream_t s
 // file; bit-identical, measured no faster - docs/NOTEBOOK.md section 10)
 inline bool attn_pp_applies(const AttnHArgs& a, int nseq);
 inline void launch_attn_pp(AttnHArgs a, int nseq, hipStream_t st);
+#endif
+
+#ifdef JMID_EXPERIMENTS
+// experiment (knob "attn_k64" = 1): F16MX / F16X2 launches without a key split on 64-key tiles - two softmax rounds per tile, their P.V
+// products behind one wait and one barrier (attn_k64.hpp, included at the end of this file; bit-identical, measured 0-4 % slower)
+inline bool attn_k64_applies(const AttnHArgs& a);
+inline void launch_attn_k64(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
 #endif
 
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
@@ -948,6 +955,11 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 #ifdef JMID_EXPERIMENTS
         if (attn_pp_applies(a, nseq)) {
             launch_attn_pp(a, nseq, st);
+        } else
+#endif
+#ifdef JMID_EXPERIMENTS
+        if (attn_k64_applies(a)) {
+            launch_attn_k64(a, nseq, nqt, st);
         } else
 #endif
         if (a.x2 && a.K8h) {
@@ -982,6 +994,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 }  // namespace jmid
 
 #ifdef JMID_EXPERIMENTS
+#include "attn_k64.hpp"
 #include "attn_pp.hpp"
 #include "attn_q64.hpp"
 #endif

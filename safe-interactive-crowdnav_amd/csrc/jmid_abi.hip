@@ -434,6 +434,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_mx", &Tuning::attn_mx, 0, 3},
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"attn_pf", &Tuning::attn_pf, 0, 2},
+        {"attn_one_wg", &Tuning::attn_one_wg, 0, 1},
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"h1_stage", &Tuning::h1_stage, 0, 2},
@@ -442,6 +443,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 #endif
 #ifdef JMID_EXPERIMENTS
         {"attn_pp", &Tuning::attn_pp, 0, 2},
+        {"attn_k64", &Tuning::attn_k64, 0, 2},
 #endif
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},

@@ -567,6 +567,32 @@ def test_attention_pingpong_equals_the_two_wave_kernel(E, A, K, T, precision):
     assert ade(out[1][:1], ref.numpy()) <= ADE_GATE
 
 
+@needs_experiments
+@pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
+@pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (3, 3, 7, 5), (2, 25, 16, 12), (9, 5, 20, 11)])
+def test_attention_on_64_key_tiles_equals_the_32_key_kernel(E, A, K, T, precision):
+    """attn_k64_kernel (experiment, knob "attn_k64" = 1: two softmax rounds per 64-key tile, their P.V products behind one wait and one barrier,
+    K double- and V^T single-buffered in 80 KB; csrc/attn_k64.hpp) runs the 32-key kernel's rounds instruction for instruction: bit-identical
+    outputs in both modes it serves, on S = 1200, 105, 4800 (dense) and 1100 (an odd number of 32-key sub-tiles: the last tile's second half
+    lies past the sequence) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
+    eng, w = get_engine(256, 23, True, "exp")
+    eng.set_step(4)
+    g = torch.Generator().manual_seed(41 + E)
+    ctx = torch.randn([E, A, 256], generator=g).cuda()
+    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
+    out = {}
+    try:
+        for v in (2, 1):
+            eng.set_tuning("attn_k64", v)
+            out[v] = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
+    finally:
+        eng.set_tuning("attn_k64", 0)
+    np.testing.assert_array_equal(out[1], out[2])
+    with torch.no_grad():
+        ref = O.denoise(w.tensors, ctx[:1].cpu(), x_T[:1].cpu(), sample=K, step=4, joint=True)
+    assert ade(out[1][:1], ref.numpy()) <= ADE_GATE
+
+
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
                ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),

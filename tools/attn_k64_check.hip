@@ -1,0 +1,142 @@
+// attn_k64_kernel (64-key tiles, attn_k64.hpp) against attn_f16x3_dma_kernel<MX / X2, P1, PF> (32-key tiles) on the same random planes: bitwise
+// comparison of the O_hi plane, then the time per launch of each.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops -w \
+//         -DJMID_DIAGNOSTICS -DJMID_EXPERIMENTS -I safe-interactive-crowdnav_amd/csrc -I include tools/attn_k64_check.hip -o build/attn_k64_check
+//   build/attn_k64_check [nseq = 51] [S = 1200] [reps = 20] [mode: 0 = F16MX operands, 1 = F16X2] [logit scale = 0.35]
+//   ONE_WG=1 in the environment: both kernels with ONE workgroup per CU (a wave alone on its SIMD); -DATT_K64_TRACE: cycle stamps (spills: perturbed)
+#include "attn_f16x3.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+using namespace jmid;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int nseq = argc > 1 ? atoi(argv[1]) : 51, S = argc > 2 ? atoi(argv[2]) : 1200, reps = argc > 3 ? atoi(argv[3]) : 20;
+    const int mode = argc > 4 ? atoi(argv[4]) : 0; const float qscale = argc > 5 ? (float)atof(argv[5]) : 0.35f;      // 0 = F16MX operands (bf8 K images), 1 = F16X2 (fp16 K_lo, Q_lo), 2 = F16X3 (+ V^T_lo, P_lo)
+    const int d = 512, nhead = 4, hd = 128, Spad = vt_spad(S);
+    const size_t M = (size_t)nseq * S, Mpad = (M + 127) / 128 * 128 + 128;
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<half_t> qh(Mpad * d), kh(Mpad * d), vt((size_t)nseq * d * Spad), ql(Mpad * d), kl(Mpad * d), vtl((size_t)nseq * d * Spad);
+    std::vector<unsigned char> q8l(Mpad * d), k8h(Mpad * d), k8l(Mpad * d);
+    auto top = [](half_t v) { return (unsigned char)((__builtin_bit_cast(unsigned short, v) + 0x80u) >> 8); };
+    for (size_t i = 0; i < qh.size(); ++i) {
+        const float q = nd(rng) * qscale, k = nd(rng);
+        qh[i] = (half_t)q; kh[i] = (half_t)k;
+        ql[i] = (half_t)(q - (float)qh[i]);
+        kl[i] = (half_t)(k - (float)kh[i]);
+        q8l[i] = top((half_t)(q - (float)qh[i]));
+        k8h[i] = top(kh[i]);
+        k8l[i] = top((half_t)(k - (float)kh[i]));
+    }
+    for (size_t i = 0; i < vt.size(); ++i) { const float v = nd(rng); vt[i] = (half_t)v; vtl[i] = (half_t)(v - (float)vt[i]); }
+    half_t *dQ, *dK, *dV, *dO[2], *dQl, *dKl, *dVl, *dOl;
+    unsigned char *dQ8, *dK8h, *dK8l;
+    int* flag;
+    const size_t oelems = blk_plane_elems(M, d) + 128 * d;
+    CK(hipMalloc(&dQ, qh.size() * 2)); CK(hipMalloc(&dK, kh.size() * 2)); CK(hipMalloc(&dV, vt.size() * 2));
+    CK(hipMalloc(&dQl, ql.size() * 2)); CK(hipMalloc(&dKl, kl.size() * 2)); CK(hipMalloc(&dVl, vtl.size() * 2));
+    CK(hipMemcpy(dQl, ql.data(), ql.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dKl, kl.data(), kl.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dVl, vtl.data(), vtl.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dQ8, q8l.size())); CK(hipMalloc(&dK8h, k8h.size())); CK(hipMalloc(&dK8l, k8l.size()));
+    CK(hipMalloc(&dO[0], oelems * 2)); CK(hipMalloc(&dO[1], oelems * 2)); CK(hipMalloc(&dOl, oelems * 2)); CK(hipMalloc(&flag, 4));
+    CK(hipMemcpy(dQ, qh.data(), qh.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dK, kh.data(), kh.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dV, vt.data(), vt.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dQ8, q8l.data(), q8l.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dK8h, k8h.data(), k8h.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dK8l, k8l.data(), k8l.size(), hipMemcpyHostToDevice));
+    CK(hipMemset(flag, 0, 4));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    Tuning tn[2];
+    tn[0].attn_k64 = 2;      // the 32-key kernel
+    tn[1].attn_k64 = 1;      // the 64-key kernel
+    if (getenv("ONE_WG")) tn[0].attn_one_wg = tn[1].attn_one_wg = 1;      // one workgroup per CU: a wave alone on its SIMD
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int round = 0; round < 3; ++round)      // alternating: the chip's clock follows its power budget, a kernel timed first runs faster
+    for (int v = 0; v < 2; ++v) {
+        if (round == 0) CK(hipMemset(dO[v], 0, oelems * 2));
+        AttnHArgs a{dQ, reinterpret_cast<half_t*>(dQ8), dK, nullptr, dV, nullptr, dO[v], nullptr, S, Spad, d, nhead, 1.f, flag, 1, nullptr, nullptr, 1,
+                    dK8h, dK8l, dQ8};
+        if (mode >= 1) { a.Qlo = dQl; a.Klo = dKl; a.K8h = a.K8l = a.Q8l = nullptr; }
+        if (mode == 2) { a.Vtlo = dVl; a.Olo = dOl; a.x2 = 0; }
+        TuneScope ts(&tn[v]);
+        CK(launch_attn_f16x3(a, nseq, hd, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; ++r) CK(launch_attn_f16x3(a, nseq, hd, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double fl = 4.0 * nseq * (double)S * S * d;
+        printf("%s: %.4f ms per launch  (%.0f TFLOP/s algorithmic)\n", v ? "64-key tiles" : "32-key tiles", ms / reps,
+               fl / (ms / reps * 1e-3) * 1e-12);
+    }
+#ifdef ATT_K64_TRACE
+    {
+        const int nqt = (S + 127) / 128, nblk = nqt * nhead * nseq;
+        unsigned long long* tr;
+        CK(hipMalloc(&tr, (size_t)nblk * 4 * 8 * 8));
+        CK(hipMemset(tr, 0, (size_t)nblk * 4 * 8 * 8));
+        AttnHArgs a{dQ, reinterpret_cast<half_t*>(dQ8), dK, nullptr, dV, nullptr, dO[1], nullptr, S, Spad, d, nhead, 1.f, flag, 1, reinterpret_cast<float*>(tr), nullptr, 1,
+                    dK8h, dK8l, dQ8};
+        if (mode >= 1) { a.Qlo = dQl; a.Klo = dKl; a.K8h = a.K8l = a.Q8l = nullptr; }
+        TuneScope ts(&tn[1]);
+        for (int rep = 0; rep < 3; ++rep) CK(launch_attn_f16x3(a, nseq, hd, st));
+        CK(hipStreamSynchronize(st));
+        std::vector<unsigned long long> t((size_t)nblk * 4 * 8);
+        CK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+        const char* names[6] = {"wait K", "barrier A", "logits", "softmax", "wait V + barrier B", "P.V"};
+        double sum[6] = {0};
+        size_t nw = 0;
+        for (size_t w = 0; w < (size_t)nblk * 4; ++w) {
+            if (!t[w * 8 + 2]) continue;
+            ++nw;
+            for (int i = 0; i < 6; ++i) sum[i] += (double)t[w * 8 + i];
+        }
+        const double nt32 = (S + 31) / 32;
+        double tot = 0;
+        for (int i = 0; i < 6; ++i) tot += sum[i];
+        printf("64-key kernel, traced: %zu active waves; cycles per wave per 32 keys:", nw);
+        for (int i = 0; i < 6; ++i) printf("  %s %.0f", names[i], sum[i] / nw / nt32);
+        printf("  total %.0f\n", tot / nw / nt32);
+    }
+#endif
+    std::vector<half_t> o0(oelems), o1(oelems);
+    CK(hipMemcpy(o0.data(), dO[0], oelems * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(o1.data(), dO[1], oelems * 2, hipMemcpyDeviceToHost));
+    size_t ndiff = 0;
+    int qhist[64] = {0}, chist[8] = {0}, shown = 0;
+    double maxd = 0;
+    for (size_t m = 0; m < M; ++m)
+        for (int c = 0; c < d; ++c) {
+            const size_t o = blk_index((int)m, c, d);
+            if (__builtin_bit_cast(unsigned short, o0[o]) != __builtin_bit_cast(unsigned short, o1[o])) {
+                ++ndiff;
+                ++qhist[(m % S) % 64];
+                ++chist[(c % 128) / 16];
+                const double dd = fabs((double)(float)o0[o] - (double)(float)o1[o]);
+                if (dd > maxd) maxd = dd;
+                if (shown < 6) { printf("  token %zu (q %zu of its sequence) col %d: %g vs %g\n", m, m % S, c, (float)o0[o], (float)o1[o]); ++shown; }
+            }
+        }
+    printf("differing elements: %zu of %zu, max |d| %g\n", ndiff, M * d, maxd);
+    if (ndiff) {
+        printf("  by query %% 64:");
+        for (int i = 0; i < 64; ++i) printf(" %d", qhist[i]);
+        printf("\n  by (head dim %% 128) / 16:");
+        for (int i = 0; i < 8; ++i) printf(" %d", chist[i]);
+        printf("\n");
+    }
+    int f = 0;
+    CK(hipMemcpy(&f, flag, 4, hipMemcpyDeviceToHost));
+    printf("range flag %d\n", f);
+    return ndiff != 0;
+}
