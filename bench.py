@@ -385,9 +385,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=2,
                     help="chunks of the denoise loop in flight at once (1..4; the library's default is 2; results are the same bits)")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--scenes", default="cv", choices=["cv", "orca", "hallway", "hallway_sfm"],
+    ap.add_argument("--scenes", default="cv", choices=["cv", "orca", "square", "hallway", "hallway_sfm"],
                     help="synthetic histories: cv = constant-velocity agents (SURVEY 8d), orca = batched circle-crossing "
-                         "crowds of ORCA agents (episodes.py), hallway = the reference's shipped scenario: a corridor with walls and "
+                         "crowds of ORCA agents, square = the same under the square-crossing rule (episodes.py), hallway = the reference's shipped scenario: a corridor with walls and "
                          "orca_plus humans, hallway_sfm = the same with the reference's social-force humans (crowd_env.py; SURVEY 8f row f3); all "
                          "agents forced in-cluster either way")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -456,8 +456,8 @@ def main():
     # ---- synthetic scene batches, resident in HBM before the timed region (what it costs to put them there is timed too and
     # reported as `host_feed`: it is OUTSIDE `value`, which is quoted with inputs already resident, as the bench contract says)
     t_feed = time.perf_counter()
-    if args.scenes in ("orca", "hallway", "hallway_sfm"):
-        from safe_interactive_crowdnav_amd.episodes import history_windows, simulate_circle_crossing
+    if args.scenes in ("orca", "square", "hallway", "hallway_sfm"):
+        from safe_interactive_crowdnav_amd.episodes import history_windows, simulate_crossing
         frame = 12                       # 3 s into the episode: the crowd is interacting
         if args.scenes.startswith("hallway"):     # the reference's SHIPPED scenario (env.config [sim] test_sim = hallway): walls and
             # orca_plus humans - or its social-force humans ([humans] policy = sfm: pinned to the reference end to end)
@@ -465,7 +465,7 @@ def main():
             hc = HallwayConfig(human_policy="sfm" if args.scenes == "hallway_sfm" else "orca_plus")
             sim = simulate_hallway(E, N, frame + H, seed=args.seed * 1000 + rank, cfg=hc, robot="goal" if args.scenes == "hallway_sfm" else "orca")
         else:
-            sim = simulate_circle_crossing(E, N, frame + H, seed=args.seed * 1000 + rank)
+            sim = simulate_crossing(E, N, frame + H, seed=args.seed * 1000 + rank, rule="square_crossing" if args.scenes == "square" else "circle_crossing")
         hum, rob = history_windows(sim, frame)
         syn = build_scenes_batched(hum, rob, 0.25, force_all_in_cluster=True)
         syn["gt"] = np.ascontiguousarray(sim["human_xy"][:, frame + 1:frame + 1 + H].transpose(0, 2, 1, 3), np.float32)

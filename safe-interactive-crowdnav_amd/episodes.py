@@ -4,8 +4,8 @@ The reference produces the histories the predictor sees by stepping ``CrowdSimPl
 (``crowd_sim_plus/envs/crowd_sim_plus.py:609-765`` reset, ``:1025-1258`` step), every human choosing its velocity
 with ORCA through Python-RVO2 (``crowd_sim_plus/envs/policy/orca.py:82-133``: a fresh simulator per step and per
 human, the human as agent 0, everybody else's preferred velocity (0, 0)).  For BASELINE configs 3 and 5 (256 - 4096
-parallel episodes) this module does the same for E episodes at once, in NumPy on the host: circle-crossing
-placement (``crowd_sim_plus.py:454-481``), agent-agent ORCA for every (episode, agent) pair in one vectorised pass
+parallel episodes) this module does the same for E episodes at once, in NumPy on the host: circle-crossing and
+square-crossing placement (``crowd_sim_plus.py:454-481, 484-520``), agent-agent ORCA for every (episode, agent) pair in one vectorised pass
 (half-plane construction and the incremental 2-D linear programs of RVO2's ``Agent::computeNewVelocity`` /
 ``linearProgram1-3``; van den Berg et al., ISRR 2011), holonomic position update.  It stays on the host like the
 rest of the simulator: a few thousand 2-D LPs with <= 10 constraints per step are microseconds of work next to the
@@ -13,8 +13,8 @@ denoise loop, and the MPC side that consumes the same states lives there too.
 
 PARITY: partially pinned.  Everything the reference itself computes around rvo2 is pinned bit for bit by fixtures that
 ``tests/golden/make_golden_episodes.py`` generates by executing the reference's own lines against stand-ins
-(``tests/golden/episodes_*.npz``): the circle-crossing placement incl. its draw order from the generator
-(``crowd_sim_plus.py:454-481``; ``place_circle_crossing_humans``), and what is handed to rvo2 per step - simulator and agent
+(``tests/golden/episodes_*.npz``): the circle-crossing and the square-crossing placement incl. their draw order from the
+generator (``crowd_sim_plus.py:454-481, 484-520``; ``place_circle_crossing_humans``, ``place_square_crossing_humans``), and what is handed to rvo2 per step - simulator and agent
 parameters, inflated radii, speed limits, preferred velocities (``orca.py:56-67, 93-129``; ``orca_call_parameters``).
 rvo2 ITSELF (RVO2 Library 2.0.2 behind Python-RVO2) STAYS UNPINNED: it is an un-vendored C++ dependency, absent from the
 reference tree and from this image, so no output of its ORCA solver exists to compare with.  For that part what is
@@ -207,6 +207,7 @@ class CrowdConfig:
     """The fields of ``configs/env.config`` / ``orca.py`` the circle-crossing simulation reads."""
     time_step: float = 0.25                 # [env] time_step
     circle_radius: float = 4.0              # [sim] circle_radius (CrowdNav's circle crossing; the shipped 1.0 is the hallway's)
+    square_width: float = 5.0               # [sim] square_width (square crossing; the shipped value)
     human_radius: float = 0.20              # [humans] radius
     human_v_pref: float = 1.5               # [humans] v_pref (drawn from U(0.5, 1.5) with randomize_attributes)
     robot_radius: float = 0.25              # [robot] radius
@@ -258,15 +259,52 @@ def place_circle_crossing_humans(N: int, rng: np.random.Generator, cfg: CrowdCon
     return pos, goal, vp
 
 
+def place_square_crossing_humans(N: int, rng: np.random.Generator, cfg: CrowdConfig):
+    """``generate_square_crossing_human`` x N for ONE episode (``crowd_sim_plus.py:436-439, 484-520``), with the reference's draw
+    order: per human the preferred speed U(0.5, 1.5) when attributes are randomised, one draw for the side of the y axis it
+    starts on, then start positions (x on its side of the square, y anywhere in it) until one is at least radius + radius +
+    discomfort distance from every earlier agent's START, then goal positions on the other side until one is that far from
+    every earlier agent's GOAL (the robot at (0, -R) -> (0, R) is agent 0).  -> pos, goal [N, 2], v_pref [N].
+    Bit-equal to the reference's lines on the same generator (``tests/golden/episodes_square_placement_*.npz``)."""
+    R, W = cfg.circle_radius, cfg.square_width
+    starts, goals, radii = [(0.0, -R)], [(0.0, R)], [cfg.robot_radius]
+    pos, goal, vp = np.zeros((N, 2)), np.zeros((N, 2)), np.full(N, cfg.human_v_pref)
+
+    def draw(side, taken):
+        for _ in range(100000):
+            x = rng.random() * W * 0.5 * side
+            y = (rng.random() - 0.5) * W
+            if not any(np.linalg.norm((x - tx, y - ty)) < cfg.human_radius + r + cfg.discomfort_dist for (tx, ty), r in zip(taken, radii)):
+                return x, y
+        raise RuntimeError("square crossing placement did not converge (square too small for the crowd?)")
+
+    for h in range(N):
+        if cfg.randomize_attributes:
+            vp[h] = rng.uniform(0.5, 1.5)
+        sign = -1 if rng.random() > 0.5 else 1
+        pos[h] = draw(sign, starts)
+        goal[h] = draw(-sign, goals)
+        starts.append(tuple(pos[h]))
+        goals.append(tuple(goal[h]))
+        radii.append(cfg.human_radius)
+    return pos, goal, vp
+
+
 def episode_rng(seed: int, episode: int) -> np.random.Generator:
     """The generator of one episode: a child stream of ``seed``, so that an episode's crowd does not depend on how many
     episodes are generated with it, and different seeds (ranks of a sweep) never share a stream."""
     return np.random.default_rng(np.random.SeedSequence(entropy=int(seed), spawn_key=(int(episode),)))
 
 
-def circle_crossing_starts(E: int, N: int, seed: int, cfg: CrowdConfig) -> Dict[str, np.ndarray]:
-    """Start record of E circle-crossing episodes: every episode placed by ``place_circle_crossing_humans`` on its own
-    generator ``episode_rng(seed, e)``.  Index 0 of the agent axis is the robot."""
+PLACEMENT = {"circle_crossing": place_circle_crossing_humans, "square_crossing": place_square_crossing_humans}
+
+
+def crossing_starts(E: int, N: int, seed: int, cfg: CrowdConfig, rule: str = "circle_crossing") -> Dict[str, np.ndarray]:
+    """Start record of E crossing episodes (``rule``: ``circle_crossing`` or ``square_crossing``, crowd_sim_plus.py:436-443): every
+    episode placed by the rule's function on its own generator ``episode_rng(seed, e)``.  Index 0 of the agent axis is the
+    robot, at (0, -circle_radius) -> (0, circle_radius) under either rule (crowd_sim_plus.py:661)."""
+    if rule not in PLACEMENT:
+        raise ValueError(f"unknown crossing rule {rule!r} (the hallway rules live in crowd_env.py)")
     pos = np.zeros((E, N + 1, 2))
     goal = np.zeros((E, N + 1, 2))
     rad = np.full((E, N + 1), cfg.human_radius)
@@ -275,8 +313,12 @@ def circle_crossing_starts(E: int, N: int, seed: int, cfg: CrowdConfig) -> Dict[
     goal[:, 0] = (0.0, cfg.circle_radius)
     rad[:, 0], vp[:, 0] = cfg.robot_radius, cfg.robot_v_pref
     for e in range(E):
-        pos[e, 1:], goal[e, 1:], vp[e, 1:] = place_circle_crossing_humans(N, episode_rng(seed, e), cfg)
+        pos[e, 1:], goal[e, 1:], vp[e, 1:] = PLACEMENT[rule](N, episode_rng(seed, e), cfg)
     return dict(pos=pos, goal=goal, radius=rad, v_pref=vp)
+
+
+def circle_crossing_starts(E: int, N: int, seed: int, cfg: CrowdConfig) -> Dict[str, np.ndarray]:
+    return crossing_starts(E, N, seed, cfg, "circle_crossing")
 
 
 def orca_call_parameters(cfg: CrowdConfig, pos, vel, goal, radius, v_pref) -> Dict[str, np.ndarray]:
@@ -298,13 +340,19 @@ def orca_call_parameters(cfg: CrowdConfig, pos, vel, goal, radius, v_pref) -> Di
 
 def simulate_circle_crossing(E: int, N: int, steps: int, seed: int, cfg: Optional[CrowdConfig] = None
                              ) -> Dict[str, np.ndarray]:
-    """E independent circle-crossing episodes with N ORCA humans and an ORCA robot, ``steps`` simulator steps.
+    return simulate_crossing(E, N, steps, seed, cfg, "circle_crossing")
+
+
+def simulate_crossing(E: int, N: int, steps: int, seed: int, cfg: Optional[CrowdConfig] = None, rule: str = "circle_crossing"
+                      ) -> Dict[str, np.ndarray]:
+    """E independent crossing episodes (``rule``: circle or square crossing) with N ORCA humans and an ORCA robot, ``steps``
+    simulator steps.
 
     Returns human_xy [E, steps + 1, N, 2], robot_xy [E, steps + 1, 2], human_vel [E, steps + 1, N, 2], stamps
     [steps + 1] and the start record (goals, radii, v_pref): what ``update_state_hists`` is fed step by step in the
     reference's loop, for all episodes at once."""
     cfg = cfg or CrowdConfig()
-    st = circle_crossing_starts(E, N, seed, cfg)
+    st = crossing_starts(E, N, seed, cfg, rule)
     pos, goal = st["pos"].copy(), st["goal"]
     vel = np.zeros_like(pos)
     traj = np.zeros((E, steps + 1, N + 1, 2))

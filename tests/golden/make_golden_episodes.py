@@ -6,6 +6,8 @@ programs (crowd_sim_plus/envs/policy/orca.py:82-133 calls it) - stays UNPINNABLE
 What CAN be pinned is everything the reference itself computes around it, which is plain Python / NumPy:
     crowd_sim_plus/envs/crowd_sim_plus.py:454-481   generate_circle_crossing_human: circle placement with positional noise,
                                                     goal at the antipode, rejection against earlier agents' starts and goals
+    crowd_sim_plus/envs/crowd_sim_plus.py:484-520   generate_square_crossing_human: start on a random side of the y axis, goal on the
+                                                    other side, starts rejected against earlier starts, goals against earlier goals
     crowd_sim_plus/envs/policy/orca.py:56-67        the ORCA parameters (neighbour distance / count, time horizons, radius, speed)
     crowd_sim_plus/envs/policy/orca.py:93-129       what is handed to rvo2 per step: simulator and per-agent parameters, the
                                                     inflated radii (+ 0.01 + safety space), max speeds, preferred velocities
@@ -58,6 +60,27 @@ def capture_placement(tag, n_humans, seed, circle_radius, randomize, human_radiu
              pos=np.array([[h.px, h.py] for h in self.humans]), goal=np.array([[h.gx, h.gy] for h in self.humans]),
              v_pref=np.array([h.v_pref for h in self.humans]), rng_next=rng.random(4))
     print("placement", tag, len(self.humans))
+
+
+def capture_square_placement(tag, n_humans, seed, square_width, randomize, circle_radius=4.0, human_radius=0.20, human_v_pref=1.5,
+                             robot_radius=0.25, discomfort=0.2):
+    cfg = {"humans": {"radius": human_radius, "v_pref": human_v_pref}}
+    robot = types.SimpleNamespace(px=0.0, py=-circle_radius, gx=0.0, gy=circle_radius, radius=robot_radius)
+    self = types.SimpleNamespace(config=cfg, human_observability=None, randomize_attributes=randomize,
+                                 square_width=square_width, robot=robot, humans=[], discomfort_dist=discomfort)
+    src = "def generate_square_crossing_human(self, rng):\n" + textwrap.indent(
+        ref_lines("crowd_sim_plus.py", 490, 520), "    ")
+    ns = dict(np=np, norm=np.linalg.norm, Human=Human)
+    exec(src, ns)
+    rng = np.random.default_rng(seed)
+    for _ in range(n_humans):                       # crowd_sim_plus.py:437-439
+        self.humans.append(ns["generate_square_crossing_human"](self, rng))
+    np.savez(os.path.join(OUT, f"episodes_square_placement_{tag}.npz"), n_humans=n_humans, seed=seed, square_width=square_width,
+             circle_radius=circle_radius, randomize=randomize, human_radius=human_radius, human_v_pref=human_v_pref,
+             robot_radius=robot_radius, discomfort_dist=discomfort,
+             pos=np.array([[h.px, h.py] for h in self.humans]), goal=np.array([[h.gx, h.gy] for h in self.humans]),
+             v_pref=np.array([h.v_pref for h in self.humans]), rng_next=rng.random(4))
+    print("square placement", tag, len(self.humans))
 
 
 class RecordingSim:
@@ -120,6 +143,9 @@ if __name__ == "__main__":
     capture_placement("n5", 5, 11, 4.0, True)
     capture_placement("n25", 25, 12, 6.0, True)            # the dense crowd: many rejected draws
     capture_placement("n3_fixed_speed", 3, 13, 4.0, False)
+    capture_square_placement("n5", 5, 31, 5.0, True)
+    capture_square_placement("n20", 20, 32, 5.0, True)     # the shipped square_width with a dense crowd: many rejected draws
+    capture_square_placement("n4_fixed_speed", 4, 33, 8.0, False)
     capture_orca_calls("n5", 5, 21, 0.25)
     capture_orca_calls("n12", 12, 22, 0.25)                # more agents than max_neighbors
     capture_orca_calls("n3_near_goal", 3, 23, 0.1)

@@ -139,6 +139,44 @@ def test_circle_crossing_placement_matches_the_reference_lines(case):
     np.testing.assert_array_equal(rng.random(4), z["rng_next"])
 
 
+@pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "episodes_square_placement_*.npz"))))
+def test_square_crossing_placement_matches_the_reference_lines(case):
+    """crowd_sim_plus.py:490-520 executed by tests/golden/make_golden_episodes.py on numpy's default_rng(seed): the same starts
+    (rejected against earlier STARTS only), goals (against earlier GOALS only) and preferred speeds bit for bit, and the
+    generator left in the same state."""
+    z = np.load(os.path.join(GOLDEN, case))
+    cfg = EP.CrowdConfig(circle_radius=float(z["circle_radius"]), square_width=float(z["square_width"]),
+                         randomize_attributes=bool(z["randomize"]), human_radius=float(z["human_radius"]),
+                         human_v_pref=float(z["human_v_pref"]), robot_radius=float(z["robot_radius"]),
+                         discomfort_dist=float(z["discomfort_dist"]))
+    rng = np.random.default_rng(int(z["seed"]))
+    pos, goal, vp = EP.place_square_crossing_humans(int(z["n_humans"]), rng, cfg)
+    np.testing.assert_array_equal(pos, z["pos"])
+    np.testing.assert_array_equal(goal, z["goal"])
+    np.testing.assert_array_equal(vp, z["v_pref"])
+    np.testing.assert_array_equal(rng.random(4), z["rng_next"])
+    # every human crosses the y axis, inside the square
+    assert np.all(pos[:, 0] * goal[:, 0] <= 0) and np.all(np.abs(np.concatenate([pos, goal])) <= cfg.square_width / 2)
+
+
+def test_square_crossing_episodes_run_and_reach_their_goals():
+    """The square-crossing rule through the batched simulator: deterministic per (seed, episode), no pair of agents ever closer
+    than the sum of their radii, and most humans arrive (ORCA; the rule of crowd_sim_plus.py:436-439)."""
+    cfg = EP.CrowdConfig(square_width=8.0, circle_radius=4.0)
+    a = EP.simulate_crossing(6, 5, 60, seed=3, cfg=cfg, rule="square_crossing")
+    b = EP.simulate_crossing(3, 5, 60, seed=3, cfg=cfg, rule="square_crossing")
+    np.testing.assert_array_equal(a["human_xy"][:3], b["human_xy"])
+    xy = np.concatenate([a["robot_xy"][:, :, None], a["human_xy"]], axis=2)            # [E, T, n, 2]
+    d = np.linalg.norm(xy[:, :, :, None] - xy[:, :, None, :], axis=-1)
+    rr = a["radius"][:, None, :, None] + a["radius"][:, None, None, :]
+    iu = np.triu_indices(xy.shape[2], 1)
+    assert np.all((d - rr)[:, :, iu[0], iu[1]] > -1e-6)
+    left = np.linalg.norm(a["human_xy"][:, -1] - a["goal"][:, 1:], axis=-1)
+    assert np.mean(left < 0.5) > 0.7
+    with pytest.raises(ValueError):
+        EP.crossing_starts(1, 2, 0, cfg, "hallway")
+
+
 @pytest.mark.parametrize("case", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "episodes_orca_calls_*.npz"))))
 def test_orca_call_parameters_match_what_the_reference_hands_to_rvo2(case):
     """orca.py:56-67, 93-129 executed against a recording rvo2 stand-in: simulator parameters, per-agent parameters (inflated
