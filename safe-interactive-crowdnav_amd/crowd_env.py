@@ -729,7 +729,10 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
     place of ``hallway_starts`` (pos, goal [E, N + 1, 2], radius, v_pref [E, N + 1]).  Returns what ``simulate_circle_crossing``
     returns (positions from the moment the robot's clock starts, frame 0 = global time 0) plus per step the outcome block
     (``step_outcomes`` with the shipped rewards): ``collision``, ``dmin``, ``reached_goal``, ``timeout``, ``done``, ``reward`` [E, steps]
-    and the step at which each episode ended (``end_step``, -1 = still running)."""
+    and the step at which each episode ended (``end_step``, -1 = still running), and ``human_times`` [E, N]: the reference's record of
+    when a human first stood within its radius of its CURRENT goal - the door's centre while a sub-goal applies - on the
+    environment's clock, which starts at -starts_moving * time_step; 0 = not yet (``crowd_sim_plus.py:1203-1206`` with its quirk: a time
+    of exactly 0.0 reads as "not yet" and is overwritten by the next arrival test that fires)."""
     cfg = cfg or HallwayConfig()
     segs, doors = static_obstacles(cfg.rule, cfg.geometry)
     st = starts if starts is not None else hallway_starts(E, N, seed, cfg)
@@ -747,10 +750,12 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
     out = {k: np.zeros((E, steps), dtype=t) for k, t in (("collision", bool), ("dmin", float), ("reached_goal", bool), ("timeout", bool),
                                                           ("done", bool), ("reward", float), ("wall_collision", bool))}
     end_step = np.full(E, -1)
+    human_times = np.zeros((E, N))
+    global_time = -cfg.starts_moving * dt                      # crowd_sim_plus.py:712
+    goal = final_goal.copy()
+    goal[:, 1:] = door_subgoal(pos[:, 1:], final_goal[:, 1:], cfg.rule, doors, len(segs))
     for s in range(total):
         live = s >= cfg.starts_moving
-        goal = final_goal.copy()
-        goal[:, 1:] = door_subgoal(pos[:, 1:], final_goal[:, 1:], cfg.rule, doors, len(segs))
         new_vel = np.zeros_like(vel)
         if cfg.human_policy == "orca_plus" or (live and robot_mode == "orca"):
             par = orca_plus_parameters(pos, goal, radius, v_pref, cfg.safety_space, dt)
@@ -789,7 +794,13 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
             end_step = np.where((end_step < 0) & o["done"], k, end_step)
         vel = new_vel
         pos = pos + vel * dt
+        goal = final_goal.copy()                                   # Human.step: set_g_xy at the new position (human_plus.py:19-79)
+        goal[:, 1:] = door_subgoal(pos[:, 1:], final_goal[:, 1:], cfg.rule, doors, len(segs))
+        global_time += dt
+        arrived = _norm((pos[:, 1:] - goal[:, 1:]).reshape(-1, 2)).reshape(E, N) < radius[:, 1:]      # agent_plus.py:217
+        human_times = np.where((human_times == 0) & arrived, global_time, human_times)
         if live:
             traj[:, s - cfg.starts_moving + 1], vels[:, s - cfg.starts_moving + 1] = pos, vel
+    out["human_times"] = human_times
     return dict(human_xy=traj[:, :, 1:], robot_xy=traj[:, :, 0], human_vel=vels[:, :, 1:], stamps=np.arange(steps + 1) * dt,
                 goal=final_goal, radius=radius, v_pref=v_pref, segments=segs, end_step=end_step, **out)

@@ -14,6 +14,7 @@ produced are stored (tests/golden/env_*.npz): nothing of the reference's text is
     crowd_sim_plus.py:522-607    generate_hallway_human: placement with its draw order, rejection against robot, humans, walls
     crowd_sim_plus.py:869-989    constrain_agent_action_exact: an action cut short at walls and wall ends
     crowd_sim_plus.py:1067-1166  step(): collision / frozen / goal / timeout detection and the reward terms
+    crowd_sim_plus.py:1203-1206  step(): the first time a human reaches its (current) goal; utils/agent_plus.py:217 reached_destination
 
 Run in the build container:  python tests/golden/make_golden_env.py
 """
@@ -395,6 +396,18 @@ def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, 
     full = lambda a: types.SimpleNamespace(px=a.px, py=a.py, vx=a.vx, vy=a.vy, radius=a.radius, gx=a.gx, gy=a.gy, v_pref=a.v_pref)
     start = dict(pos=np.array([[h.px, h.py] for h in env.humans]), final_goal=np.array([[h.final_gx, h.final_gy] for h in env.humans]),
                  v_pref=np.array([h.v_pref for h in env.humans]))
+    # the human_times bookkeeping of step() (crowd_sim_plus.py:1203-1206) and Agent.reached_destination (utils/agent_plus.py:217), both
+    # executed from the reference's lines; the stand-in humans answer get_position / get_goal_position like agent_plus.py:136-144
+    env.human_times = [0] * n_humans
+    reached_src = "def reached_destination(self):\n" + textwrap.indent(ref_lines("utils/agent_plus.py", 217, 217), "    ")
+    times_src = "def record_human_times(self):\n" + textwrap.indent(ref_lines("crowd_sim_plus.py", 1203, 1206), "    ")
+    tns = dict(np=np, norm=np.linalg.norm)
+    exec(reached_src, tns)
+    exec(times_src, tns)
+    for h in env.humans:
+        h.get_position = (lambda self: (lambda: (self.px, self.py)))(h)
+        h.get_goal_position = (lambda self: (lambda: (self.gx, self.gy)))(h)
+        h.reached_destination = (lambda self: (lambda: tns["reached_destination"](self)))(h)
     traj, racts, outs = [], [], []
     for s in range(starts_moving + steps):
         human_actions = []
@@ -419,9 +432,11 @@ def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, 
             h.vx, h.vy = a.vx, a.vy
             h.set_g_xy(h.px, h.py)
         env.global_time += time_step
+        tns["record_human_times"](env)
         traj.append([[robot.px, robot.py]] + [[h.px, h.py] for h in env.humans])
     np.savez(os.path.join(OUT, f"env_rollout_sfm_{tag}.npz"), rule=rule, n_humans=n_humans, seed=seed, steps=steps, starts_moving=starts_moving,
-             time_step=time_step, traj=np.array(traj), robot_wanted=np.array(racts), outcomes=np.array(outs), **start)
+             time_step=time_step, traj=np.array(traj), robot_wanted=np.array(racts), outcomes=np.array(outs),
+             human_times=np.array(env.human_times, dtype=np.float64), **start)
     print("sfm rollout", tag, rule, n_humans, "steps", steps, "robot end", traj[-1][0])
 
 
@@ -432,6 +447,7 @@ if __name__ == "__main__":
     capture_sfm_rollout(ns, "hallway_n3", "hallway", 3, 81, 30)
     capture_sfm_rollout(ns, "static_n4", "hallway_static", 4, 82, 40)
     capture_sfm_rollout(ns, "bottleneck_n3", "hallway_bottleneck", 3, 83, 30)
+    capture_sfm_rollout(ns, "hallway_n4_long", "hallway", 4, 84, 70)      # long enough for humans to arrive: human_times
     capture_orca_plus_calls(ns, "hallway_n3", "hallway", 3, 61)
     capture_orca_plus_calls(ns, "static_n5", "hallway_static", 5, 62)
     capture_orca_plus_calls(ns, "near_goal", "hallway_bottleneck", 2, 63, near_goal=True)
