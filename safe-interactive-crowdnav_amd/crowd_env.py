@@ -11,6 +11,7 @@ simulator and the MPC live):
   ``door_subgoal``            ``Human.get_g_xy``                    ``utils/human_plus.py:19-52``    intermediate goal in front of a door
   ``place_hallway_humans``    ``generate_hallway_human``            ``crowd_sim_plus.py:522-607``   placement, with the draw order
   ``constrain_actions``       ``constrain_agent_action_exact``      ``crowd_sim_plus.py:869-989``   an action cut short at a wall
+  ``constrain_unicycle_actions``  the same, ``ActionRot`` branch     ``crowd_sim_plus.py:976-987``   the MPC's unicycle: |v| shrinks, r stays
   ``step_outcomes``           the outcome block of ``step()``       ``crowd_sim_plus.py:1067-1166`` flags, reward terms, done
   ``sfm_velocities``          ``SFM.predict``                       ``policy/social_force.py:38-95`` social-force humans
   ``orca_plus_parameters``    what ``ORCAPlus.predict`` hands rvo2  ``policy/orca_plus.py:43-84``
@@ -25,8 +26,10 @@ block, position updates - land on the positions the reference's lines produce st
 steps, <= 1e-10 m).  With the shipped ``orca_plus`` humans the velocities come out of rvo2, an un-vendored C++ dependency that is
 absent from the reference tree and from this image: ``obstacle_orca_lines`` (like the agent-agent half-planes and the linear
 programs of ``episodes.py``) restates its published algorithm and is UNPINNED, checked against a scalar restatement kept with the
-test infrastructure, by brute force and through properties (no agent of a generated crowd ever enters a wall).  Holonomic agents
-only (``ActionXY``): the humans always are, the robot of the shipped configuration is.
+test infrastructure, by brute force and through properties (no agent of a generated crowd ever enters a wall).  The humans are
+holonomic (``ActionXY``); the robot is either that or the MPC's unicycle (``ActionRot``, ``sicnav_acados.py:143``): wall constraint,
+outcome block, position / heading update in their ``ActionRot`` branches, pinned the same way incl. two whole episodes
+(``env_rotconstrain_*.npz``, ``env_step_outcomes_unicycle_*.npz``, ``env_rollout_sfm_unicycle_*.npz``).
 """
 from __future__ import annotations
 
@@ -263,9 +266,15 @@ def _closest_between_segments(a0, a1, b0, b1):
     return pA, pB, dist(pA, pB)
 
 
-def _constrain_one(cur, act, r, dt, segs):
-    """``constrain_agent_action_exact`` for one holonomic agent against the segments that its step comes within r of."""
-    fut = cur + act * dt
+def _constrain_one(cur, act, r, dt, segs, rot=None):
+    """``constrain_agent_action_exact`` for one agent against the segments that its step comes within r of.  Holonomic: ``act`` is
+    the velocity, the constrained velocity comes back.  ``rot`` = (theta, v, r_step) - the unicycle of ``agent_plus.py:175-185``
+    (heading theta + r_step, signed speed v): the constrained signed speed comes back (``crowd_sim_plus.py:976-987``)."""
+    if rot is not None:
+        th = rot[0] + rot[2]
+        fut = np.array([cur[0] + np.cos(th) * rot[1] * dt, cur[1] + np.sin(th) * rot[1] * dt])
+    else:
+        fut = cur + act * dt
     move = fut - cur
     move_mag = float(np.sqrt(move @ move))
     hits = []
@@ -273,7 +282,8 @@ def _constrain_one(cur, act, r, dt, segs):
         pA, pB, cd = _closest_between_segments(s[0], s[1], cur, fut)
         if cd - r < 0.0:
             hits.append((s, cd, pA, pB))
-    final = act.copy()
+    final = act.copy() if rot is None else None
+    final_v = rot[1] if rot is not None else None
     nrm = lambda v: float(np.sqrt(v @ v))
     for s, cd, pA, pB in hits:
         if (nrm(pA - s[0]) < 1e-8 or nrm(pA - s[1]) < 1e-8) and nrm(pA - pB) > 1e-8:
@@ -311,10 +321,19 @@ def _constrain_one(cur, act, r, dt, segs):
                 fin = cur + np.array([ix - cur[0], iy - cur[1]]) * max(0.0, (dc0 - (r + 1e-7)) / dc0)
             else:
                 fin = cur
+        if rot is not None:                                                     # the rotation stays, |v| shrinks
+            step = fin - cur
+            vv = float(np.sqrt(step @ step)) / dt
+            if rot[1] > 0:
+                if vv < final_v:
+                    final_v = vv
+            elif -vv > final_v:
+                final_v = -vv
+            continue
         cand = (fin - cur) / dt
         if cand[0] ** 2 + cand[1] ** 2 < final[0] ** 2 + final[1] ** 2:       # the slowest of the candidates wins
             final = cand
-    return final
+    return final if rot is None else final_v
 
 
 def constrain_actions(pos, action, radius, time_step: float, segments) -> np.ndarray:
@@ -341,6 +360,30 @@ def constrain_actions(pos, action, radius, time_step: float, segments) -> np.nda
 
 
 # ------------------------------------------------------------------------------------------------ step outcomes
+def constrain_unicycle_actions(pos, theta, v, r_step, radius, time_step: float, segments) -> np.ndarray:
+    """``constrain_agent_action_exact`` for B non-holonomic agents (the MPC's robot: ``ActionRot(v, r)``, the step goes along heading
+    theta + r with signed speed v, ``agent_plus.py:175-185``): the speeds actually driven [B] - the rotation is kept as commanded
+    (``crowd_sim_plus.py:976-987``).  Pinned by ``tests/golden/env_rotconstrain_*.npz``."""
+    pos = np.asarray(pos, np.float64)
+    B = pos.shape[0]
+    theta, v, r_step = (np.broadcast_to(np.asarray(a, np.float64), (B,)) for a in (theta, v, r_step))
+    segments = np.asarray(segments, np.float64).reshape(-1, 2, 2)
+    out = np.array(v, np.float64)
+    if B == 0 or len(segments) == 0:
+        return out
+    radius = np.broadcast_to(np.asarray(radius, np.float64), (B,))
+    vel = np.stack([np.cos(theta + r_step) * v, np.sin(theta + r_step) * v], axis=1)
+    mid = pos + 0.5 * time_step * vel
+    reach = 0.5 * time_step * np.abs(v) + radius + 1e-6
+    d = _point_segment_dist(segments[None, :, 0, 0], segments[None, :, 0, 1], segments[None, :, 1, 0], segments[None, :, 1, 1],
+                            mid[:, None, 0], mid[:, None, 1])
+    near = d < reach[:, None]
+    for b in np.nonzero(near.any(axis=1))[0]:
+        out[b] = _constrain_one(pos[b], None, float(radius[b]), time_step, segments[near[b]],
+                                rot=(float(theta[b]), float(v[b]), float(r_step[b])))
+    return out
+
+
 INFO_KEYS = ("ReachGoal", "Timeout", "Collision", "WallCollision", "Frozen", "Danger", "Progress", "AngularSmoothness",
              "LinearSmoothness")
 
@@ -354,8 +397,11 @@ def shipped_rewards() -> Dict[str, float]:
 
 def step_outcomes(robot_pos, robot_action, robot_goal, robot_radius, human_pos, human_action, human_radius, global_time,
                   time_limit: float, time_step: float, rewards: Dict[str, float], stat_collision=None, prev_dist_to_goal=None,
-                  prev_angular=None, prev_linear=None, detailed: bool = False) -> Dict[str, np.ndarray]:
-    """The outcome block of ``CrowdSimPlus.step`` (``crowd_sim_plus.py:1067-1166``) for E episodes at once, holonomic robot.
+                  prev_angular=None, prev_linear=None, detailed: bool = False, robot_rot=None) -> Dict[str, np.ndarray]:
+    """The outcome block of ``CrowdSimPlus.step`` (``crowd_sim_plus.py:1067-1166``) for E episodes at once.  Holonomic robot:
+    ``robot_action`` [E, 2] is its velocity.  The MPC's unicycle (``sicnav_acados.py:143``): ``robot_rot`` = (theta [E], v [E], r [E]) -
+    ``ActionRot(v, r)`` on heading theta, the step goes along theta + r (``agent_plus.py:175-185``; ``robot_action`` is ignored); "frozen"
+    tests |v|, the angular term is |r| * time_step, the linear term compares the SIGNED speeds (``:1085-1088, 1144-1164``).
 
     robot_pos, robot_action, robot_goal [E, 2] (the action already wall-constrained), robot_radius [E] or scalar; human_pos,
     human_action [E, N, 2], human_radius [E, N]; global_time [E] or scalar (BEFORE the step); stat_collision [E] (did the walls
@@ -364,6 +410,10 @@ def step_outcomes(robot_pos, robot_action, robot_goal, robot_radius, human_pos, 
     the scan stops at the first colliding human, so ``dmin`` is the smallest distance among the humans BEFORE it), ``dmin``,
     ``frozen`` (the step is shorter than 1 cm), ``reached_goal``, ``timeout``, ``done``, ``reward``, the value of every info term
     (``info[<key>]``, 0 where it did not fire) and the carried state (``next_prev_*``)."""
+    if robot_rot is not None:
+        th, rv, rw = (np.asarray(a, np.float64) for a in robot_rot)
+        head = th + rw
+        robot_action = np.stack([np.cos(head) * rv, np.sin(head) * rv], axis=1)
     rp, ra, rg = (np.asarray(a, np.float64) for a in (robot_pos, robot_action, robot_goal))
     hp, ha, hr = (np.asarray(a, np.float64) for a in (human_pos, human_action, human_radius))
     E = rp.shape[0]
@@ -378,7 +428,7 @@ def step_outcomes(robot_pos, robot_action, robot_goal, robot_radius, human_pos, 
     first = np.where(collision, hit.argmax(axis=1), hit.shape[1])
     before = np.arange(hit.shape[1])[None, :] < first[:, None]
     dmin = np.where(before, dist, np.inf).min(axis=1, initial=np.inf)
-    frozen = np.sqrt(ra[:, 0] ** 2 + ra[:, 1] ** 2) * time_step < 0.01
+    frozen = (np.sqrt(ra[:, 0] ** 2 + ra[:, 1] ** 2) * time_step < 0.01) if robot_rot is None else (np.abs(rv * time_step) < 0.01)
     reached = _norm(end - rg) < rr
     curr_dist = _norm(rg - end)
     info = {k: np.zeros(E) for k in INFO_KEYS}
@@ -417,15 +467,15 @@ def step_outcomes(robot_pos, robot_action, robot_goal, robot_radius, human_pos, 
         reward += info["Frozen"]
     next_ang = nan.copy() if prev_angular is None else np.asarray(prev_angular, np.float64).copy()
     if has("angular_smoothness_factor"):
-        cur = np.arctan2(ra[:, 1], ra[:, 0])
+        cur = np.arctan2(ra[:, 1], ra[:, 0]) if robot_rot is None else rw
         firststep = np.isnan(next_ang)
-        info["AngularSmoothness"] = np.where(firststep, 0.0, np.abs(np.abs(cur - np.where(firststep, cur, next_ang)))
-                                             * rewards["angular_smoothness_factor"])
+        diff = np.abs(cur - np.where(firststep, cur, next_ang)) if robot_rot is None else cur * time_step      # (a point turn: the angle itself)
+        info["AngularSmoothness"] = np.where(firststep, 0.0, np.abs(diff) * rewards["angular_smoothness_factor"])
         reward += info["AngularSmoothness"]
         next_ang = cur
     next_lin = nan.copy() if prev_linear is None else np.asarray(prev_linear, np.float64).copy()
     if has("linear_smoothness_factor"):
-        cur = np.sqrt(ra[:, 0] ** 2 + ra[:, 1] ** 2)
+        cur = np.sqrt(ra[:, 0] ** 2 + ra[:, 1] ** 2) if robot_rot is None else rv
         firststep = np.isnan(next_lin)
         info["LinearSmoothness"] = np.where(firststep, 0.0, np.abs(np.where(firststep, cur, next_lin) - cur)
                                             * rewards["linear_smoothness_factor"])
@@ -725,7 +775,10 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
     own arithmetic - whole episodes reproduce the reference's lines, ``tests/golden/env_rollout_sfm_*.npz``) is cut short at the
     walls (``constrain_agent_action_exact``), then all agents move.  The reference's robot is driven by the MPC (out of scope);
     here ``robot`` = "orca" (an ORCA agent like the orca_plus humans, v_pref 1), "goal" (straight at its goal at v_pref), "still",
-    or an array [E, steps, 2] of commanded velocities (wall-constrained like everybody's).  ``starts``: a start record in the
+    an array [E, steps, 2] of commanded velocities (wall-constrained like everybody's), or - the MPC's own kinematics
+    (``sicnav_acados.py:143``) - a dict ``{"v": [E, steps], "r": [E, steps]}`` of ``ActionRot`` commands for a unicycle that starts
+    heading pi / 2 (``crowd_sim_plus.py:661``): heading and position by ``agent_plus.py:175-214``, the wall constraint and the
+    outcome block in their ``ActionRot`` branches; ``robot_theta`` [E, steps + 1] is returned with it.  ``starts``: a start record in the
     place of ``hallway_starts`` (pos, goal [E, N + 1, 2], radius, v_pref [E, N + 1]).  Returns what ``simulate_circle_crossing``
     returns (positions from the moment the robot's clock starts, frame 0 = global time 0) plus per step the outcome block
     (``step_outcomes`` with the shipped rewards): ``collision``, ``dmin``, ``reached_goal``, ``timeout``, ``done``, ``reward`` [E, steps]
@@ -739,9 +792,11 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
     pos, final_goal, radius, v_pref = np.array(st["pos"], np.float64), st["goal"], st["radius"], st["v_pref"]
     if cfg.human_policy not in ("orca_plus", "sfm"):
         raise ValueError("human_policy must be 'orca_plus' or 'sfm'")
-    robot_mode = robot if isinstance(robot, str) else "given"
-    if robot_mode not in ("orca", "goal", "still", "given"):
-        raise ValueError("robot must be 'orca', 'goal', 'still' or an array of commanded velocities")
+    robot_mode = robot if isinstance(robot, str) else "unicycle" if isinstance(robot, dict) else "given"
+    if robot_mode not in ("orca", "goal", "still", "given", "unicycle"):
+        raise ValueError("robot must be 'orca', 'goal', 'still', an array of commanded velocities or a dict of ActionRot commands")
+    theta = np.full(E, np.pi / 2)
+    thetas = np.zeros((E, steps + 1))
     vel = np.zeros_like(pos)
     dt = cfg.time_step
     rewards = shipped_rewards()
@@ -775,25 +830,39 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
             new_vel[:, 0] = 0.0                                       # the dummy start: ActionXY(0, 0) for the robot
         elif robot_mode == "given":
             new_vel[:, 0] = np.asarray(robot, np.float64)[:, s - cfg.starts_moving]
+        elif robot_mode == "unicycle":
+            v_cmd = np.asarray(robot["v"], np.float64)[:, s - cfg.starts_moving]
+            r_cmd = np.asarray(robot["r"], np.float64)[:, s - cfg.starts_moving]
+            v_drv = constrain_unicycle_actions(pos[:, 0], theta, v_cmd, r_cmd, radius[:, 0], dt, segs)
+            head = theta + r_cmd
+            new_vel[:, 0] = np.stack([np.cos(head) * v_drv, np.sin(head) * v_drv], axis=1)
         elif robot_mode == "goal":
             d = final_goal[:, 0] - pos[:, 0]
             new_vel[:, 0] = d / np.maximum(_norm(d), 1e-9)[:, None] * v_pref[:, 0:1]
         wanted = new_vel.copy()
+        uni = live and robot_mode == "unicycle"
         new_vel = constrain_actions(pos.reshape(-1, 2), new_vel.reshape(-1, 2), radius.reshape(-1), dt, segs).reshape(E, N + 1, 2)
+        if uni:
+            new_vel[:, 0] = wanted[:, 0]                               # (cut short above, in its own ActionRot branch)
+        wall_hit = (v_cmd != v_drv) if uni else (wanted[:, 0] != new_vel[:, 0])[:, 0]      # crowd_sim_plus.py:1059-1063
         if live:
             k = s - cfg.starts_moving
             if k == 0:
-                traj[:, 0], vels[:, 0] = pos, vel
+                traj[:, 0], vels[:, 0], thetas[:, 0] = pos, vel, theta
                 prev_dist = _norm(final_goal[:, 0] - pos[:, 0])
             o = step_outcomes(pos[:, 0], new_vel[:, 0], final_goal[:, 0], radius[:, 0], pos[:, 1:], new_vel[:, 1:], radius[:, 1:],
-                              k * dt, cfg.time_limit, dt, rewards, stat_collision=(wanted[:, 0] != new_vel[:, 0])[:, 0],
-                              prev_dist_to_goal=prev_dist)
+                              k * dt, cfg.time_limit, dt, rewards, stat_collision=wall_hit,
+                              prev_dist_to_goal=prev_dist, robot_rot=(theta, v_drv, r_cmd) if uni else None)
             for key in ("collision", "dmin", "reached_goal", "timeout", "done", "reward"):
                 out[key][:, k] = o[key]
-            out["wall_collision"][:, k] = (wanted[:, 0] != new_vel[:, 0])[:, 0]
+            out["wall_collision"][:, k] = wall_hit
             end_step = np.where((end_step < 0) & o["done"], k, end_step)
         vel = new_vel
         pos = pos + vel * dt
+        if uni:                                                    # Agent.step of a unicycle (agent_plus.py:211-214)
+            unwrapped = (theta + r_cmd) % (2 * np.pi)
+            theta = np.where(unwrapped > np.pi, unwrapped - 2 * np.pi, unwrapped)
+            vel[:, 0] = np.stack([v_drv * np.cos(theta), v_drv * np.sin(theta)], axis=1)
         goal = final_goal.copy()                                   # Human.step: set_g_xy at the new position (human_plus.py:19-79)
         goal[:, 1:] = door_subgoal(pos[:, 1:], final_goal[:, 1:], cfg.rule, doors, len(segs))
         global_time += dt
@@ -801,6 +870,9 @@ def simulate_hallway(E: int, N: int, steps: int, seed: int, cfg: Optional[Hallwa
         human_times = np.where((human_times == 0) & arrived, global_time, human_times)
         if live:
             traj[:, s - cfg.starts_moving + 1], vels[:, s - cfg.starts_moving + 1] = pos, vel
+            thetas[:, s - cfg.starts_moving + 1] = theta
     out["human_times"] = human_times
+    if robot_mode == "unicycle":
+        out["robot_theta"] = thetas
     return dict(human_xy=traj[:, :, 1:], robot_xy=traj[:, :, 0], human_vel=vels[:, :, 1:], stamps=np.arange(steps + 1) * dt,
                 goal=final_goal, radius=radius, v_pref=v_pref, segments=segs, end_step=end_step, **out)

@@ -204,14 +204,61 @@ def capture_constrained_actions(ns, tag, rule, n, seed, radius=0.21, time_step=0
     print("constrained actions", tag, rule, n, "changed:", changed)
 
 
+def capture_constrained_rot_actions(ns, tag, rule, n, seed, radius=0.25, time_step=0.25, **geo):
+    """The same for a NON-holonomic agent (the MPC's unicycle robot: ActionRot(v, r), position by utils/agent_plus.py:175-185 executed from
+    its lines): the constrained action keeps the rotation and shortens |v| (crowd_sim_plus.py:976-987), forwards and backwards."""
+    env = make_env(ns, rule, **geo)
+    segs = np.array(env.static_obstacles, dtype=np.float64).reshape(-1, 2, 2)
+    rng = np.random.default_rng(seed)
+    R = ns["ActionRot"]
+    cls_ns = dict(np=np)
+    exec("class Uni:\n    kinematics = 'unicycle'\n    def check_validity(self, action):\n        pass\n"
+         + textwrap.indent(ref_lines("utils/agent_plus.py", 175, 185), "    "), cls_ns)
+    pos, theta, act, got = [], [], [], []
+    while len(pos) < n:
+        s = segs[rng.integers(0, len(segs))]
+        d = s[1] - s[0]
+        nrm = np.array([-d[1], d[0]]) / np.linalg.norm(d)
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            p = np.array([rng.uniform(-env.rect_width, env.rect_width), rng.uniform(-env.rect_height, env.rect_height)])
+        elif kind == 1:
+            p = s[0] + rng.uniform(0.1, 0.9) * d + nrm * rng.choice([-1, 1]) * rng.uniform(radius + 1e-6, radius + 0.3)
+        elif kind == 2:
+            e = s[rng.integers(0, 2)]
+            ang = rng.uniform(0, 2 * np.pi)
+            p = e + rng.uniform(radius + 1e-6, radius + 0.35) * np.array([np.cos(ang), np.sin(ang)])
+        else:
+            p = s[0] + rng.uniform(0.1, 0.9) * d + nrm * rng.choice([-1, 1]) * (radius + 1e-7)
+        if min(ns["point_to_segment_dist"](q[0][0], q[0][1], q[1][0], q[1][1], p[0], p[1]) for q in segs) < radius:
+            continue
+        th, v, r = rng.uniform(-np.pi, np.pi), rng.uniform(-1.0, 1.5), rng.uniform(-0.6, 0.6)
+        if rng.random() < 0.05:
+            v = 0.0
+        agent = cls_ns["Uni"]()
+        agent.px, agent.py, agent.theta, agent.radius, agent.time_step = float(p[0]), float(p[1]), float(th), radius, time_step
+        try:
+            c = ns["constrain_agent_action_exact"](env, agent, R(float(v), float(r)))
+        except AssertionError:
+            continue
+        pos.append(p); theta.append(th); act.append((v, r)); got.append((c.v, c.r))
+    np.savez(os.path.join(OUT, f"env_rotconstrain_{tag}.npz"), rule=rule, radius=radius, time_step=time_step, segments=segs,
+             pos=np.array(pos), theta=np.array(theta), action=np.array(act), constrained=np.array(got))
+    print("constrained unicycle actions", tag, rule, n, "changed:", int((np.array(got)[:, 0] != np.array(act)[:, 0]).sum()))
+
+
 INFO_KEYS = ("ReachGoal", "Timeout", "Collision", "WallCollision", "Frozen", "Danger", "Progress", "AngularSmoothness", "LinearSmoothness")
 
 
-def capture_step_outcomes(ns, tag, n, seed, rewards, detailed):
+def capture_step_outcomes(ns, tag, n, seed, rewards, detailed, unicycle=False):
     """The outcome block of step() for n random situations of one robot and three humans."""
     rng = np.random.default_rng(seed)
     A = ns["ActionXY"]
-    rec = {k: [] for k in ("robot", "robot_action", "humans", "human_actions", "human_radius", "global_time", "stat_collision",
+    uni_ns = dict(np=np)      # the unicycle robot's position update: utils/agent_plus.py:175-185 from its lines
+    exec("class Uni:\n    kinematics = 'unicycle'\n    def check_validity(self, action):\n        pass\n"
+         "    def get_goal_position(self):\n        return self.gx, self.gy\n"
+         + textwrap.indent(ref_lines("utils/agent_plus.py", 175, 185), "    "), uni_ns)
+    rec = {k: [] for k in ("robot_theta", "robot_rot", "robot", "robot_action", "humans", "human_actions", "human_radius", "global_time", "stat_collision",
                            "prev_dist", "prev_angular", "prev_linear", "reward", "done", "dmin", "collision", "frozen", "reached",
                            "curr_dist", "info_vals", "info_present", "next_prev_dist", "next_prev_angular", "next_prev_linear")}
     time_limit, time_step = 30.0, 0.25
@@ -234,6 +281,14 @@ def capture_step_outcomes(ns, tag, n, seed, rewards, detailed):
             hp[2] = p + v * time_step - hv[2] * time_step + (0.25 + hr[2] + rng.uniform(0.0, 0.25)) * np.array([np.cos(ang), np.sin(ang)])
         gt = float(rng.choice([rng.uniform(0, 29.0), 30.0, 30.25])) if kind == 5 else float(rng.uniform(0, 29.0))
         robot = Agent(float(p[0]), float(p[1]), float(goal[0]), float(goal[1]), 0.25, time_step)
+        th = vr = vs = 0.0
+        if unicycle:      # the same world-frame step, expressed as ActionRot(v, r) on heading th: th + r = the direction of v (or its opposite)
+            vr = float(rng.uniform(-0.6, 0.6))
+            vs = float(rng.choice([-1.0, 1.0]) * np.linalg.norm(v))
+            th = float(np.arctan2(v[1], v[0]) - vr + (np.pi if vs < 0 else 0.0))
+            robot = uni_ns["Uni"]()
+            robot.px, robot.py, robot.gx, robot.gy, robot.radius, robot.time_step, robot.theta = (
+                float(p[0]), float(p[1]), float(goal[0]), float(goal[1]), 0.25, time_step, th)
         humans = [Agent(float(hp[j, 0]), float(hp[j, 1]), 0.0, 0.0, float(hr[j]), time_step) for j in range(3)]
         first = rng.random() < 0.2
         env = types.SimpleNamespace(robot=robot, humans=humans, time_step=time_step, global_time=gt, time_limit=time_limit,
@@ -244,7 +299,9 @@ def capture_step_outcomes(ns, tag, n, seed, rewards, detailed):
         stat = bool(rng.random() < 0.15)
         pd, pa, pl = env.robot_prev_dist_to_goal, env.prev_action_angular, env.prev_action_linear
         r, done, info, dmin, coll, frozen, reached, cd = ns["step_outcome"](
-            env, A(float(v[0]), float(v[1])), [A(float(hv[j, 0]), float(hv[j, 1])) for j in range(3)], stat, True)
+            env, ns["ActionRot"](vs, vr) if unicycle else A(float(v[0]), float(v[1])),
+            [A(float(hv[j, 0]), float(hv[j, 1])) for j in range(3)], stat, True)
+        rec["robot_theta"].append(th); rec["robot_rot"].append([vs, vr])
         rec["robot"].append([p[0], p[1], goal[0], goal[1], 0.25]); rec["robot_action"].append(v)
         rec["humans"].append(hp); rec["human_actions"].append(hv); rec["human_radius"].append(hr)
         rec["global_time"].append(gt); rec["stat_collision"].append(stat)
@@ -258,7 +315,7 @@ def capture_step_outcomes(ns, tag, n, seed, rewards, detailed):
         rec["next_prev_angular"].append(np.nan if env.prev_action_angular is None else env.prev_action_angular)
         rec["next_prev_linear"].append(np.nan if env.prev_action_linear is None else env.prev_action_linear)
     np.savez(os.path.join(OUT, f"env_step_outcomes_{tag}.npz"), time_limit=time_limit, time_step=time_step, detailed=detailed,
-             reward_keys=np.array(sorted(rewards)), reward_vals=np.array([float(rewards[k]) for k in sorted(rewards)]),
+             unicycle=unicycle, reward_keys=np.array(sorted(rewards)), reward_vals=np.array([float(rewards[k]) for k in sorted(rewards)]),
              info_keys=np.array(INFO_KEYS), **{k: np.array(v) for k, v in rec.items()})
     print("step outcomes", tag, n, "done:", int(np.sum(rec["done"])), "collisions:", int(np.sum(rec["collision"])),
           "reached:", int(np.sum(rec["reached"])), "frozen:", int(np.sum(rec["frozen"])))
@@ -367,7 +424,7 @@ def capture_sfm_calls(ns, tag, rule, n, seed, n_others=3, time_step=0.25):
     print("sfm calls", tag, rule, n)
 
 
-def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, time_step=0.25):
+def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, time_step=0.25, unicycle=False):
     """A whole episode with social-force humans, step by step with the reference's own lines: placement (generate_hallway_human),
     per step every human's observation (the other humans, then the robot: crowd_sim_plus.py:1044-1052), SFM.predict, the wall
     constraint, the outcome block, the position update and the door sub-goal (Agent.step / Human.step).  The robot stands for the
@@ -385,6 +442,15 @@ def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, 
         h.time_step, h.vx, h.vy, h.kinematics = time_step, 0.0, 0.0, "holonomic"
         h.compute_position = (lambda self: (lambda action, dt: (self.px + action.vx * dt, self.py + action.vy * dt)))(h)
     robot = env.robot
+    if unicycle:      # the MPC's robot (sicnav_acados.py:143): ActionRot commands, position and heading by utils/agent_plus.py:175-214 from its lines
+        uni_ns = dict(np=np)
+        exec("class Uni:\n    kinematics = 'unicycle'\n    def check_validity(self, action):\n        pass\n"
+             + textwrap.indent(ref_lines("utils/agent_plus.py", 175, 185), "    ") + "\n"
+             + textwrap.indent(ref_lines("utils/agent_plus.py", 199, 214), "    "), uni_ns)
+        old, robot = robot, uni_ns["Uni"]()
+        robot.px, robot.py, robot.gx, robot.gy, robot.radius, robot.time_step, robot.theta = old.px, old.py, old.gx, old.gy, old.radius, time_step, np.pi / 2
+        robot.get_goal_position = lambda: (robot.gx, robot.gy)
+        env.robot = robot
     robot.vx = robot.vy = 0.0
     robot.v_pref = 1.0
     env.robot_goal_pos = np.array([robot.gx, robot.gy])
@@ -408,25 +474,41 @@ def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, 
         h.get_position = (lambda self: (lambda: (self.px, self.py)))(h)
         h.get_goal_position = (lambda self: (lambda: (self.gx, self.gy)))(h)
         h.reached_destination = (lambda self: (lambda: tns["reached_destination"](self)))(h)
-    traj, racts, outs = [], [], []
+    traj, racts, outs, thetas = [], [], [], []
     for s in range(starts_moving + steps):
         human_actions = []
         for h in env.humans:                                                            # crowd_sim_plus.py:1044-1056
             ob = [obs(o) for o in env.humans if o is not h] + [obs(robot)]
             state = types.SimpleNamespace(self_state=full(h), human_states=ob, static_obs=env.static_obstacles)
             human_actions.append(ns["constrain_agent_action_exact"](env, h, predict(pol, state)))
-        if s < starts_moving:
-            want = A(0.0, 0.0)
+        if unicycle:
+            if s < starts_moving:
+                want = ns["ActionRot"](0.0, 0.0)                                            # crowd_sim_plus.py:718
+            else:      # scripted: turn towards a point that swings across the corridor (so that walls are met), at most 0.5 rad per step
+                k = s - starts_moving
+                tx, ty = robot.gx + 1.2 * np.sin(0.45 * k), robot.gy
+                err = (np.arctan2(ty - robot.py, tx - robot.px) - robot.theta + np.pi) % (2 * np.pi) - np.pi
+                want = ns["ActionRot"](robot.v_pref if k % 11 != 7 else -0.4, float(np.clip(err, -0.5, 0.5)))
+            act = ns["constrain_agent_action_exact"](env, robot, want)
+            stat = act.v != want.v
         else:
-            d = np.array([robot.gx - robot.px, robot.gy - robot.py])
-            want = A(*(d / max(np.linalg.norm(d), 1e-9) * robot.v_pref))
-        act = ns["constrain_agent_action_exact"](env, robot, want)
-        stat = act.vx != want.vx
+            if s < starts_moving:
+                want = A(0.0, 0.0)
+            else:
+                d = np.array([robot.gx - robot.px, robot.gy - robot.py])
+                want = A(*(d / max(np.linalg.norm(d), 1e-9) * robot.v_pref))
+            act = ns["constrain_agent_action_exact"](env, robot, want)
+            stat = act.vx != want.vx
         r, done, info, dmin, coll, frozen, reached, cd = ns["step_outcome"](env, act, human_actions, stat, True)
         outs.append([r, float(done), dmin, float(coll), float(reached)])
-        racts.append([want.vx, want.vy])
-        robot.px, robot.py = robot.compute_position(act, time_step)                     # Agent.step
-        robot.vx, robot.vy = act.vx, act.vy
+        if unicycle:
+            racts.append([want.v, want.r])
+            robot.step(act)                                                             # Agent.step, from the reference's lines
+            thetas.append(robot.theta)
+        else:
+            racts.append([want.vx, want.vy])
+            robot.px, robot.py = robot.compute_position(act, time_step)                 # Agent.step
+            robot.vx, robot.vy = act.vx, act.vy
         for h, a in zip(env.humans, human_actions):                                     # Human.step
             h.px, h.py = h.px + a.vx * time_step, h.py + a.vy * time_step
             h.vx, h.vy = a.vx, a.vy
@@ -436,7 +518,7 @@ def capture_sfm_rollout(ns, tag, rule, n_humans, seed, steps, starts_moving=10, 
         traj.append([[robot.px, robot.py]] + [[h.px, h.py] for h in env.humans])
     np.savez(os.path.join(OUT, f"env_rollout_sfm_{tag}.npz"), rule=rule, n_humans=n_humans, seed=seed, steps=steps, starts_moving=starts_moving,
              time_step=time_step, traj=np.array(traj), robot_wanted=np.array(racts), outcomes=np.array(outs),
-             human_times=np.array(env.human_times, dtype=np.float64), **start)
+             human_times=np.array(env.human_times, dtype=np.float64), unicycle=unicycle, robot_theta=np.array(thetas), **start)
     print("sfm rollout", tag, rule, n_humans, "steps", steps, "robot end", traj[-1][0])
 
 
@@ -448,6 +530,8 @@ if __name__ == "__main__":
     capture_sfm_rollout(ns, "static_n4", "hallway_static", 4, 82, 40)
     capture_sfm_rollout(ns, "bottleneck_n3", "hallway_bottleneck", 3, 83, 30)
     capture_sfm_rollout(ns, "hallway_n4_long", "hallway", 4, 84, 70)      # long enough for humans to arrive: human_times
+    capture_sfm_rollout(ns, "unicycle_hallway_n3", "hallway", 3, 85, 40, unicycle=True)
+    capture_sfm_rollout(ns, "unicycle_static_n3", "hallway_static", 3, 86, 40, unicycle=True)
     capture_orca_plus_calls(ns, "hallway_n3", "hallway", 3, 61)
     capture_orca_plus_calls(ns, "static_n5", "hallway_static", 5, 62)
     capture_orca_plus_calls(ns, "near_goal", "hallway_bottleneck", 2, 63, near_goal=True)
@@ -461,9 +545,13 @@ if __name__ == "__main__":
     capture_constrained_actions(ns, "static", "hallway_static", 500, 42)
     capture_constrained_actions(ns, "squeeze", "hallway_squeeze", 300, 43)
     capture_constrained_actions(ns, "rectangle", "rectangle", 200, 44, circle_radius=4.0, rect_width=6.0, rect_height=8.0)
+    capture_constrained_rot_actions(ns, "hallway", "hallway", 300, 45)
+    capture_constrained_rot_actions(ns, "static", "hallway_static", 400, 46)
     # the shipped [reward] section (env.config:66-71) as configure() leaves it for non-RL testing (crowd_sim_plus.py:110-128)
     shipped = {"success_reward": 1.0, "collision_penalty": -0.25, "freezing_penalty": -0.125, "discomfort_dist": 0.2,
                "discomfort_penalty_factor": 0.5, "discomfort": True, "timeout": -1.0, "wall_collision_penalty": -1.0}
     capture_step_outcomes(ns, "shipped", 400, 51, shipped, False)
     full = dict(shipped, progress_factor=0.1, angular_smoothness_factor=-0.01, linear_smoothness_factor=-0.02)
     capture_step_outcomes(ns, "all_terms", 400, 52, full, True)
+    capture_step_outcomes(ns, "unicycle_all_terms", 400, 53, full, True, unicycle=True)
+    capture_step_outcomes(ns, "unicycle_shipped", 300, 54, shipped, False, unicycle=True)
