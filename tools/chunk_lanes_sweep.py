@@ -12,7 +12,7 @@ g = torch.Generator().manual_seed(3)
 ctx = torch.randn([E, A, 256], generator=g).cuda()
 x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
 ref = None
-for chunk in (0, 17, 21, 26, 32, 34, 43, 51):
+for chunk in ([int(c) for c in os.environ["CHUNKS"].split(",")] if os.environ.get("CHUNKS") else (0, 17, 21, 26, 32, 34, 43, 51)):
     row = []
     for lanes in (1, 2, 3):
         eng.set_tuning("lanes", lanes)
