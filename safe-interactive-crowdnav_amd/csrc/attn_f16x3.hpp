@@ -934,6 +934,12 @@ inline void launch_attn_pp(AttnHArgs a, int nseq, hipStream_t st);
 // products behind one wait and one barrier (attn_k64.hpp, included at the end of this file; bit-identical, measured 0-4 % slower)
 inline bool attn_k64_applies(const AttnHArgs& a);
 inline void launch_attn_k64(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
+// experiment (knob "attn_sp" = 1): the same launches with P.V of tile t - 1 pipelined into the logits of tile t (attn_sp.hpp; bit-identical)
+inline bool attn_sp_applies(const AttnHArgs& a);
+inline void launch_attn_sp(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
+// ("attn_sp" = 2): ... and the softmax of tile t in the gaps of those matrix instructions (attn_sp2.hpp)
+inline bool attn_sp2_applies(const AttnHArgs& a);
+inline void launch_attn_sp2(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
 #endif
 
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
@@ -958,7 +964,11 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
         } else
 #endif
 #ifdef JMID_EXPERIMENTS
-        if (attn_k64_applies(a)) {
+        if (attn_sp2_applies(a)) {
+            launch_attn_sp2(a, nseq, nqt, st);
+        } else if (attn_sp_applies(a)) {
+            launch_attn_sp(a, nseq, nqt, st);
+        } else if (attn_k64_applies(a)) {
             launch_attn_k64(a, nseq, nqt, st);
         } else
 #endif
@@ -995,6 +1005,8 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 
 #ifdef JMID_EXPERIMENTS
 #include "attn_k64.hpp"
+#include "attn_sp.hpp"
+#include "attn_sp2.hpp"
 #include "attn_pp.hpp"
 #include "attn_q64.hpp"
 #endif

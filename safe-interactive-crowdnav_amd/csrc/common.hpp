@@ -141,6 +141,7 @@ struct Tuning {
     int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
     int attn_q64 = 0;        // experiment (diagnostics): 1 = F16MX attention launches without a key split on the one-wave-per-SIMD kernel (attn_q64.hpp: bit-identical, measured slower)
     int attn_k64 = 0;        // head_dim-128 attention of F16MX / F16X2 without a key split on 64-key tiles (attn_k64.hpp, experiments flavour; bit-identical to the 32-key kernel, measured 0-4 % slower): 0 = automatic (= never), 1 = always, 2 = never
+    int attn_sp = 0;         // (experiments flavour) 1 = F16MX / F16X2 attention without a key split with P.V(t - 1) pipelined into the logits of tile t (attn_sp.hpp; bit-identical)
     int attn_one_wg = 0;     // (probe) 1 = the head_dim-128 LDS-DMA attention kernels request the CU's whole 160 KB of LDS: ONE workgroup per CU, one wave per SIMD
     int attn_pp = 0;         // head_dim-128 attention as the 8-wave ping-pong kernel (attn_pp.hpp; bit-identical): 0 = automatic, 1 = always, 2 = never
     int h1_stage = 0;        // F16MX linear1 in the 256 x 256 / 128 x 256 shapes: 0 / 1 = tile out through LDS in whole lines (h1_staged_store), 2 = the element-wise epilogue

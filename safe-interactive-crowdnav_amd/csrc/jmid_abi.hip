@@ -444,6 +444,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 #ifdef JMID_EXPERIMENTS
         {"attn_pp", &Tuning::attn_pp, 0, 2},
         {"attn_k64", &Tuning::attn_k64, 0, 2},
+        {"attn_sp", &Tuning::attn_sp, 0, 2},
 #endif
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},

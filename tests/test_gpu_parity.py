@@ -569,12 +569,15 @@ def test_attention_pingpong_equals_the_two_wave_kernel(E, A, K, T, precision):
 
 @needs_experiments
 @pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
+@pytest.mark.parametrize("knob,value", [("attn_k64", 1), ("attn_sp", 1), ("attn_sp", 2)])
 @pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (3, 3, 7, 5), (2, 25, 16, 12), (9, 5, 20, 11)])
-def test_attention_on_64_key_tiles_equals_the_32_key_kernel(E, A, K, T, precision):
-    """attn_k64_kernel (experiment, knob "attn_k64" = 1: two softmax rounds per 64-key tile, their P.V products behind one wait and one barrier,
-    K double- and V^T single-buffered in 80 KB; csrc/attn_k64.hpp) runs the 32-key kernel's rounds instruction for instruction: bit-identical
-    outputs in both modes it serves, on S = 1200, 105, 4800 (dense) and 1100 (an odd number of 32-key sub-tiles: the last tile's second half
-    lies past the sequence) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
+def test_restructured_attention_kernels_equal_the_32_key_kernel(E, A, K, T, knob, value, precision):
+    """Three experiments on the head-dim-128 attention of F16MX / F16X2 (csrc/attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp), each running the
+    shipped kernel's instructions per accumulator in its order: "attn_k64" = 1 - two softmax rounds per 64-key tile, their P.V products
+    behind one wait and one barrier; "attn_sp" = 1 - P.V of tile t - 1 between the logits' matrix instructions of tile t (three-stage
+    ring); "attn_sp" = 2 - the full in-wave pipeline: logits(t + 1) + P.V(t - 1) with the softmax of tile t cut into 17 atoms in their
+    gaps, two score accumulators, loop unrolled six times.  Bit-identical outputs on S = 1200, 105, 4800 (dense) and 1100 (an odd
+    number of 32-key tiles) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
     eng, w = get_engine(256, 23, True, "exp")
     eng.set_step(4)
     g = torch.Generator().manual_seed(41 + E)
@@ -582,15 +585,15 @@ def test_attention_on_64_key_tiles_equals_the_32_key_kernel(E, A, K, T, precisio
     x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
     out = {}
     try:
-        for v in (2, 1):
-            eng.set_tuning("attn_k64", v)
+        for v in (0, value):
+            eng.set_tuning(knob, v)
             out[v] = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
     finally:
-        eng.set_tuning("attn_k64", 0)
-    np.testing.assert_array_equal(out[1], out[2])
+        eng.set_tuning(knob, 0)
+    np.testing.assert_array_equal(out[value], out[0])
     with torch.no_grad():
         ref = O.denoise(w.tensors, ctx[:1].cpu(), x_T[:1].cpu(), sample=K, step=4, joint=True)
-    assert ade(out[1][:1], ref.numpy()) <= ADE_GATE
+    assert ade(out[value][:1], ref.numpy()) <= ADE_GATE
 
 
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),

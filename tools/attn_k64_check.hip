@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
     Tuning tn[2];
     tn[0].attn_k64 = 2;      // the 32-key kernel
     tn[1].attn_k64 = 1;      // the 64-key kernel
+    if (getenv("SP")) { tn[1].attn_k64 = 2; tn[1].attn_sp = atoi(getenv("SP")); }      // SP=1: the software-pipelined kernel (attn_sp.hpp) in its place
     if (getenv("ONE_WG")) tn[0].attn_one_wg = tn[1].attn_one_wg = 1;      // one workgroup per CU: a wave alone on its SIMD
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -76,7 +77,7 @@ int main(int argc, char** argv) {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double fl = 4.0 * nseq * (double)S * S * d;
-        printf("%s: %.4f ms per launch  (%.0f TFLOP/s algorithmic)\n", v ? "64-key tiles" : "32-key tiles", ms / reps,
+        printf("%s: %.4f ms per launch  (%.0f TFLOP/s algorithmic)\n", v ? (getenv("SP") ? "pipelined   " : "64-key tiles") : "32-key tiles", ms / reps,
                fl / (ms / reps * 1e-3) * 1e-12);
     }
 #ifdef ATT_K64_TRACE
