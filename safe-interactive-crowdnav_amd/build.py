@@ -11,7 +11,7 @@ LIB = os.path.join(CSRC, "libjmid_hip.so")
 # (-DJMID_DIAGNOSTICS).  tests/ and tools/ load it (tests/conftest.py sets JMID_LIB); the product never does.
 LIB_DIAG = os.path.join(CSRC, "libjmid_hip_diag.so")
 # the experiments flavour: the diagnostics flavour + the kernels that were built, measured slower and kept for the record
-# (-DJMID_EXPERIMENTS: attn_q64.hpp, attn_pp.hpp, attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp, tail_f16x3.hpp, the small-launch GEMM + LayerNorm / output tails; docs/NOTEBOOK.md).
+# (-DJMID_EXPERIMENTS: attn_q64.hpp, attn_pp.hpp, attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp, attn_pp2.hpp, tail_f16x3.hpp, the small-launch GEMM + LayerNorm / output tails; docs/NOTEBOOK.md).
 # Not built by build(): `python safe-interactive-crowdnav_amd/build.py experiments`; its tests skip when it is absent.
 LIB_EXP = os.path.join(CSRC, "libjmid_hip_exp.so")
 # translation units of the host side (csrc/jmid_ctx.hpp says what each holds); every unit instantiates the kernels it launches

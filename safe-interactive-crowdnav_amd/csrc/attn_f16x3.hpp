@@ -940,6 +940,9 @@ inline void launch_attn_sp(const AttnHArgs& a, int nseq, int nqt, hipStream_t st
 // ("attn_sp" = 2): ... and the softmax of tile t in the gaps of those matrix instructions (attn_sp2.hpp)
 inline bool attn_sp2_applies(const AttnHArgs& a);
 inline void launch_attn_sp2(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
+// ("attn_pp" = 3): the ping-pong rebuilt on attn_sp.hpp's matrix phase, copies three segments ahead by group 0 only (attn_pp2.hpp)
+inline bool attn_pp2_applies(const AttnHArgs& a);
+inline void launch_attn_pp2(AttnHArgs a, int nseq, hipStream_t st);
 #endif
 
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
@@ -964,7 +967,9 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
         } else
 #endif
 #ifdef JMID_EXPERIMENTS
-        if (attn_sp2_applies(a)) {
+        if (attn_pp2_applies(a)) {
+            launch_attn_pp2(a, nseq, st);
+        } else if (attn_sp2_applies(a)) {
             launch_attn_sp2(a, nseq, nqt, st);
         } else if (attn_sp_applies(a)) {
             launch_attn_sp(a, nseq, nqt, st);
@@ -1007,6 +1012,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 #include "attn_k64.hpp"
 #include "attn_sp.hpp"
 #include "attn_sp2.hpp"
+#include "attn_pp2.hpp"
 #include "attn_pp.hpp"
 #include "attn_q64.hpp"
 #endif

@@ -442,7 +442,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_q64", &Tuning::attn_q64, 0, 1},
 #endif
 #ifdef JMID_EXPERIMENTS
-        {"attn_pp", &Tuning::attn_pp, 0, 2},
+        {"attn_pp", &Tuning::attn_pp, 0, 3},
         {"attn_k64", &Tuning::attn_k64, 0, 2},
         {"attn_sp", &Tuning::attn_sp, 0, 2},
 #endif

@@ -569,14 +569,15 @@ def test_attention_pingpong_equals_the_two_wave_kernel(E, A, K, T, precision):
 
 @needs_experiments
 @pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
-@pytest.mark.parametrize("knob,value", [("attn_k64", 1), ("attn_sp", 1), ("attn_sp", 2)])
+@pytest.mark.parametrize("knob,value", [("attn_k64", 1), ("attn_sp", 1), ("attn_sp", 2), ("attn_pp", 3)])
 @pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (3, 3, 7, 5), (2, 25, 16, 12), (9, 5, 20, 11)])
 def test_restructured_attention_kernels_equal_the_32_key_kernel(E, A, K, T, knob, value, precision):
-    """Three experiments on the head-dim-128 attention of F16MX / F16X2 (csrc/attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp), each running the
+    """Four experiments on the head-dim-128 attention of F16MX / F16X2 (csrc/attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp, attn_pp2.hpp), each running the
     shipped kernel's instructions per accumulator in its order: "attn_k64" = 1 - two softmax rounds per 64-key tile, their P.V products
     behind one wait and one barrier; "attn_sp" = 1 - P.V of tile t - 1 between the logits' matrix instructions of tile t (three-stage
     ring); "attn_sp" = 2 - the full in-wave pipeline: logits(t + 1) + P.V(t - 1) with the softmax of tile t cut into 17 atoms in their
-    gaps, two score accumulators, loop unrolled six times.  Bit-identical outputs on S = 1200, 105, 4800 (dense) and 1100 (an odd
+    gaps, two score accumulators, loop unrolled six times; "attn_pp" = 3 - the 8-wave ping-pong rebuilt on attn_sp's matrix phase, copies
+    three segments ahead by one of the two wave groups, four-stage rings.  Bit-identical outputs on S = 1200, 105, 4800 (dense) and 1100 (an odd
     number of 32-key tiles) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
     eng, w = get_engine(256, 23, True, "exp")
     eng.set_step(4)

@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops -w \
 //         -DJMID_DIAGNOSTICS -DJMID_EXPERIMENTS -I safe-interactive-crowdnav_amd/csrc -I include tools/attn_k64_check.hip -o build/attn_k64_check
 //   build/attn_k64_check [nseq = 51] [S = 1200] [reps = 20] [mode: 0 = F16MX operands, 1 = F16X2] [logit scale = 0.35]
+//   SP=1 / SP=2: the in-wave software pipelines (attn_sp.hpp / attn_sp2.hpp) in the 64-key kernel's place; PP2=1: the rebuilt ping-pong (attn_pp2.hpp)
 //   ONE_WG=1 in the environment: both kernels with ONE workgroup per CU (a wave alone on its SIMD); -DATT_K64_TRACE: cycle stamps (spills: perturbed)
 #include "attn_f16x3.hpp"
 #include <cstdio>
@@ -56,7 +57,8 @@ int main(int argc, char** argv) {
     Tuning tn[2];
     tn[0].attn_k64 = 2;      // the 32-key kernel
     tn[1].attn_k64 = 1;      // the 64-key kernel
-    if (getenv("SP")) { tn[1].attn_k64 = 2; tn[1].attn_sp = atoi(getenv("SP")); }      // SP=1: the software-pipelined kernel (attn_sp.hpp) in its place
+    if (getenv("SP")) { tn[1].attn_k64 = 2; tn[1].attn_sp = atoi(getenv("SP")); }
+    if (getenv("PP2")) { tn[1].attn_k64 = 2; tn[1].attn_pp = 3; }      // PP2=1: the rebuilt ping-pong (attn_pp2.hpp)      // SP=1: the software-pipelined kernel (attn_sp.hpp) in its place
     if (getenv("ONE_WG")) tn[0].attn_one_wg = tn[1].attn_one_wg = 1;      // one workgroup per CU: a wave alone on its SIMD
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -77,7 +79,7 @@ int main(int argc, char** argv) {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double fl = 4.0 * nseq * (double)S * S * d;
-        printf("%s: %.4f ms per launch  (%.0f TFLOP/s algorithmic)\n", v ? (getenv("SP") ? "pipelined   " : "64-key tiles") : "32-key tiles", ms / reps,
+        printf("%s: %.4f ms per launch  (%.0f TFLOP/s algorithmic)\n", v ? (getenv("PP2") ? "ping-pong 2 " : getenv("SP") ? "pipelined   " : "64-key tiles") : "32-key tiles", ms / reps,
                fl / (ms / reps * 1e-3) * 1e-12);
     }
 #ifdef ATT_K64_TRACE
