@@ -249,7 +249,8 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
  * [nseq*S, 3*d_model] -> OUT [nseq*S, d_model] (heads/dims of the handle). */
 int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int precision, float* OUT);
 /* X <- LayerNorm(X + A . Wt^T + bias) * gamma + beta in JMID_PREC_F16MX at d_model 512 (A [M, K], Wt [512, K], X [M, 512]), with the
- * second-generation kernels: fused = 1 the row-complete GEMM + residual + LayerNorm, 0 the GEMM + add_ln2 pair (bit-identical). */
+ * second-generation kernels: fused = 1 the row-complete GEMM + residual + LayerNorm, 0 the GEMM + add_ln2 pair, 3 the small-launch
+ * GEMM whose workgroups exchange the row statistics and normalise their own columns (all bit-identical). */
 int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const float* Wt, const float* bias, const float* gamma,
                         const float* beta, float* X, int fused);
 /* X <- LayerNorm(X + Y) * gamma + beta, eps = 1e-5 (post-norm residual of nn.TransformerEncoderLayer). */

@@ -89,7 +89,9 @@ __device__ __forceinline__ void store_stream(T* p, const T& v) {
 #endif
 }
 
-enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2, OUT_LN = 3 };     // OUT_LN: gemm_small.hpp only (fp32 tile + residual + LayerNorm by the last workgroup of the row tile)
+enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2, OUT_LN = 3, OUT_LNX = 4 };     // gemm_small.hpp only.  OUT_LN: fp32 tile + residual + LayerNorm by the last
+                                                                                  // workgroup of the row tile; OUT_LNX: every workgroup normalises its own 64 columns after
+                                                                                  // exchanging the row statistics with the seven others of its row tile
 
 
 struct GemmHArgs {
@@ -123,6 +125,9 @@ struct GemmHArgs {
     unsigned* ln_cnt;         // [ceil(M / 64)] arrival counters, monotonic over launches (zeroed once per call)
     float ln_eps;
     int ln_no_lo;             // the last LayerNorm of the net: nobody reads its lo plane (F16MX)
+    // OUT_LNX (gemm_small.hpp): the row-statistics exchange of the workgroups of a row tile
+    unsigned long long* ln_xchg;   // [2 kinds][ceil(M / 64)][8 column tiles][64 rows] granules {fp32 partial, launch tag}, zeroed once per call
+    unsigned ln_epoch;             // this launch's tag: never 0, never repeated within a call
 };
 
 constexpr int GEMMH_BK = 32;

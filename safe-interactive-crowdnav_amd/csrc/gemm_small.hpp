@@ -302,6 +302,146 @@ __device__ __forceinline__ void ln_tail_planes(const float* Y, const float* gamm
     }
 }
 
+// ---- OUT_LNX: out_proj / linear2 + residual + LayerNorm in ONE small launch WITHOUT concentrating the row-wise work: the eight
+// workgroups of a 64-row tile (N = 512 = 8 column tiles of 64) each keep their own 64 x 64 block, exchange only the ROW STATISTICS -
+// the block's partial sum P_c, then its partial sum of squared deviations - and normalise and store their own columns.  What goes
+// between workgroups is 64 granules of 8 bytes per block and statistic: {fp32 partial, launch tag} written and polled as ONE relaxed
+// agent-scope 64-bit atomic each (global_store / global_load_dwordx2 sc1: the value and its validity arrive together, no fence, no
+// flag, no counter); a workgroup waits for the seven other blocks of its rows only, which were dispatched next to it.  The partials
+// and the totals are formed in gemm_ln2_mx.hpp's canonical order (partial(c, h) by ONE thread over its 32 columns, P_c = partial(c, 0)
+// + partial(c, 1), total = ((P0 + P1) + ...) + P7), so the rows are bit-identical to the GEMM + add_ln2_kernel pair and to the
+// row-complete kernel of full launches.  The launch must fit the chip with one workgroup per CU (the waiting workgroups need their
+// partners resident: <= 256 tiles, nothing else in flight on the handle); the polls are BOUNDED - a workgroup that does not see a
+// partner within ~10^5 polls sets bit 1 of the range flag and leaves, and the host drops the fused path for the handle.
+constexpr int SM_LNX_POLLS = 1 << 17;
+constexpr size_t SM_LNX_GRANULES = size_t(2) * 32 * 8 * 64;     // per step workspace: two statistics x 32 row tiles x 8 blocks x 64 rows
+
+__device__ __forceinline__ void lnx_publish(unsigned long long* slot, float v, unsigned tag) {
+    __hip_atomic_store(slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the seven other blocks' partials of this workgroup's 64 rows -> red[row * 8 + block]; thread t polls blocks 2 (t & 3), + 1 of row t >> 2
+__device__ __forceinline__ bool lnx_gather(const unsigned long long* tile_slots, float* red, int own, unsigned tag, int tid) {
+    const int r = tid >> 2, k = tid & 3;
+    const unsigned long long* p0 = tile_slots + (2 * k) * 64 + r;
+    const unsigned long long* p1 = p0 + 64;
+    bool need0 = 2 * k != own, need1 = 2 * k + 1 != own;
+    int budget = SM_LNX_POLLS;
+    while ((need0 || need1) && budget > 0) {
+        const unsigned long long g0 = need0 ? __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        const unsigned long long g1 = need1 ? __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        if (need0 && (unsigned)(g0 >> 32) == tag) { red[r * 8 + 2 * k] = __uint_as_float((unsigned)g0); need0 = false; }
+        if (need1 && (unsigned)(g1 >> 32) == tag) { red[r * 8 + 2 * k + 1] = __uint_as_float((unsigned)g1); need1 = false; }
+        if (need0 || need1) __builtin_amdgcn_s_sleep(1);
+        --budget;
+    }
+    return !(need0 || need1);
+}
+
+// what the tail wants from memory that does not depend on the product - the residual rows (planes the PREVIOUS launch wrote: an
+// Infinity-Cache round trip) and gamma / beta of the thread's 32 columns - requested before the K loop by the waves that will use them
+struct LnxPre {
+    f16x8 xh[4];
+    i32x2 xb[4];
+    f32x4 gm[8], bt[8];
+};
+__device__ __forceinline__ void lnx_prefetch(const GemmHArgs& g, int c, int m0, int tid, LnxPre& pre) {
+    constexpr int d = GLN_BN;
+    if (tid >= 128) return;
+    const int row = (tid >> 1) & 63, h = tid & 1;
+    const int grow = m0 + row, rowc = grow < g.M ? grow : g.M - 1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + h * 8;
+        pre.xh[u] = *reinterpret_cast<const f16x8*>(g.ln_xh + blk_index(rowc, c0, d));
+        pre.xb[u] = *reinterpret_cast<const i32x2*>(g.ln_xl8 + blk8_index(rowc, c0, d));
+        pre.gm[2 * u] = *reinterpret_cast<const f32x4*>(g.ln_gamma + c0), pre.gm[2 * u + 1] = *reinterpret_cast<const f32x4*>(g.ln_gamma + c0 + 4);
+        pre.bt[2 * u] = *reinterpret_cast<const f32x4*>(g.ln_beta + c0), pre.bt[2 * u + 1] = *reinterpret_cast<const f32x4*>(g.ln_beta + c0 + 4);
+    }
+}
+
+// stg: the workgroup's staged tile [64][SM_STG_LD] (accumulator + bias); red: [2][64][8] floats behind it
+__device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pre, const float* stg, float* red, int tm, int c, int m0, int tid) {
+    constexpr int d = GLN_BN;
+    const bool owner = tid < 128;                      // waves 0 and 1: thread (row, h) owns the 32 columns of partial(c, h)
+    const int row = (tid >> 1) & 63, h = tid & 1;
+    const int grow = m0 + row;
+    const int ntm = (g.M + 63) / 64;
+    unsigned long long* slots_s = g.ln_xchg + ((size_t)tm * 8) * 64;                    // [block][row] of this row tile: sums ...
+    unsigned long long* slots_q = g.ln_xchg + ((size_t)(ntm + tm) * 8) * 64;            // ... and squared deviations
+    float v[32];
+    float s = 0.f;
+    if (owner) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int cl = (u >> 1) * 32 + (u & 1) * 16 + h * 8;
+            const f32x4 y0 = *reinterpret_cast<const f32x4*>(stg + row * SM_STG_LD + cl), y1 = *reinterpret_cast<const f32x4*>(stg + row * SM_STG_LD + cl + 4);
+            float xl[8];
+            f32_of_bf8x8(pre.xb[u], xl);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (float)pre.xh[u][e] + xl[e];
+                const float t = a + (e < 4 ? y0[e] : y1[e - 4]);
+                v[u * 8 + e] = t;
+                s += t;
+            }
+        }
+        s += __shfl_xor(s, 1, 64);
+        if (h == 0) {
+            lnx_publish(slots_s + c * 64 + row, s, g.ln_epoch);
+            red[row * 8 + c] = s;
+        }
+    }
+    bool ok = lnx_gather(slots_s, red, c, g.ln_epoch, tid);
+    __syncthreads();
+    auto row_total = [&](const float* r8p) {
+        float t = r8p[0] + r8p[1];
+#pragma unroll
+        for (int k = 2; k < 8; ++k) t += r8p[k];
+        return t;
+    };
+    float mean = 0.f;
+    if (owner) {
+        mean = row_total(red + row * 8) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const float t = v[e] - mean;
+            q += t * t;
+        }
+        q += __shfl_xor(q, 1, 64);
+        if (h == 0) {
+            lnx_publish(slots_q + c * 64 + row, q, g.ln_epoch);
+            red[512 + row * 8 + c] = q;
+        }
+    }
+    ok &= lnx_gather(slots_q, red + 512, c, g.ln_epoch, tid);
+    __syncthreads();
+    if (!ok) atomicOr(g.range_flag, 2);                // a partner never showed up: the call is repeated without this kernel
+    if (!owner) return;
+    const float rstd = rsqrtf(row_total(red + 512 + row * 8) / (float)d + g.ln_eps);
+    bool overflow = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + h * 8;
+        const f32x4 g0 = pre.gm[2 * u], g1 = pre.gm[2 * u + 1], t0 = pre.bt[2 * u], t1 = pre.bt[2 * u + 1];
+        f16x8 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float o = (v[u * 8 + e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+            half_t hh, ll;
+            split_f32(o, hh, ll);
+            overflow |= !(fabsf(o) <= kHalfMax);
+            vh[e] = hh;
+            vl[e] = ll;
+        }
+        if (grow < g.M) {
+            *reinterpret_cast<f16x8*>(g.ln_xh + blk_index(grow, c0, d)) = vh;
+            if (!g.ln_no_lo) *reinterpret_cast<i32x2*>(g.ln_xl8 + blk8_index(grow, c0, d)) = bf8x8_of_f16(vl);
+        }
+    }
+    if (overflow && grow < g.M) atomicOr(g.range_flag, 1);
+}
+
 // The K loop of one tile (tm, tn): ring primed, then per stage wait + barrier + the mode's canonical MFMA sequence per k64 block.
 // SWAP: the transposed product (W fragment first).  Shared by gemm_small_kernel and gemm_small_out_kernel.
 template <int MODE, int WC, bool TWO, bool SWAP>
@@ -588,6 +728,33 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
         SM_STAMP(6);
         return;
     }
+    if constexpr (OUT == OUT_LNX) {
+        // as OUT_LN up to the staged tile; then the statistics exchange and the workgroup's own 64 columns (lnx_tail_mx)
+        static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
+        if constexpr (MODE == SM_MX && !TWO) {
+            LnxPre pre;
+            lnx_prefetch(g, tn, m0, tid, pre);
+            acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
+            __syncthreads();                                   // everybody is done with the operand ring: it becomes the staging tile
+            float* stg = reinterpret_cast<float*>(lds_raw);
+            {
+                float* sr = stg + (wr * 32 + l31) * SM_STG_LD + wc * 32 + 4 * hi;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 32 + 8 * q + 4 * hi);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[0][0][4 * q + e], kWInv, bv[e]);
+                    *reinterpret_cast<f32x4*>(sr + 8 * q) = o;
+                }
+            }
+            __syncthreads();
+            SM_STAMP(4);
+            lnx_tail_mx(g, pre, stg, stg + 64 * SM_STG_LD, tm, tn, m0, tid);
+            SM_STAMP(5);
+        }
+        return;
+    }
     // the ConcatSquash GEMMs (and, on request, linear1) run transposed with the row-wise epilogue, as in the large-tile kernels
     if constexpr (csl_rowwise<EPI, OUT>() || (EPI == EPI_BIAS_RELU && OUT == OUT_SPLIT)) {
         if (csl_rowwise<EPI, OUT>() ? (!MX || (flags & 4)) : (flags & 8)) {
@@ -607,7 +774,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
             return;
         }
     }
-    if constexpr (OUT != OUT_LN) {
+    if constexpr (OUT != OUT_LN && OUT != OUT_LNX) {
     acc[0][0] = small_kloop<MODE, WC, TWO, false>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
     gemm_h_epilogue<1, 1, EPI, OUT, X2, MX && OUT == OUT_QKV>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
     }
@@ -759,7 +926,7 @@ inline int small_gemm_shape(const GemmHArgs& g) {
 template <int EPI, int OUT, int MODE>
 inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t st) {
     if (wc == 2) return launch_gemm_small_cfg<EPI, OUT, MODE, 2>(g, st);
-    if constexpr (OUT == OUT_LN) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
+    if constexpr (OUT == OUT_LN || OUT == OUT_LNX) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
     else {
         if constexpr (MODE != SM_X3)
             if (wc == 8) return launch_gemm_small_cfg<EPI, OUT, MODE, 4, true>(g, st);
@@ -770,6 +937,15 @@ inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch (OUT_LN)?  d_model 512, at most 256 tiles of 64 x 64
 inline bool small_ln_fits(int M, int K) {
     return tune().gemm_small != 1 && tune().small_now == 1 && tune().gemm_h_variant == 0 && tune().small_ln == 1 && K % 128 == 0 && (long)((M + 63) / 64) * (GLN_BN / 64) <= 256;
+}
+
+// does out_proj / linear2 + residual + LayerNorm run as ONE small launch with the statistics exchange (OUT_LNX)?  F16MX at d_model 512,
+// at most 256 tiles of 64 x 64 with nothing else in flight on the handle (the waiting workgroups need their partners resident), at
+// most 32 row tiles (the exchange buffer).  "small_lnx" knob: 0 on, 2 off (GEMM + add_ln2).
+inline bool small_lnx_fits(int M, int K) {
+    const long ntm = (M + 63) / 64;
+    return tune().gemm_small != 1 && tune().small_now == 1 && tune().gemm_h_variant == 0 && tune().small_lnx != 2 && K % 128 == 0 &&
+           ntm * (GLN_BN / 64) <= 256 && ntm <= 32;
 }
 
 template <int EPI, int OUT>

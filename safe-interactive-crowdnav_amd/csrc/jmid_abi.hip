@@ -386,6 +386,7 @@ int jmid_predict(jmid_handle_t h, int E, int A, int K, int T, int k, const float
     HIPCHK(h, hipMemcpyAsync(pout, dev + o_out, out_floats * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (flagged && *reinterpret_cast<const int*>(pout + (o_flag - o_out))) {
+        if (*reinterpret_cast<const int*>(pout + (o_flag - o_out)) & 2) { h->lnx_off = true; ++h->lnx_timeouts; }
         ++h->erange_calls;
         h->last_pos = nullptr;
         return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
@@ -452,6 +453,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches
 #endif
         {"small_lanes", &Tuning::small_lanes, 0, 2},
+        {"small_lnx", &Tuning::small_lnx, 0, 2},               // 2: GEMM + add_ln2 instead of the one-launch GEMM + LayerNorm with the statistics exchange
 #ifdef JMID_EXPERIMENTS
         {"small_out", &Tuning::small_out, 0, 2},
 #endif

@@ -106,6 +106,9 @@ struct jmid_ctx {
     size_t io_dev_bytes = 0;
     bool chained = false;       // the running run_network is a stage of jmid_predict: no caller-stream ordering, no flag round trip
     int64_t erange_calls = 0;   // calls on this handle that ended with JMID_ERANGE (jmid_erange_count)
+    unsigned lnx_epoch = 0;     // launch tag of the small-launch GEMM + LayerNorm with the statistics exchange (gemm_small.hpp, OUT_LNX)
+    bool lnx_off = false;       // a workgroup of that kernel once gave up waiting for a partner (range flag bit 1): the handle stays on GEMM + add_ln2
+    int64_t lnx_timeouts = 0;
     int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
@@ -149,6 +152,7 @@ struct jmid_ctx {
 };
 
 constexpr size_t kLnCounters = 256;      // arrival counters of the small-launch GEMM + LayerNorm per step workspace (gemm_small.hpp, OUT_LN)
+constexpr size_t kLnxWords = 2 * jmid::SM_LNX_GRANULES;      // ... followed by the exchange granules of OUT_LNX (8 bytes each), zeroed with them
 
 namespace jmid_host {
 

@@ -197,15 +197,28 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
     if (int rc = make_w8(h, dW, N, K, &img)) return rc;
     tmp.push_back(img.p);
     int rc = 0;
-    if (fused) {
+    if (fused == 1) {
         GemmLn2Args g2{ah, w16h, img.p, dB, dG, dT, xh, xl8, M, K, 1e-5f, h->range_flag, 0};
         hipError_t e = launch_gemm_ln2_mx(g2, h->stream);
         if (e != hipSuccess) rc = fail(h, JMID_EHIP, hipGetErrorString(e));
     } else {
         GemmHArgs g{};
         g.Ahi = ah; g.Alo = al; g.Whi = wh; g.Wlo = wl; g.W8 = img.p; g.bias = dB; g.C = dY; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        if (fused == 3) {        // the small-launch kernel with the statistics exchange (gemm_small.hpp, OUT_LNX)
+            unsigned long long* xs = (unsigned long long*)dalloc(kLnxWords * sizeof(unsigned), nullptr);
+            if (!xs || !small_lnx_fits(M, K)) return fail(h, JMID_EINVAL, "jmid_dbg_gemm_ln_mx: shape does not take the small kernel with the statistics exchange");
+            g.ln_gamma = dG; g.ln_beta = dT; g.ln_xh = xh; g.ln_xl = nullptr; g.ln_xl8 = xl8; g.ln_xchg = xs; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
+            (void)hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream);
+            rc = run_gemm_lnx_small(h, KC_GEMM_OUT, g);
+            if (!rc) {
+                int flag = 0;
+                (void)hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+                (void)hipStreamSynchronize(h->stream);
+                if (flag & 2) rc = fail(h, JMID_EHIP, "jmid_dbg_gemm_ln_mx: a workgroup gave up waiting for its row tile's statistics");
+            }
+        } else
 #ifndef JMID_EXPERIMENTS
-        if (fused == 2) return fail(h, JMID_EINVAL, "jmid_dbg_gemm_ln_mx: fused = 2 (small-launch GEMM + LayerNorm) is compiled with -DJMID_EXPERIMENTS only");
+        if (fused == 2) { return fail(h, JMID_EINVAL, "jmid_dbg_gemm_ln_mx: fused = 2 (small-launch GEMM + LayerNorm) is compiled with -DJMID_EXPERIMENTS only"); } else
 #else
         if (fused == 2) {        // the small-launch kernel with the LayerNorm tail (gemm_small.hpp, OUT_LN)
             unsigned* cnt = (unsigned*)dalloc(kLnCounters * sizeof(unsigned), nullptr);

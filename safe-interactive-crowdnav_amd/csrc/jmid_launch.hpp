@@ -34,6 +34,17 @@ inline int run_gemm_ln_small(jmid_ctx* h, int cls, GemmHArgs& g) {
 }
 #endif
 
+// the same with the row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX; F16MX at d_model 512)
+inline int run_gemm_lnx_small(jmid_ctx* h, int cls, GemmHArgs& g) {
+    g.range_flag = h->range_flag;
+    g.x2 = h->x2;
+    if (++h->lnx_epoch == 0) h->lnx_epoch = 1;        // (0 is what the zeroed granules hold)
+    g.ln_epoch = h->lnx_epoch;
+    ProfScope ps(h, cls);
+    HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LNX>(g, 2, h->stream)));
+    return 0;
+}
+
 // JMID_PREC_F16MX: hand the GEMM the fp8 image of this weight's lo plane (the kernels that have no fp8 path ignore it)
 inline void set_w8(jmid_ctx* h, GemmHArgs& g, const std::string& name) {
     g.W8 = nullptr;

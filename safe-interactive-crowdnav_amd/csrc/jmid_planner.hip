@@ -41,6 +41,7 @@ struct StepBuffers {
     int attn_nsplit;          // split-KV factor of the attention launch (1 = off)
     float *Opart, *MLpart;
     unsigned* ln_cnt;         // arrival counters of the small-launch GEMM + LayerNorm (gemm_small.hpp, OUT_LN): kLnCounters words
+    unsigned long long* ln_xchg;   // ... and, behind them, the exchange granules of OUT_LNX (kLnxWords words)
 };
 
 half_t* take_half(Carver& c, size_t n) { return reinterpret_cast<half_t*>(c.take((n + 1) / 2)); }
@@ -63,7 +64,8 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
     StepBuffers s{};
     s.X = c.take(Mc * h->d);
     s.Y = c.take((Mc + 63) / 64 * 64 * h->d);     // (whole 64-row tiles: the hand-off layout of gemm_small.hpp's LayerNorm tail)
-    s.ln_cnt = reinterpret_cast<unsigned*>(c.take(kLnCounters));
+    s.ln_cnt = reinterpret_cast<unsigned*>(c.take(kLnCounters + kLnxWords));
+    s.ln_xchg = reinterpret_cast<unsigned long long*>(s.ln_cnt + kLnCounters);
     s.Y4 = c.take(Mc * h->dlow);
     if (precision == JMID_PREC_F32) {
         s.QKV = c.take(Mc * 3 * h->d);
@@ -255,6 +257,11 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                     if (int rc = run_gemm_ln_small(h, KC_GEMM_OUT, g)) return rc;
                 } else
 #endif
+                if (mxv2 && !h->lnx_off && small_lnx_fits(M, g.K)) {
+                    g.ln_gamma = W(h, p + ".norm1.weight"); g.ln_beta = W(h, p + ".norm1.bias"); g.ln_xh = sb.Xh; g.ln_xl = nullptr;
+                    g.ln_xl8 = Xl8; g.ln_xchg = sb.ln_xchg; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
+                    if (int rc = run_gemm_lnx_small(h, KC_GEMM_OUT, g)) return rc;
+                } else
                 {
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), M, d, sb.Xh,
@@ -296,6 +303,11 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                     if (int rc = run_gemm_ln_small(h, KC_GEMM_FF2, g)) return rc;
                 } else
 #endif
+                if (mxv2 && !h->lnx_off && small_lnx_fits(M, g.K)) {
+                    g.ln_gamma = W(h, p + ".norm2.weight"); g.ln_beta = W(h, p + ".norm2.bias"); g.ln_xh = sb.Xh; g.ln_xl = nullptr;
+                    g.ln_xl8 = Xl8; g.ln_xchg = sb.ln_xchg; g.ln_eps = 1e-5f; g.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
+                    if (int rc = run_gemm_lnx_small(h, KC_GEMM_FF2, g)) return rc;
+                } else
                 {
                 if (int rc = (run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_FF2, g))) return rc;
                 if (int rc = run_add_ln(h, sb.X, sb.Y, W(h, p + ".norm2.weight"), W(h, p + ".norm2.bias"), M, d, sb.Xh,
@@ -547,7 +559,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     const StepBuffers& sb = sbs[0];
     if (precision != JMID_PREC_F32) {
         HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
-        for (int l = 0; l < lanes; ++l) HIPCHK(h, hipMemsetAsync(sbs[l].ln_cnt, 0, kLnCounters * sizeof(unsigned), h->stream));
+        for (int l = 0; l < lanes; ++l) HIPCHK(h, hipMemsetAsync(sbs[l].ln_cnt, 0, (kLnCounters + kLnxWords) * sizeof(unsigned), h->stream));
         for (int l = 0; l < lanes; ++l)
             if (sbs[l].Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
                 HIPCHK(h, hipMemsetAsync(sbs[l].Vth, 0, sbs[l].vt_elems * sizeof(half_t), h->stream));
@@ -684,6 +696,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (flag & 2) { h->lnx_off = true; ++h->lnx_timeouts; }     // (gemm_small.hpp, OUT_LNX: a workgroup gave up waiting; the caller's rerun takes GEMM + add_ln2)
         if (flag) ++h->erange_calls;
         if (flag) h->last_pos = nullptr;     // the integrated positions are poisoned too: jmid_topk(pos = NULL) must not rank them
         if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");

@@ -405,6 +405,27 @@ def test_split_modes_hold_parity_when_attention_is_peaked():
     assert oerr["f16x2"] <= ADE_GATE and oerr["f16mx"] <= ADE_GATE, oerr
 
 
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz"])
+def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
+    """One scene in F16MX (d_model 512): out_proj / linear2 + residual + LayerNorm run as ONE small launch whose workgroups exchange
+    the row statistics (gemm_small.hpp, OUT_LNX; six launches less per denoise step).  Same bits as GEMM + add_ln2 over a whole
+    50-step loop, repeated on one handle (the exchange buffer is reused by every launch of every call); no workgroup ever gives up
+    waiting (that would come back as JMID_ERANGE and switch the handle to the pair)."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    eng.set_step(int(z["step"]), "ddim")
+    out = []
+    try:
+        for knob in (2, 0, 0, 0):
+            eng.set_tuning("small_lnx", knob)
+            out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16mx", want_pos=False)[0][0])
+    finally:
+        eng.set_tuning("small_lnx", 0)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o, out[0])
+    assert ade(out[1], z["vel"]) <= ADE_GATE
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w32_a5k20t12_s50.npz", "ddpm_jmid_w32_a2k3t4_s10.npz"])
 def test_output_kernel_with_fused_next_embedding_is_bit_identical(case, precision):
