@@ -89,9 +89,8 @@ __device__ __forceinline__ void store_stream(T* p, const T& v) {
 #endif
 }
 
-enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2, OUT_LN = 3, OUT_LNX = 4 };     // gemm_small.hpp only.  OUT_LN: fp32 tile + residual + LayerNorm by the last
-                                                                                  // workgroup of the row tile; OUT_LNX: every workgroup normalises its own 64 columns after
-                                                                                  // exchanging the row statistics with the seven others of its row tile
+enum GemmOut { OUT_F32 = 0, OUT_SPLIT = 1, OUT_QKV = 2, OUT_LNX = 4 };     // OUT_LNX (gemm_small.hpp only): + residual + LayerNorm, every workgroup normalising its own
+                                                                        // 64 columns after exchanging the row statistics with the seven others of its row tile
 
 
 struct GemmHArgs {
@@ -118,16 +117,16 @@ struct GemmHArgs {
     unsigned char *K8h, *K8l; // OUT_QKV, JMID_PREC_F16MX with head_dim 128: bf8 images of K_hi / K_lo, [M, d] bytes each, written
                               // INSTEAD of the fp16 K_lo plane (attn_f16x3_dma_kernel<.., MX>); null: K_lo as fp16
     unsigned char* Q8l;       // with them: bf8 image of Q_lo, [M, d] bytes, INSTEAD of the fp16 Q_lo plane (all that kernel wants of Q_lo)
-    // OUT_LN (gemm_small.hpp, N = 512): X <- LayerNorm(X + C) * gamma + beta by the last-arriving workgroup of each 64-row tile
+    // OUT_LNX (gemm_small.hpp, N = 512): X <- LayerNorm(X + A . W^T + bias) * gamma + beta
     const float *ln_gamma, *ln_beta;
     half_t *ln_xh, *ln_xl;    // residual stream planes (blocked); F16MX at d_model 512: ln_xl8 instead of ln_xl
     unsigned char* ln_xl8;    // bf8 image of the lo plane (gemm_ln2_mx.hpp::blk8_index), or null
-    unsigned* ln_cnt;         // [ceil(M / 64)] arrival counters, monotonic over launches (zeroed once per call)
     float ln_eps;
     int ln_no_lo;             // the last LayerNorm of the net: nobody reads its lo plane (F16MX)
-    // OUT_LNX (gemm_small.hpp): the row-statistics exchange of the workgroups of a row tile
+    // the row-statistics exchange of the workgroups of a row tile
     unsigned long long* ln_xchg;   // [2 kinds][ceil(M / 64)][8 column tiles][64 rows] granules {fp32 partial, launch tag}, zeroed once per call
     unsigned ln_epoch;             // this launch's tag: never 0, never repeated within a call
+    int ln_one;                    // one exchange (sum + squared deviations from the block's own mean, merged) instead of two in the canonical order
 };
 
 constexpr int GEMMH_BK = 32;

@@ -74,233 +74,8 @@ struct SmCfg {
     static_assert(NS >= 2 && (L - 1) * NR <= 63, "ring depth against the vmcnt range");
 };
 
-// sc1 (agent-scope, write-through / L1-bypassing) 16-byte accesses for data handed from one workgroup to another inside a launch
-__device__ __forceinline__ void store_sc1_b128(float* p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ f32x4 load_sc1_b128(const float* p) {
-    f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
-// ---- OUT_LN: residual + LayerNorm of a 64-row tile by ONE 256-thread workgroup (the last of the tile's ntn workgroups to arrive).
-// The fp32 rows (accumulator + bias) of the other workgroups come through memory: every producer stages its 64 x 64 tile in LDS
-// and writes it out in 1 KB wave-instructions (sc1: write-through), in the order the consumer's lanes will want it; the consumer
-// reads it back with sc1 loads (past its L1), all of them requested before the first use - one memory round trip for the tile.
-// Per row the arithmetic and the summation order are those of the stand-alone kernels (add_ln2_kernel / add_ln_kernel<2, true>):
-// the rows are bit-identical to the unfused pair.
-//
-// F16MX at d_model 512 (byte lo plane, gemm_ln2_mx.hpp's canonical order: partial(c, h) over the 32 columns 64 c + 32 j + 16 p + 8 h + e,
-// P_c = partial(c, 0) + partial(c, 1), total = ((((((P0 + P1) + P2) + P3) + P4) + P5) + P6) + P7):
-//   hand-off layout of a row tile: [c = 0..7][pass = 0..3][i = 0..7][32 lanes] x 16 B, lane = 2 (row % 16) + h, row = 16 pass + row % 16,
-//   i = 2 u + half: the four floats 64 c + 32 (u >> 1) + 16 (u & 1) + 8 h + 4 half + 0..3.  Block c (16 KB, contiguous) is exactly
-//   what the workgroup of N-tile c produces; consumer wave w owns blocks 2 w and 2 w + 1 (lanes 0-31 / 32-63) for all 64 rows, and the
-//   row totals are formed from the eight P_c in LDS, in the canonical order.
 __device__ __forceinline__ bool tune_small_qk(int flags) { return (flags & 16) == 0; }      // ("small_qk" = 2: the generic epilogue, A/B)
-constexpr int SM_LN_TILE_BYTES = 64 * GLN_BN * 4;          // one row tile of the hand-off buffer: 128 KB
-constexpr int SM_STG_LD = 68;                              // floats per row of the staged 64 x 64 tile (272 B: conflict-free b128)
-
-__device__ __forceinline__ void sm_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// the producer's side: the staged tile (LDS, [64][SM_STG_LD] floats) -> global, 1 KB per wave-instruction
-template <bool MXV2>
-__device__ __forceinline__ void ln_handoff_store(const float* stg, float* Y, int ldc, int m0, int n0, int tn, int tm, int M, int tid) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int idx = ps * 256 + tid;                    // 16-byte unit of the tile
-        if (MXV2) {
-            const int hi = idx & 1, r16 = (idx >> 1) & 15, i = (idx >> 5) & 7, p = idx >> 8;
-            const int u = i >> 1, half = i & 1, row = p * 16 + r16, col = (u >> 1) * 32 + (u & 1) * 16 + hi * 8 + half * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SM_STG_LD + col);
-            store_sc1_b128(Y + (size_t)tm * (SM_LN_TILE_BYTES / 4) + tn * 4096 + idx * 4, v);
-        } else {                                           // row-major [M, 512]: 256-byte row pieces
-            const int row = idx >> 4, ch = idx & 15;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SM_STG_LD + ch * 4);
-            if (m0 + row < M) store_sc1_b128(Y + (size_t)(m0 + row) * ldc + n0 + ch * 4, v);
-        }
-    }
-}
-
-__device__ __forceinline__ void ln_tail_mx(const float* Yt, const float* gamma, const float* beta, int M, float eps, half_t* Xh,
-                                           unsigned char* Xl8, int no_lo_out, int* range_flag, int row0, int tid, float* red
-#ifdef JMID_SMALL_TRACE
-                                           , unsigned long long* sm_trace_p
-#endif
-                                           ) {
-    constexpr int d = GLN_BN, NP = 4;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int c = 2 * wid + (lane >> 5), r16 = (lane >> 1) & 15, hi = lane & 1;
-    f16x8 xh[NP][4];
-    i32x2 xb[NP][4];
-    f32x4 y[NP][8];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = row0 + p * 16 + r16, rowc = row < M ? row : M - 1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
-            xh[p][u] = *reinterpret_cast<const f16x8*>(Xh + blk_index(rowc, c0, d));
-            xb[p][u] = *reinterpret_cast<const i32x2*>(Xl8 + blk8_index(rowc, c0, d));
-        }
-    }
-    const float* yb = Yt + c * 4096 + (lane & 31) * 4;
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[p][i] = load_sc1_b128(yb + (p * 8 + i) * 128);
-    sm_wait_loads();
-    SM_STAMP(7);
-#pragma unroll
-    for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(y[p][i]));
-    // red: [2][64 rows][8] floats - the P_c of every row, first of the sums, then of the squared deviations
-    auto row_total = [&](const float* r8p) {
-        float t = r8p[0] + r8p[1];
-#pragma unroll
-        for (int k = 2; k < 8; ++k) t += r8p[k];
-        return t;
-    };
-    float v[NP][32];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        float s = 0.f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float xl[8];
-            f32_of_bf8x8(xb[p][u], xl);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float a = (float)xh[p][u][e] + xl[e];
-                const float t = a + (e < 4 ? y[p][2 * u][e] : y[p][2 * u + 1][e - 4]);
-                v[p][u * 8 + e] = t;
-                s += t;
-            }
-        }
-        s += __shfl_xor(s, 1, 64);
-        if (hi == 0) red[(p * 16 + r16) * 8 + c] = s;
-    }
-    __syncthreads();
-    float mean[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        mean[p] = row_total(red + (p * 16 + r16) * 8) / (float)d;
-        float q = 0.f;
-#pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const float t = v[p][e] - mean[p];
-            q += t * t;
-        }
-        q += __shfl_xor(q, 1, 64);
-        if (hi == 0) red[512 + (p * 16 + r16) * 8 + c] = q;
-    }
-    __syncthreads();
-    SM_STAMP(8);
-    bool overflow = false;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = row0 + p * 16 + r16;
-        const float rstd = rsqrtf(row_total(red + 512 + (p * 16 + r16) * 8) / (float)d + eps);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + hi * 8;
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(beta + c0), t1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
-            f16x8 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float o = (v[p][u * 8 + e] - mean[p]) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
-                half_t hh, ll;
-                split_f32(o, hh, ll);
-                overflow |= row < M && !(fabsf(o) <= kHalfMax);
-                vh[e] = hh;
-                vl[e] = ll;
-            }
-            if (row < M) {
-                *reinterpret_cast<f16x8*>(Xh + blk_index(row, c0, d)) = vh;
-                if (!no_lo_out) *reinterpret_cast<i32x2*>(Xl8 + blk8_index(row, c0, d)) = bf8x8_of_f16(vl);
-            }
-        }
-    }
-    if (overflow) atomicOr(range_flag, 1);
-}
-
-// F16X2 / F16X3 (fp16 lo plane): one wave per row and pass, lane l the columns 4 l .. 4 l + 3 and 256 + 4 l .. (add_ln_kernel<2, true>);
-// the hand-off buffer is the row-major fp32 [M, 512] the stand-alone GEMM writes: a wave's loads are whole 1 KB half rows
-__device__ __forceinline__ void ln_tail_planes(const float* Y, const float* gamma, const float* beta, int M, float eps, half_t* Xh,
-                                               half_t* Xl, int row0, int tid) {
-    constexpr int d = GLN_BN, NP = 16;                 // 4 waves x 16 passes = 64 rows
-    const int lane = tid & 63, wid = tid >> 6;
-    f16x4 ph[NP][2], pl[NP][2];
-    f32x4 y[NP][2];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = row0 + p * 4 + wid, rowc = row < M ? row : M - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const size_t ob = blk_index(rowc, (i * 64 + lane) * 4, d);
-            ph[p][i] = *reinterpret_cast<const f16x4*>(Xh + ob);
-            pl[p][i] = *reinterpret_cast<const f16x4*>(Xl + ob);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = row0 + p * 4 + wid, rowc = row < M ? row : M - 1;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) y[p][i] = load_sc1_b128(Y + (size_t)rowc * d + (i * 64 + lane) * 4);
-    }
-    sm_wait_loads();
-#pragma unroll
-    for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(y[p][0]), "+v"(y[p][1]));
-    f32x4 gm[2], bt[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        gm[i] = *reinterpret_cast<const f32x4*>(gamma + (i * 64 + lane) * 4);
-        bt[i] = *reinterpret_cast<const f32x4*>(beta + (i * 64 + lane) * 4);
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = row0 + p * 4 + wid;
-        f32x4 v[2];
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f32x4 a;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[e] = (float)ph[p][i][e] + (float)pl[p][i][e];
-            v[i] = a + y[p][i];
-            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
-        const float mean = wave_sum(s) / (float)d;
-        float q = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = v[i][e] - mean;
-                q += t * t;
-            }
-        const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            f16x4 vh, vl;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float o = (v[i][e] - mean) * rstd * gm[i][e] + bt[i][e];
-                half_t hh, ll;
-                split_f32(o, hh, ll);
-                vh[e] = hh;
-                vl[e] = ll;
-            }
-            if (row < M) {
-                const size_t ob = blk_index(row, (i * 64 + lane) * 4, d);
-                *reinterpret_cast<f16x4*>(Xh + ob) = vh;
-                *reinterpret_cast<f16x4*>(Xl + ob) = vl;
-            }
-        }
-    }
-}
+constexpr int SM_STG_LD = 68;                              // floats per row of a staged 64 x 64 tile (272 B: conflict-free b128)
 
 // ---- OUT_LNX: out_proj / linear2 + residual + LayerNorm in ONE small launch WITHOUT concentrating the row-wise work: the eight
 // workgroups of a 64-row tile (N = 512 = 8 column tiles of 64) each keep their own 64 x 64 block, exchange only the ROW STATISTICS -
@@ -319,22 +94,37 @@ constexpr size_t SM_LNX_GRANULES = size_t(2) * 32 * 8 * 64;     // per step work
 __device__ __forceinline__ void lnx_publish(unsigned long long* slot, float v, unsigned tag) {
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the seven other blocks' partials of this workgroup's 64 rows -> red[row * 8 + block]; thread t polls blocks 2 (t & 3), + 1 of row t >> 2
-__device__ __forceinline__ bool lnx_gather(const unsigned long long* tile_slots, float* red, int own, unsigned tag, int tid) {
+// the seven other blocks' partials of this workgroup's 64 rows -> red[row * 8 + block]; thread t polls blocks 2 (t & 3), + 1 of row t >> 2.
+// TWO_STATS: the granules of both statistics in one sweep (slots_q / red + 512 next to slots_s / red)
+template <bool TWO_STATS>
+__device__ __forceinline__ bool lnx_gather(const unsigned long long* slots_s, const unsigned long long* slots_q, float* red, int own,
+                                           unsigned tag, int tid) {
     const int r = tid >> 2, k = tid & 3;
-    const unsigned long long* p0 = tile_slots + (2 * k) * 64 + r;
+    const unsigned long long* p0 = slots_s + (2 * k) * 64 + r;
     const unsigned long long* p1 = p0 + 64;
-    bool need0 = 2 * k != own, need1 = 2 * k + 1 != own;
+    const unsigned long long* q0 = slots_q + (2 * k) * 64 + r;
+    const unsigned long long* q1 = q0 + 64;
+    float* d0 = red + r * 8 + 2 * k;
+    bool n0 = 2 * k != own, n1 = 2 * k + 1 != own, m0 = TWO_STATS && n0, m1 = TWO_STATS && n1;
     int budget = SM_LNX_POLLS;
-    while ((need0 || need1) && budget > 0) {
-        const unsigned long long g0 = need0 ? __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        const unsigned long long g1 = need1 ? __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        if (need0 && (unsigned)(g0 >> 32) == tag) { red[r * 8 + 2 * k] = __uint_as_float((unsigned)g0); need0 = false; }
-        if (need1 && (unsigned)(g1 >> 32) == tag) { red[r * 8 + 2 * k + 1] = __uint_as_float((unsigned)g1); need1 = false; }
-        if (need0 || need1) __builtin_amdgcn_s_sleep(1);
+    while ((n0 || n1 || m0 || m1) && budget > 0) {
+        unsigned long long g0 = 0, g1 = 0, h0 = 0, h1 = 0;
+        if (n0) g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n1) g1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (TWO_STATS) {
+            if (m0) h0 = __hip_atomic_load(q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (m1) h1 = __hip_atomic_load(q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (n0 && (unsigned)(g0 >> 32) == tag) { d0[0] = __uint_as_float((unsigned)g0); n0 = false; }
+        if (n1 && (unsigned)(g1 >> 32) == tag) { d0[1] = __uint_as_float((unsigned)g1); n1 = false; }
+        if (TWO_STATS) {
+            if (m0 && (unsigned)(h0 >> 32) == tag) { d0[512] = __uint_as_float((unsigned)h0); m0 = false; }
+            if (m1 && (unsigned)(h1 >> 32) == tag) { d0[513] = __uint_as_float((unsigned)h1); m1 = false; }
+        }
+        if (n0 || n1 || m0 || m1) __builtin_amdgcn_s_sleep(1);
         --budget;
     }
-    return !(need0 || need1);
+    return !(n0 || n1 || m0 || m1);
 }
 
 // what the tail wants from memory that does not depend on the product - the residual rows (planes the PREVIOUS launch wrote: an
@@ -344,24 +134,40 @@ struct LnxPre {
     i32x2 xb[4];
     f32x4 gm[8], bt[8];
 };
+// (Inline assembly, so that they stay where they are and their registers are not touched before lnx_prefetch_landed().  The loads are
+//  OLDER than every copy of the ring: the ring's counted waits cover them.)
 __device__ __forceinline__ void lnx_prefetch(const GemmHArgs& g, int c, int m0, int tid, LnxPre& pre) {
     constexpr int d = GLN_BN;
-    if (tid >= 128) return;
     const int row = (tid >> 1) & 63, h = tid & 1;
     const int grow = m0 + row, rowc = grow < g.M ? grow : g.M - 1;
+    if (tid < 128) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + h * 8;
-        pre.xh[u] = *reinterpret_cast<const f16x8*>(g.ln_xh + blk_index(rowc, c0, d));
-        pre.xb[u] = *reinterpret_cast<const i32x2*>(g.ln_xl8 + blk8_index(rowc, c0, d));
-        pre.gm[2 * u] = *reinterpret_cast<const f32x4*>(g.ln_gamma + c0), pre.gm[2 * u + 1] = *reinterpret_cast<const f32x4*>(g.ln_gamma + c0 + 4);
-        pre.bt[2 * u] = *reinterpret_cast<const f32x4*>(g.ln_beta + c0), pre.bt[2 * u + 1] = *reinterpret_cast<const f32x4*>(g.ln_beta + c0 + 4);
+        for (int u = 0; u < 4; ++u) {
+            const int c0 = c * 64 + (u >> 1) * 32 + (u & 1) * 16 + h * 8;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre.xh[u]) : "v"(g.ln_xh + blk_index(rowc, c0, d)) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(pre.xb[u]) : "v"(g.ln_xl8 + blk8_index(rowc, c0, d)) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre.gm[2 * u]) : "v"(g.ln_gamma + c0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre.gm[2 * u + 1]) : "v"(g.ln_gamma + c0 + 4) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre.bt[2 * u]) : "v"(g.ln_beta + c0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(pre.bt[2 * u + 1]) : "v"(g.ln_beta + c0 + 4) : "memory");
+        }
     }
+}
+__device__ __forceinline__ void lnx_prefetch_landed(LnxPre& pre) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(pre.xh[u]), "+v"(pre.xb[u]), "+v"(pre.gm[2 * u]), "+v"(pre.gm[2 * u + 1]), "+v"(pre.bt[2 * u]), "+v"(pre.bt[2 * u + 1]));
 }
 
 // stg: the workgroup's staged tile [64][SM_STG_LD] (accumulator + bias); red: [2][64][8] floats behind it
+// !ONE (what ships): two exchanges, the canonical order, bit-identical to the pair.  ONE ("small_lnx" = 1, diagnostics flavour): a single
+// exchange - every block publishes its sum P_c AND the squared deviations from ITS OWN mean, and the row variance is merged from the
+// eight (count, mean, M2) triples (Chan et al.): as accurate as the two-pass form and one memory round trip less per LayerNorm (one
+// scene 10.47 against 10.67 ms per call), but NOT the canonical summation order: the rows differ from add_ln2_kernel's in the last
+// bits, which 50 steps of F16MX carry to 1e-5 m - and every knob / chunk-plan / graph-replay test of tests/ compares bits.
 __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pre, const float* stg, float* red, int tm, int c, int m0, int tid) {
     constexpr int d = GLN_BN;
+    const bool ONE = g.ln_one != 0;                    // (uniform: a kernel argument)
     const bool owner = tid < 128;                      // waves 0 and 1: thread (row, h) owns the 32 columns of partial(c, h)
     const int row = (tid >> 1) & 63, h = tid & 1;
     const int grow = m0 + row;
@@ -386,12 +192,29 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
             }
         }
         s += __shfl_xor(s, 1, 64);
-        if (h == 0) {
+        if (ONE) {
+            const float mc = s / 64.f;
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const float t = v[e] - mc;
+                q += t * t;
+            }
+            q += __shfl_xor(q, 1, 64);
+            if (h == 0) {
+                lnx_publish(slots_s + c * 64 + row, s, g.ln_epoch);
+                lnx_publish(slots_q + c * 64 + row, q, g.ln_epoch);
+                red[row * 8 + c] = s;
+                red[512 + row * 8 + c] = q;
+            }
+        } else if (h == 0) {
             lnx_publish(slots_s + c * 64 + row, s, g.ln_epoch);
             red[row * 8 + c] = s;
         }
     }
-    bool ok = lnx_gather(slots_s, red, c, g.ln_epoch, tid);
+    bool ok;
+    if (ONE) ok = lnx_gather<true>(slots_s, slots_q, red, c, g.ln_epoch, tid);
+    else ok = lnx_gather<false>(slots_s, slots_q, red, c, g.ln_epoch, tid);
     __syncthreads();
     auto row_total = [&](const float* r8p) {
         float t = r8p[0] + r8p[1];
@@ -399,26 +222,38 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
         for (int k = 2; k < 8; ++k) t += r8p[k];
         return t;
     };
-    float mean = 0.f;
+    float mean = 0.f, rstd = 0.f;
     if (owner) {
         mean = row_total(red + row * 8) / (float)d;
-        float q = 0.f;
+        if (ONE) {
+            float dm = 0.f;
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const float t = v[e] - mean;
-            q += t * t;
-        }
-        q += __shfl_xor(q, 1, 64);
-        if (h == 0) {
-            lnx_publish(slots_q + c * 64 + row, q, g.ln_epoch);
-            red[512 + row * 8 + c] = q;
+            for (int k = 0; k < 8; ++k) {
+                const float t = red[row * 8 + k] / 64.f - mean;
+                dm += t * t;
+            }
+            rstd = rsqrtf((row_total(red + 512 + row * 8) + 64.f * dm) / (float)d + g.ln_eps);
+        } else {
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) {
+                const float t = v[e] - mean;
+                q += t * t;
+            }
+            q += __shfl_xor(q, 1, 64);
+            if (h == 0) {
+                lnx_publish(slots_q + c * 64 + row, q, g.ln_epoch);
+                red[512 + row * 8 + c] = q;
+            }
         }
     }
-    ok &= lnx_gather(slots_q, red + 512, c, g.ln_epoch, tid);
-    __syncthreads();
+    if (!ONE) {
+        ok &= lnx_gather<false>(slots_q, slots_q, red + 512, c, g.ln_epoch, tid);
+        __syncthreads();
+        if (owner) rstd = rsqrtf(row_total(red + 512 + row * 8) / (float)d + g.ln_eps);
+    }
     if (!ok) atomicOr(g.range_flag, 2);                // a partner never showed up: the call is repeated without this kernel
     if (!owner) return;
-    const float rstd = rsqrtf(row_total(red + 512 + row * 8) / (float)d + g.ln_eps);
     bool overflow = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -682,59 +517,20 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
     const int tm = fast_div(rem, gw, mgw), tn = cg * gw + (rem - tm * gw);
     const int m0 = tm * BM, n0 = tn * BN;
     f32x16 acc[1][1];
-    if constexpr (OUT == OUT_LN) {
-        // Transposed product: a lane owns token row l31 of its wave's block and four runs of 4 consecutive columns.  The fp32 rows
-        // (accumulator + bias: what the stand-alone GEMM hands add_ln*) go out write-through (sc1), the workgroup's arrival is counted
-        // per row tile, and the LAST of the ntn workgroups of a tile - whoever that is, wherever it runs - reads the complete rows
-        // back (sc1: past its L1) and normalises them.  No spinning: nobody waits for anybody.
-        static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
-        acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
-        __syncthreads();                                       // everybody is done with the operand ring: it becomes the staging tile
-        float* stg = reinterpret_cast<float*>(lds_raw);
-        {
-            float* sr = stg + (wr * 32 + l31) * SM_STG_LD + wc * 32 + 4 * hi;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 32 + 8 * q + 4 * hi);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[0][0][4 * q + e], kWInv, bv[e]);
-                *reinterpret_cast<f32x4*>(sr + 8 * q) = o;
-            }
-        }
-        __syncthreads();
-        if (g.ln_xl8) ln_handoff_store<true>(stg, g.C, g.ldc, m0, n0, tn, tm, g.M, tid);
-        else ln_handoff_store<false>(stg, g.C, g.ldc, m0, n0, tn, tm, g.M, tid);
-        SM_STAMP(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of the tile is out ...
-        __syncthreads();                                       // ... and the workgroup's
-        __shared__ unsigned sm_last;
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(g.ln_cnt + tm, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sm_last = (old % (unsigned)ntn) == (unsigned)(ntn - 1);
-        }
-        __syncthreads();
-        SM_STAMP(5);
-        if (!sm_last) return;
-        if (g.ln_xl8)
-            ln_tail_mx(g.C + (size_t)tm * (SM_LN_TILE_BYTES / 4), g.ln_gamma, g.ln_beta, g.M, g.ln_eps, g.ln_xh, g.ln_xl8, g.ln_no_lo,
-                       g.range_flag, m0, tid, stg
-#ifdef JMID_SMALL_TRACE
-                       , sm_trace_p
-#endif
-                       );
-        else
-            ln_tail_planes(g.C, g.ln_gamma, g.ln_beta, g.M, g.ln_eps, g.ln_xh, g.ln_xl, m0, tid);
-        SM_STAMP(6);
-        return;
-    }
     if constexpr (OUT == OUT_LNX) {
-        // as OUT_LN up to the staged tile; then the statistics exchange and the workgroup's own 64 columns (lnx_tail_mx)
+        // Transposed product: a lane owns token row l31 of its wave's block and four runs of 4 consecutive columns.  The fp32 rows
+        // (accumulator + bias: what the stand-alone GEMM hands add_ln2) are staged in LDS - the operand ring's place - in the ownership
+        // of the row statistics; then the exchange and the workgroup's own 64 columns (lnx_tail_mx)
         static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
         if constexpr (MODE == SM_MX && !TWO) {
+            // (the tile indices reach the prefetch through an opaque vector copy: with a visible vector use in front of the K loop hipcc
+            //  computes them in vector registers altogether, and the K loop's scalar-base copies fail to compile - "illegal VGPR to SGPR copy")
+            int m0_v = m0, c_v = tn;
+            asm volatile("" : "+v"(m0_v), "+v"(c_v));
             LnxPre pre;
-            lnx_prefetch(g, tn, m0, tid, pre);
+            lnx_prefetch(g, c_v, m0_v, tid, pre);
             acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
+            lnx_prefetch_landed(pre);
             __syncthreads();                                   // everybody is done with the operand ring: it becomes the staging tile
             float* stg = reinterpret_cast<float*>(lds_raw);
             {
@@ -774,7 +570,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
             return;
         }
     }
-    if constexpr (OUT != OUT_LN && OUT != OUT_LNX) {
+    if constexpr (OUT != OUT_LNX) {
     acc[0][0] = small_kloop<MODE, WC, TWO, false>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
     gemm_h_epilogue<1, 1, EPI, OUT, X2, MX && OUT == OUT_QKV>(g, acc, m0, n0, wr, wc, l31, hi, BM, BN);
     }
@@ -907,7 +703,7 @@ inline hipError_t launch_gemm_small_cfg(const GemmHArgs& g, hipStream_t st) {
 }
 
 // Does this GEMM run on the small-launch kernel, and in which shape?  One workgroup per CU: at most 256 tiles.
-//   -> 0 no, 2 / 4 = WC, 8 = WC 4 with two workgroups per CU.  (OUT_LN callers: 2 means the fused tail applies.)  "gemm_small" knob: 0 auto, 1 never.
+//   -> 0 no, 2 / 4 = WC, 8 = WC 4 with two workgroups per CU.  "gemm_small" knob: 0 auto, 1 never.
 inline int small_gemm_shape(const GemmHArgs& g) {
     if (tune().gemm_small == 1 || tune().gemm_h_variant != 0 || !tune().small_now) return 0;
     if (g.K % 128 != 0 || g.N % 128 != 0) return 0;       // (k128 ring stages)
@@ -926,7 +722,7 @@ inline int small_gemm_shape(const GemmHArgs& g) {
 template <int EPI, int OUT, int MODE>
 inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t st) {
     if (wc == 2) return launch_gemm_small_cfg<EPI, OUT, MODE, 2>(g, st);
-    if constexpr (OUT == OUT_LN || OUT == OUT_LNX) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
+    if constexpr (OUT == OUT_LNX) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
     else {
         if constexpr (MODE != SM_X3)
             if (wc == 8) return launch_gemm_small_cfg<EPI, OUT, MODE, 4, true>(g, st);
@@ -934,17 +730,13 @@ inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t
     }
 }
 
-// does out_proj / linear2 + residual + LayerNorm run as ONE small launch (OUT_LN)?  d_model 512, at most 256 tiles of 64 x 64
-inline bool small_ln_fits(int M, int K) {
-    return tune().gemm_small != 1 && tune().small_now == 1 && tune().gemm_h_variant == 0 && tune().small_ln == 1 && K % 128 == 0 && (long)((M + 63) / 64) * (GLN_BN / 64) <= 256;
-}
-
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch with the statistics exchange (OUT_LNX)?  F16MX at d_model 512,
 // at most 256 tiles of 64 x 64 with nothing else in flight on the handle (the waiting workgroups need their partners resident), at
-// most 32 row tiles (the exchange buffer).  "small_lnx" knob: 0 on, 2 off (GEMM + add_ln2).
+// most 32 row tiles (the exchange buffer), in calls of ONE chunk (a call's bits must not depend on its chunk plan or its lanes).  "small_lnx" knob: 0 on with two exchanges (the default: bit-identical to the pair), 1 on with
+// ONE exchange (diagnostics flavour), 2 off (GEMM + add_ln2).
 inline bool small_lnx_fits(int M, int K) {
     const long ntm = (M + 63) / 64;
-    return tune().gemm_small != 1 && tune().small_now == 1 && tune().gemm_h_variant == 0 && tune().small_lnx != 2 && K % 128 == 0 &&
+    return tune().gemm_small != 1 && tune().small_now == 1 && tune().one_chunk == 1 && tune().gemm_h_variant == 0 && tune().small_lnx != 2 && K % 128 == 0 &&
            ntm * (GLN_BN / 64) <= 256 && ntm <= 32;
 }
 

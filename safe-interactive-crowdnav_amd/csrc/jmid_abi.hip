@@ -449,11 +449,8 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 #endif
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
-#ifdef JMID_EXPERIMENTS
-        {"small_ln", &Tuning::small_ln, 0, 2},                 // 2: no fused LayerNorm tail in small launches
-#endif
         {"small_lanes", &Tuning::small_lanes, 0, 2},
-        {"small_lnx", &Tuning::small_lnx, 0, 2},               // 2: GEMM + add_ln2 instead of the one-launch GEMM + LayerNorm with the statistics exchange
+        {"small_lnx", &Tuning::small_lnx, 0, 2},               // the one-launch GEMM + LayerNorm with the statistics exchange: 0 two exchanges (bit-identical), 1 one exchange, 2 off (GEMM + add_ln2)
 #ifdef JMID_EXPERIMENTS
         {"small_out", &Tuning::small_out, 0, 2},
 #endif

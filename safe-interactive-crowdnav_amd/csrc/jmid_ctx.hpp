@@ -151,8 +151,7 @@ struct jmid_ctx {
     std::string err;
 };
 
-constexpr size_t kLnCounters = 256;      // arrival counters of the small-launch GEMM + LayerNorm per step workspace (gemm_small.hpp, OUT_LN)
-constexpr size_t kLnxWords = 2 * jmid::SM_LNX_GRANULES;      // ... followed by the exchange granules of OUT_LNX (8 bytes each), zeroed with them
+constexpr size_t kLnxWords = 2 * jmid::SM_LNX_GRANULES;      // 32-bit words of the exchange granules (8 bytes each) of the small-launch GEMM + LayerNorm per step workspace (gemm_small.hpp, OUT_LNX)
 
 namespace jmid_host {
 

@@ -217,16 +217,6 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
                 if (flag & 2) rc = fail(h, JMID_EHIP, "jmid_dbg_gemm_ln_mx: a workgroup gave up waiting for its row tile's statistics");
             }
         } else
-#ifndef JMID_EXPERIMENTS
-        if (fused == 2) { return fail(h, JMID_EINVAL, "jmid_dbg_gemm_ln_mx: fused = 2 (small-launch GEMM + LayerNorm) is compiled with -DJMID_EXPERIMENTS only"); } else
-#else
-        if (fused == 2) {        // the small-launch kernel with the LayerNorm tail (gemm_small.hpp, OUT_LN)
-            unsigned* cnt = (unsigned*)dalloc(kLnCounters * sizeof(unsigned), nullptr);
-            if (!cnt || !small_ln_fits(M, K)) return fail(h, JMID_EINVAL, "jmid_dbg_gemm_ln_mx: shape does not take the small fused kernel");
-            g.ln_gamma = dG; g.ln_beta = dT; g.ln_xh = xh; g.ln_xl = nullptr; g.ln_xl8 = xl8; g.ln_cnt = cnt; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
-            rc = run_gemm_ln_small(h, KC_GEMM_OUT, g);
-        } else
-#endif
         {
         rc = run_gemm_h<EPI_BIAS, OUT_F32>(h, KC_GEMM_OUT, g);
         if (!rc) rc = run_add_ln(h, nullptr, dY, dG, dT, M, N, xh, reinterpret_cast<half_t*>(xl8), true, 0);

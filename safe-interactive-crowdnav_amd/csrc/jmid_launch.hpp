@@ -23,23 +23,13 @@ int run_gemm_h(jmid_ctx* h, int cls, GemmHArgs& g) {
     return 0;
 }
 
-#ifdef JMID_EXPERIMENTS
-// out_proj / linear2 + residual + LayerNorm as ONE small launch (gemm_small.hpp, OUT_LN); g carries the GEMM, the ln_* fields the tail
-inline int run_gemm_ln_small(jmid_ctx* h, int cls, GemmHArgs& g) {
-    g.range_flag = h->range_flag;
-    g.x2 = h->x2;
-    ProfScope ps(h, cls);
-    HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LN>(g, 2, h->stream)));
-    return 0;
-}
-#endif
-
-// the same with the row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX; F16MX at d_model 512)
+// out_proj / linear2 + residual + LayerNorm as ONE small launch, the row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX; F16MX at d_model 512)
 inline int run_gemm_lnx_small(jmid_ctx* h, int cls, GemmHArgs& g) {
     g.range_flag = h->range_flag;
     g.x2 = h->x2;
     if (++h->lnx_epoch == 0) h->lnx_epoch = 1;        // (0 is what the zeroed granules hold)
     g.ln_epoch = h->lnx_epoch;
+    g.ln_one = tune().small_lnx == 1;
     ProfScope ps(h, cls);
     HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LNX>(g, 2, h->stream)));
     return 0;

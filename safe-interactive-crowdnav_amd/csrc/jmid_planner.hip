@@ -40,8 +40,7 @@ struct StepBuffers {
     size_t vt_elems;
     int attn_nsplit;          // split-KV factor of the attention launch (1 = off)
     float *Opart, *MLpart;
-    unsigned* ln_cnt;         // arrival counters of the small-launch GEMM + LayerNorm (gemm_small.hpp, OUT_LN): kLnCounters words
-    unsigned long long* ln_xchg;   // ... and, behind them, the exchange granules of OUT_LNX (kLnxWords words)
+    unsigned long long* ln_xchg;   // exchange granules of the small-launch GEMM + LayerNorm (gemm_small.hpp, OUT_LNX): kLnxWords words, zeroed once per call
 };
 
 half_t* take_half(Carver& c, size_t n) { return reinterpret_cast<half_t*>(c.take((n + 1) / 2)); }
@@ -63,9 +62,8 @@ size_t step_ws_floats(const jmid_ctx* h, size_t Mc, int precision, const SeqGeom
     Carver c(base);
     StepBuffers s{};
     s.X = c.take(Mc * h->d);
-    s.Y = c.take((Mc + 63) / 64 * 64 * h->d);     // (whole 64-row tiles: the hand-off layout of gemm_small.hpp's LayerNorm tail)
-    s.ln_cnt = reinterpret_cast<unsigned*>(c.take(kLnCounters + kLnxWords));
-    s.ln_xchg = reinterpret_cast<unsigned long long*>(s.ln_cnt + kLnCounters);
+    s.Y = c.take((Mc + 63) / 64 * 64 * h->d);     // (whole 64-row tiles)
+    s.ln_xchg = reinterpret_cast<unsigned long long*>(c.take(kLnxWords));
     s.Y4 = c.take(Mc * h->dlow);
     if (precision == JMID_PREC_F32) {
         s.QKV = c.take(Mc * 3 * h->d);
@@ -225,10 +223,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             // per launch: 36.8 vs 39.1 ms per 12-episode call; 5: 33.8 vs 33.5, 4: 29.6 vs 28.8)
             // (enough row tiles to occupy the chip); otherwise GEMM -> fp32 Y -> add_ln.  Both give bit-identical rows.
             const bool ln_fused = d == GLN_BN && tune().ln_fuse != 2 && (tune().ln_fuse == 1 || M >= 7168);
-            // small launches (one scene ... a few): GEMM + residual + LayerNorm in one kernel, the LayerNorm by the last-arriving
-            // workgroup of each 64-row tile (gemm_small.hpp; bit-identical to the pair below it replaces, two launches per layer fewer).
-            // F16MX: only with the byte lo plane of the second-generation LayerNorm (mxv2), whose order the tail reproduces
-            const bool ln_small = d == GLN_BN && (!h->mx || mxv2);
+            // one scene in F16MX (one chunk of <= 2048 rows, byte lo plane of the second-generation LayerNorm: mxv2): GEMM + residual +
+            // LayerNorm in ONE small launch whose workgroups exchange the row statistics (gemm_small.hpp, OUT_LNX; two launches per
+            // layer fewer); a handle on which such a kernel ever gave up waiting (lnx_off) stays on the pair
             if (ln_fused && mxv2) {
                 GemmLn2Args g2{sb.Ah, h->w16[p + ".self_attn.out_proj.weight"].hi, h->w8[p + ".self_attn.out_proj.weight"].p,
                                W(h, p + ".self_attn.out_proj.bias"), W(h, p + ".norm1.weight"), W(h, p + ".norm1.bias"), sb.Xh, Xl8,
@@ -250,13 +247,6 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
                 set_w8(h, g, p + ".self_attn.out_proj.weight");
                 g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
-#ifdef JMID_EXPERIMENTS
-                if (ln_small && small_ln_fits(M, g.K)) {
-                    g.ln_gamma = W(h, p + ".norm1.weight"); g.ln_beta = W(h, p + ".norm1.bias"); g.ln_xh = sb.Xh; g.ln_xl = sb.Xl;
-                    g.ln_xl8 = Xl8; g.ln_cnt = sb.ln_cnt; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
-                    if (int rc = run_gemm_ln_small(h, KC_GEMM_OUT, g)) return rc;
-                } else
-#endif
                 if (mxv2 && !h->lnx_off && small_lnx_fits(M, g.K)) {
                     g.ln_gamma = W(h, p + ".norm1.weight"); g.ln_beta = W(h, p + ".norm1.bias"); g.ln_xh = sb.Xh; g.ln_xl = nullptr;
                     g.ln_xl8 = Xl8; g.ln_xchg = sb.ln_xchg; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
@@ -296,13 +286,6 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.H1h; g.Alo = sb.H1l; g.Whi = w2.hi; g.Wlo = w2.lo;
                 set_w8(h, g, p + ".linear2.weight");
                 g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
-#ifdef JMID_EXPERIMENTS
-                if (ln_small && small_ln_fits(M, g.K)) {
-                    g.ln_gamma = W(h, p + ".norm2.weight"); g.ln_beta = W(h, p + ".norm2.bias"); g.ln_xh = sb.Xh; g.ln_xl = sb.Xl;
-                    g.ln_xl8 = Xl8; g.ln_cnt = sb.ln_cnt; g.ln_eps = 1e-5f; g.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
-                    if (int rc = run_gemm_ln_small(h, KC_GEMM_FF2, g)) return rc;
-                } else
-#endif
                 if (mxv2 && !h->lnx_off && small_lnx_fits(M, g.K)) {
                     g.ln_gamma = W(h, p + ".norm2.weight"); g.ln_beta = W(h, p + ".norm2.bias"); g.ln_xh = sb.Xh; g.ln_xl = nullptr;
                     g.ln_xl8 = Xl8; g.ln_xchg = sb.ln_xchg; g.ln_eps = 1e-5f; g.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
@@ -536,9 +519,9 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     // the small-launch GEMMs (gemm_small.hpp: one workgroup per CU, most of its LDS) only while one chunk is in flight
     struct SmallNow {
         Tuning& t;
-        SmallNow(Tuning& t_, int v) : t(t_) { t.small_now = v; }
-        ~SmallNow() { t.small_now = 1; }
-    } small_now_scope(h->tune, lanes == 1 || h->tune.small_lanes == 1 ? 1 : h->tune.small_lanes == 2 ? 2 : 0);
+        SmallNow(Tuning& t_, int v, int one) : t(t_) { t.small_now = v; t.one_chunk = one; }
+        ~SmallNow() { t.small_now = 1; t.one_chunk = 1; }
+    } small_now_scope(h->tune, lanes == 1 || h->tune.small_lanes == 1 ? 1 : h->tune.small_lanes == 2 ? 2 : 0, nchunks == 1 && tune().graph != 1);      // (a captured loop would replay the launch tags of OUT_LNX)
     const size_t lane_floats = step_ws_floats(h, Mc, precision, sg_full, ns_call, nullptr, nullptr);
     const size_t need = io_off + lanes * lane_floats;
     if (int rc = ensure_arena(h, need)) return rc;
@@ -559,7 +542,7 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
     const StepBuffers& sb = sbs[0];
     if (precision != JMID_PREC_F32) {
         HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
-        for (int l = 0; l < lanes; ++l) HIPCHK(h, hipMemsetAsync(sbs[l].ln_cnt, 0, (kLnCounters + kLnxWords) * sizeof(unsigned), h->stream));
+        for (int l = 0; l < lanes; ++l) HIPCHK(h, hipMemsetAsync(sbs[l].ln_xchg, 0, kLnxWords * sizeof(unsigned), h->stream));
         for (int l = 0; l < lanes; ++l)
             if (sbs[l].Vth && sg_full.Spad != sg_full.S) {  // padding keys of V^T must be finite (they meet P = 0)
                 HIPCHK(h, hipMemsetAsync(sbs[l].Vth, 0, sbs[l].vt_elems * sizeof(half_t), h->stream));

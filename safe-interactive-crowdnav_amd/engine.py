@@ -338,8 +338,8 @@ class JmidEngine:
 
     def dbg_gemm_ln_mx(self, A: np.ndarray, Wt: np.ndarray, bias, gamma, beta, X: np.ndarray, fused) -> np.ndarray:
         """LayerNorm(X + A Wt^T + bias) with the F16MX second-generation kernels (d_model 512): fused = 1 the row-complete kernel,
-        0 the GEMM + add_ln2 pair, 2 the small-launch GEMM whose last workgroup per row tile normalises, 3 the small-launch GEMM
-        whose workgroups exchange the row statistics and normalise their own columns (gemm_small.hpp)."""
+        0 the GEMM + add_ln2 pair, 3 the small-launch GEMM whose workgroups exchange the row statistics and normalise their own
+        columns (gemm_small.hpp, OUT_LNX)."""
         A = np.ascontiguousarray(A, np.float32)
         Wt = np.ascontiguousarray(Wt, np.float32)
         X = np.array(X, np.float32, order="C", copy=True)

@@ -151,7 +151,7 @@ needs_experiments = pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="the 
 def test_small_launch_gemm_with_statistics_exchange_equals_its_unfused_pair(M, K):
     """gemm_small_kernel<.., OUT_LNX> (one scene in F16MX: out_proj / linear2 + residual + LayerNorm in ONE launch - the eight
     workgroups of a 64-row tile exchange the row statistics as {value, launch tag} granules and normalise their own 64 columns)
-    against float64 and bit for bit against the GEMM + add_ln2 pair; repeated, so that a stale granule (the buffer is reused
+    against float64 and - in its two-exchange form - bit for bit against the GEMM + add_ln2 pair; repeated, so that a stale granule (the buffer is reused
     launch after launch, only the tag moves) or an unlucky arrival order would show - every word is compared."""
     eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
     try:
@@ -163,36 +163,18 @@ def test_small_launch_gemm_with_statistics_exchange_equals_its_unfused_pair(M, K
         pair = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=0)
         row_complete = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=1)
         np.testing.assert_array_equal(row_complete, pair)
+        eng.set_tuning("small_lnx", 0)           # what ships: two exchanges (sums, then squared deviations from the row mean), the canonical order
         for _ in range(8):
             fused = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=3)
             np.testing.assert_array_equal(fused, pair)
-    finally:
-        eng.close()
-    v = X.astype(np.float64) + A.astype(np.float64) @ W.astype(np.float64).T + b
-    ref = (v - v.mean(1, keepdims=True)) / np.sqrt(v.var(1, keepdims=True) + 1e-5) * g + t
-    assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
-
-
-@needs_experiments
-@pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128)])
-def test_small_launch_gemm_with_layernorm_tail_equals_its_unfused_pair(M, K):
-    """gemm_small_kernel<.., OUT_LN> (one scene: out_proj / linear2 + residual + LayerNorm in ONE launch, the rows normalised by
-    the last-arriving workgroup of each 64-row tile after an sc1 hand-off) against float64 and bit for bit against the GEMM +
-    add_ln2 pair - repeated, so that an unlucky arrival order or a stale line would show (every word is compared)."""
-    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True, lib_path=EXP_LIB)
-    try:
-        rng = np.random.default_rng(M + K)
-        A = rng.standard_normal((M, K)).astype(np.float32) * np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
-        W = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32) * np.linspace(1.5, 0.5, 512, dtype=np.float32)[:, None]
-        b, g, t = (rng.standard_normal(512).astype(np.float32) for _ in range(3))
-        X = rng.standard_normal((M, 512)).astype(np.float32) * 2.0
-        eng.set_tuning("gemm_small", 1)
-        pair = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=0)          # round-3 tile shapes + add_ln2
-        eng.set_tuning("gemm_small", 0)
-        eng.set_tuning("small_ln", 1)                                 # (opt-in: measured slower than the pair for one scene)
-        for _ in range(5):
-            fused = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=2)
-            np.testing.assert_array_equal(fused, pair)
+        eng.set_tuning("small_lnx", 1)           # diagnostics: ONE exchange, the variance merged from the blocks' (mean, M2) pairs -
+        one = [eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=3) for _ in range(8)]      # deterministic, but another summation order:
+        for o in one[1:]:
+            np.testing.assert_array_equal(o, one[0])
+        # ... a last-bit difference of a row statistic can move an output across an fp16 rounding boundary of its hi plane; hi + bf8(lo)
+        # then differ by at most one step of the lo image (2^-14 of the value)
+        assert np.abs(one[0] - pair).max() <= 2.5e-4 * max(1.0, np.abs(pair).max())
+        assert (one[0] != pair).mean() <= 0.02
     finally:
         eng.close()
     v = X.astype(np.float64) + A.astype(np.float64) @ W.astype(np.float64).T + b

@@ -408,22 +408,27 @@ def test_split_modes_hold_parity_when_attention_is_peaked():
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz"])
 def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
     """One scene in F16MX (d_model 512): out_proj / linear2 + residual + LayerNorm run as ONE small launch whose workgroups exchange
-    the row statistics (gemm_small.hpp, OUT_LNX; six launches less per denoise step).  Same bits as GEMM + add_ln2 over a whole
-    50-step loop, repeated on one handle (the exchange buffer is reused by every launch of every call); no workgroup ever gives up
+    the row statistics (gemm_small.hpp, OUT_LNX; six launches less per denoise step).  With two exchanges per LayerNorm (what ships) the same
+    bits as GEMM + add_ln2 over a whole 50-step loop; with one (a diagnostics knob) deterministic and within rounding of them; repeated on one handle (the exchange buffer is reused by every launch of every call); no workgroup ever gives up
     waiting (that would come back as JMID_ERANGE and switch the handle to the pair)."""
     z = np.load(os.path.join(GOLDEN, case))
     eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
     eng.set_step(int(z["step"]), "ddim")
     out = []
     try:
-        for knob in (2, 0, 0, 0):
+        for knob in (2, 0, 0, 1, 1, 1):
             eng.set_tuning("small_lnx", knob)
             out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16mx", want_pos=False)[0][0])
     finally:
         eng.set_tuning("small_lnx", 0)
-    for o in out[1:]:
-        np.testing.assert_array_equal(o, out[0])
-    assert ade(out[1], z["vel"]) <= ADE_GATE
+    np.testing.assert_array_equal(out[1], out[0])          # two exchanges per LayerNorm, the canonical summation order: the pair's bits
+    np.testing.assert_array_equal(out[2], out[0])
+    np.testing.assert_array_equal(out[4], out[3])          # the diagnostics variant with ONE exchange: deterministic ...
+    np.testing.assert_array_equal(out[5], out[3])
+    # ... last-bit differences of the row statistics - which 50 steps of a mode that rounds every activation to fp16 carry to ~1e-5 m,
+    # the distance between any two summation orders in this mode (f16mx against the oracle: 5e-6 ... 1.2e-5 m)
+    assert ade(out[3], out[0]) <= 3e-5, ade(out[3], out[0])
+    assert ade(out[3], z["vel"]) <= ADE_GATE
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
