@@ -90,6 +90,7 @@ struct AttnHArgs {
     // them 64-bit: 1.8 us of a one-scene wave's 10 us).  0 = not filled in (probes that launch the kernel directly): divide.
     unsigned mq = 0, ms = 0, mh = 0;
     int nseq = 0;
+    int skip_combine = 0;        // split-KV launches: the partial outputs are merged by the consumer (gemm_small.hpp, lnx_combine), not by attn_combine_kernel
 };
 
 
@@ -988,7 +989,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
         } else {
             launch_attn_dma<false, false, false, false>(a, grid1, nqt, st);
         }
-        if (a.nsplit > 1) {
+        if (a.nsplit > 1 && !a.skip_combine) {
             const size_t Mtot = (size_t)nseq * a.S;
             const int blocks = (int)std::min<size_t>((Mtot * (a.d / 4) + 255) / 256, 2048);
             hipLaunchKernelGGL(attn_combine_kernel, dim3(blocks), dim3(256), bystander_lds(attn_combine_kernel), st, a, Mtot, 128);

@@ -127,6 +127,13 @@ struct GemmHArgs {
     unsigned long long* ln_xchg;   // [2 kinds][ceil(M / 64)][8 column tiles][64 rows] granules {fp32 partial, launch tag}, zeroed once per call
     unsigned ln_epoch;             // this launch's tag: never 0, never repeated within a call
     int ln_one;                    // one exchange (sum + squared deviations from the block's own mean, merged) instead of two in the canonical order
+    // OUT_LNX of the attention out-projection after a split-KV attention launch: the merge of the partial outputs (attn_combine_kernel's
+    // arithmetic) happens in THIS launch - every workgroup merges its 64 rows x 64 columns of the A operand, publishes a flag, waits
+    // for the seven others of its row tile and only then starts its K loop
+    const float* cmb_O;            // [cmb_ns][cmb_Mtot][d] fp32 partial outputs, or null: A is ready
+    const float* cmb_ML;           // [cmb_ns][cmb_Mtot][nhead][2] their (max, sum)
+    int cmb_ns, cmb_nhead;
+    unsigned cmb_Mtot;
 };
 
 constexpr int GEMMH_BK = 32;

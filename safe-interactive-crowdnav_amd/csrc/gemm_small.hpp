@@ -89,7 +89,8 @@ constexpr int SM_STG_LD = 68;                              // floats per row of 
 // partners resident: <= 256 tiles, nothing else in flight on the handle); the polls are BOUNDED - a workgroup that does not see a
 // partner within ~10^5 polls sets bit 1 of the range flag and leaves, and the host drops the fused path for the handle.
 constexpr int SM_LNX_POLLS = 1 << 17;
-constexpr size_t SM_LNX_GRANULES = size_t(2) * 32 * 8 * 64;     // per step workspace: two statistics x 32 row tiles x 8 blocks x 64 rows
+constexpr size_t SM_LNX_STATS = size_t(2) * 32 * 8 * 64;        // per step workspace: two statistics x 32 row tiles x 8 blocks x 64 rows ...
+constexpr size_t SM_LNX_GRANULES = SM_LNX_STATS + 32 * 8;       // ... + one flag per block of the A operand (lnx_combine)
 
 __device__ __forceinline__ void lnx_publish(unsigned long long* slot, float v, unsigned tag) {
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -125,6 +126,79 @@ __device__ __forceinline__ bool lnx_gather(const unsigned long long* slots_s, co
         --budget;
     }
     return !(n0 || n1 || m0 || m1);
+}
+
+// The split-KV merge in front of the out-projection's K loop (GemmHArgs::cmb_*): the workgroup of tile (tm, c) merges rows m0 .. m0 + 63,
+// columns 64 c .. 64 c + 63 of the attention output - attn_combine_kernel's operations in its order: the same bits - and writes the fp16
+// plane the K loops read (write-through), then tells the seven other workgroups of its row tile and waits for theirs: a flag granule
+// {launch tag} per block behind the statistics granules.  The L2 of an XCD holds no line of the plane when the launch begins (a kernel
+// boundary invalidates it) and nobody reads the plane before the flags are up, so the K loop's ordinary copies see the merged rows.
+// head_dim 128, at most 8 partials, F16X2 / F16MX (one plane of A).
+__device__ __forceinline__ void lnx_combine(const GemmHArgs& g, int tm, int c, int m0, int tid) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const int d = g.K, ns = g.cmb_ns;
+    const size_t Mtot = g.cmb_Mtot;
+    half_t* Ohi = const_cast<half_t*>(g.Ahi);
+    f32x2_ ml[4][8];
+    f32x4 p[4][8];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, r = idx >> 4, col = c * 64 + (idx & 15) * 4, h = col >> 7;
+        const int tok = m0 + r < g.M ? m0 + r : g.M - 1;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < ns) {
+                ml[it][i] = *reinterpret_cast<const f32x2_*>(g.cmb_ML + (((size_t)i * Mtot + tok) * g.cmb_nhead + h) * 2);
+                p[it][i] = *reinterpret_cast<const f32x4*>(g.cmb_O + ((size_t)i * Mtot + tok) * d + col);
+            }
+    }
+    bool overflow = false;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, r = idx >> 4, col = c * 64 + (idx & 15) * 4;
+        float M = -INFINITY, L = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < ns) M = fmaxf(M, ml[it][i][0]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < ns) {
+                const float w = __builtin_amdgcn_exp2f(ml[it][i][0] - M);
+                L = fmaf(w, ml[it][i][1], L);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaf(w, p[it][i][e], o[e]);
+            }
+        const float inv = 1.0f / L;
+        f16x4 vh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = o[e] * inv;
+            half_t hh, ll;
+            split_f32(v, hh, ll);
+            overflow |= m0 + r < g.M && !(fabsf(v) <= kHalfMax);
+            vh[e] = hh;
+        }
+        if (m0 + r < g.M)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(Ohi + blk_index(m0 + r, col, d)), __builtin_bit_cast(unsigned long long, vh),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (overflow) atomicOr(g.range_flag, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of the block is out ...
+    __syncthreads();                                       // ... and the workgroup's
+    unsigned long long* flags = g.ln_xchg + SM_LNX_STATS + (size_t)tm * 8;
+    if (tid == 0) __hip_atomic_store(flags + c, (unsigned long long)g.ln_epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 8 && tid != c) {
+        int budget = SM_LNX_POLLS;
+        bool need = true;
+        while (need && budget > 0) {
+            need = (unsigned)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != g.ln_epoch;
+            if (need) __builtin_amdgcn_s_sleep(1);
+            --budget;
+        }
+        if (need) atomicOr(g.range_flag, 2);               // a partner never showed up: the call is repeated without this kernel
+    }
+    __syncthreads();
 }
 
 // what the tail wants from memory that does not depend on the product - the residual rows (planes the PREVIOUS launch wrote: an
@@ -527,6 +601,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
             //  computes them in vector registers altogether, and the K loop's scalar-base copies fail to compile - "illegal VGPR to SGPR copy")
             int m0_v = m0, c_v = tn;
             asm volatile("" : "+v"(m0_v), "+v"(c_v));
+            if (g.cmb_O) lnx_combine(g, tm, tn, m0, tid);
             LnxPre pre;
             lnx_prefetch(g, c_v, m0_v, tid, pre);
             acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
@@ -728,6 +803,11 @@ inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t
             if (wc == 8) return launch_gemm_small_cfg<EPI, OUT, MODE, 4, true>(g, st);
         return launch_gemm_small_cfg<EPI, OUT, MODE, 4>(g, st);
     }
+}
+
+// does the out-projection's OUT_LNX launch also merge the partial outputs of a split-KV attention launch (lnx_combine)?  "small_cmb": 0 on, 2 off
+inline bool small_cmb_fits(int nsplit, int head_dim, int x2) {
+    return tune().small_cmb != 2 && nsplit > 1 && nsplit <= 8 && head_dim == 128 && x2;
 }
 
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch with the statistics exchange (OUT_LNX)?  F16MX at d_model 512,

@@ -180,6 +180,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             const std::string p = "transformer_encoder.layers." + std::to_string(l);
             GemmHArgs g{};
             g.rmap = rm; g.M = M;
+            bool cmb_in_gemm = false;
+            int cmb_ns = 0;
+            size_t cmb_Mtot = 0;
             const HalfPair& win = h->wsplit[p + ".self_attn.in_proj_weight"];
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = win.hi; g.Wlo = win.lo;
             set_w8(h, g, p + ".self_attn.in_proj_weight");
@@ -210,6 +213,13 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 const int ns = sb.attn_nsplit;   // per call, not per chunk (run_network)
                 AttnHArgs aa{sb.Qh, sb.Ql, sb.Kh, sb.Kl, sb.Vth, sb.Vtl, sb.Ah, sb.Al, S, sg.Spad, d, h->nhead,
                              att_scale, h->range_flag, ns, sb.Opart, sb.MLpart, h->x2, k8h, k8l, q8l};
+                // one scene: the partial outputs are merged in front of the out-projection's K loop (gemm_small.hpp, lnx_combine) when
+                // that launch is the one with the LayerNorm inside (the same conditions as below)
+                cmb_in_gemm = mxv2 && !h->lnx_off && !(tune().ln_fuse != 2 && (tune().ln_fuse == 1 || M >= 7168)) && small_lnx_fits(M, d) &&
+                              small_cmb_fits(ns, hd, h->x2);
+                aa.skip_combine = cmb_in_gemm;
+                cmb_ns = ns;
+                cmb_Mtot = (size_t)nseq * S;
                 HIPCHK(h, launch_attn_f16x3(aa, nseq, hd, h->stream));
                 g.K8h = nullptr; g.K8l = nullptr; g.Q8l = nullptr;
             } else {
@@ -247,7 +257,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 g.Ahi = sb.Ah; g.Alo = sb.Al; g.Whi = wout.hi; g.Wlo = wout.lo;
                 set_w8(h, g, p + ".self_attn.out_proj.weight");
                 g.bias = W(h, p + ".self_attn.out_proj.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = d;
+                if (cmb_in_gemm && !(mxv2 && !h->lnx_off && small_lnx_fits(M, g.K))) return fail(h, JMID_EINVAL, "split-KV merge left to a launch that does not exist");
                 if (mxv2 && !h->lnx_off && small_lnx_fits(M, g.K)) {
+                    g.cmb_O = cmb_in_gemm ? sb.Opart : nullptr; g.cmb_ML = sb.MLpart; g.cmb_ns = cmb_ns; g.cmb_nhead = h->nhead; g.cmb_Mtot = (unsigned)cmb_Mtot;
                     g.ln_gamma = W(h, p + ".norm1.weight"); g.ln_beta = W(h, p + ".norm1.bias"); g.ln_xh = sb.Xh; g.ln_xl = nullptr;
                     g.ln_xl8 = Xl8; g.ln_xchg = sb.ln_xchg; g.ln_eps = 1e-5f; g.ln_no_lo = 0;
                     if (int rc = run_gemm_lnx_small(h, KC_GEMM_OUT, g)) return rc;
@@ -287,6 +299,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 set_w8(h, g, p + ".linear2.weight");
                 g.bias = W(h, p + ".linear2.bias"); g.C = sb.Y; g.ldc = d; g.N = d; g.K = ff;
                 if (mxv2 && !h->lnx_off && small_lnx_fits(M, g.K)) {
+                    g.cmb_O = nullptr;
                     g.ln_gamma = W(h, p + ".norm2.weight"); g.ln_beta = W(h, p + ".norm2.bias"); g.ln_xh = sb.Xh; g.ln_xl = nullptr;
                     g.ln_xl8 = Xl8; g.ln_xchg = sb.ln_xchg; g.ln_eps = 1e-5f; g.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
                     if (int rc = run_gemm_lnx_small(h, KC_GEMM_FF2, g)) return rc;

@@ -431,6 +431,29 @@ def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
     assert ade(out[3], z["vel"]) <= ADE_GATE
 
 
+@pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w256_a7k9t24_s10.npz"])
+def test_one_scene_split_kv_merge_inside_the_out_projection_launch_is_bit_identical(case, precision):
+    """One scene: the attention launch splits the key range over several workgroups per query tile; their partial outputs are merged
+    by the workgroups of the out-projection launch in front of their K loops (gemm_small.hpp, lnx_combine: every workgroup its 64 x 64
+    block of the A operand, then a flag per block) instead of by attn_combine_kernel - three launches less per denoise step.  Same
+    operations in the same order: the same bits, call after call on one handle.  (F16X2 has no one-launch GEMM + LayerNorm: its
+    merge stays where it was, and the knob must change nothing.)"""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
+    eng.set_step(int(z["step"]), "ddim")
+    out = []
+    try:
+        for knob in (2, 0, 0, 0, 2):
+            eng.set_tuning("small_cmb", knob)
+            out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False)[0][0])
+    finally:
+        eng.set_tuning("small_cmb", 0)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o, out[0])
+    assert ade(out[1], z["vel"]) <= ADE_GATE
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w32_a5k20t12_s50.npz", "ddpm_jmid_w32_a2k3t4_s10.npz"])
 def test_output_kernel_with_fused_next_embedding_is_bit_identical(case, precision):
