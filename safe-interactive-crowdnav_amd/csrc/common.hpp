@@ -150,6 +150,7 @@ struct Tuning {
     int mx_ln = 0;           // F16MX at d_model 512: 0 = second-generation GEMM + LayerNorm (gemm_ln2_mx.hpp: byte lo plane of the residual stream, two workgroups per CU), 2 = the first generation
     int attn_pf = 0;         // F16MX / F16X2 attention with one plane of P: 2 = fragment reads one step ahead instead of three (A/B; same bits)
     int gemm_small = 0;      // launches of at most one workgroup per CU (gemm_small.hpp): 0 = the deep-ring k64 kernel, 1 = the round-3 tile shapes, 2 = the deep-ring kernel only up to one workgroup per CU
+    int small_mlp = 0;       // linear1 -> ReLU -> linear2 + residual + LayerNorm of a one-scene F16MX call in ONE launch (gemm_small.hpp, gemm_small_mlp_kernel; experiments flavour, measured slower): 1 on, 0 / 2 off (linear1's launch + the OUT_LNX launch)
     int small_cmb = 0;       // the split-KV merge of a one-scene attention launch inside the out-projection's OUT_LNX launch (gemm_small.hpp, lnx_combine): 0 on, 2 off (attn_combine_kernel)
     int small_lnx = 0;       // out_proj / linear2 + residual + LayerNorm of a small F16MX launch in ONE kernel, row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX): 0 on, two exchanges in the canonical summation order (bit-identical to the pair); 1 on, ONE exchange (0.2 ms per one-scene call faster, another summation order: diagnostics); 2 off (GEMM + add_ln2)
     int gemm_pn = 0;         // F16MX large-tile GEMMs: column groups of the XCD tile order (0 / 1 = N fastest over all N-tiles)

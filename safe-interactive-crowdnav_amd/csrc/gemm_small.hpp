@@ -566,6 +566,125 @@ __device__ __forceinline__ void small_qk_staged_store(const GemmHArgs& g, const 
     }
 }
 
+// The OUT_LNX launch of one tile (tm, c): [split-KV merge] -> K loop (transposed: a lane owns token row l31 of its wave's block and
+// four runs of 4 consecutive columns) -> the fp32 rows (accumulator + bias: what the stand-alone GEMM hands add_ln2) staged in LDS, the
+// operand ring's place, in the ownership of the row statistics -> the exchange and the workgroup's own 64 columns (lnx_tail_mx).
+__device__ __forceinline__ void lnx_body(const GemmHArgs& g, unsigned char* lds_raw, int tm, int tn, int tid
+#ifdef JMID_SMALL_TRACE
+                                         , unsigned long long* sm_trace_p
+#endif
+) {
+    const int lane = tid & 63, wid = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid / 2, wc = wid % 2;
+    const int m0 = tm * 64, n0 = tn * 64;
+    // (the tile indices reach the prefetch through an opaque vector copy: with a visible vector use in front of the K loop hipcc
+    //  computes them in vector registers altogether, and the K loop's scalar-base copies fail to compile - "illegal VGPR to SGPR copy")
+    int m0_v = m0, c_v = tn;
+    asm volatile("" : "+v"(m0_v), "+v"(c_v));
+    if (g.cmb_O) lnx_combine(g, tm, tn, m0, tid);
+    LnxPre pre;
+    lnx_prefetch(g, c_v, m0_v, tid, pre);
+    const f32x16 acc = small_kloop<SM_MX, 2, false, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
+    lnx_prefetch_landed(pre);
+    __syncthreads();                                   // everybody is done with the operand ring: it becomes the staging tile
+    float* stg = reinterpret_cast<float*>(lds_raw);
+    {
+        float* sr = stg + (wr * 32 + l31) * SM_STG_LD + wc * 32 + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 32 + 8 * q + 4 * hi);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[4 * q + e], kWInv, bv[e]);
+            *reinterpret_cast<f32x4*>(sr + 8 * q) = o;
+        }
+    }
+    __syncthreads();
+    SM_STAMP(4);
+    lnx_tail_mx(g, pre, stg, stg + 64 * SM_STG_LD, tm, tn, m0, tid);
+    SM_STAMP(5);
+}
+
+#ifdef JMID_EXPERIMENTS
+// ---- linear1 -> ReLU -> linear2 + residual + LayerNorm of one scene in ONE launch (F16MX, d_model 512, ff = 1024).  The seam between the
+// two GEMMs is the one lnx_combine crosses: workgroup (tm, c) first computes the two 64 x 64 blocks 2 c, 2 c + 1 of the hidden rows
+// (linear1's K loop and epilogue: + bias, ReLU, the fp16 plane - the stand-alone launch's operations, the same bits), writes them
+// through, raises its flag, waits for the seven others of its row tile - the 1024 hidden columns of its 64 rows are complete then -
+// and runs linear2's OUT_LNX launch on them (lnx_body).  One launch and one kernel boundary less per layer; what it costs is linear1
+// on 4-wave workgroups with 64-column tiles (two K loops of 512 one after the other, each with its own cold ring) where the stand-alone
+// launch has 8 waves and 128-column tiles - and that is more than the launch saves: bit-identical at the first run, and MEASURED
+// SLOWER (one scene 11.23 against 10.70 ms per 50-step call, profiles/r05_lnx_mlp_single_scene.log).  Experiments flavour, knob
+// "small_mlp" = 1.
+__device__ __forceinline__ void mlp_hidden_block(const GemmHArgs& g1, unsigned char* lds_raw, int tm, int tn1, int m0_v, int tn1_v, int tid
+#ifdef JMID_SMALL_TRACE
+                                                 , unsigned long long* sm_trace_p
+#endif
+) {
+    const int lane = tid & 63, wid = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wr = wid / 2, wc = wid % 2;
+    const f32x16 acc = small_kloop<SM_MX, 2, false, true>(g1, lds_raw, tm, tn1, tid SM_TRACE_ARG);
+    const int row = m0_v + wr * 32 + l31;
+    bool overflow = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = tn1_v * 64 + wc * 32 + 8 * q + 4 * hi;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(g1.bias + col);
+        f16x4 vh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = fmaf(acc[4 * q + e], kWInv, bv[e]);
+            v = v > 0.f ? v : 0.f;
+            half_t hh, ll;
+            split_f32(v, hh, ll);
+            overflow |= row < g1.M && !(fabsf(v) <= kHalfMax);
+            vh[e] = hh;
+        }
+        if (row < g1.M)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(g1.Chi + blk_index(row, col, g1.N)), __builtin_bit_cast(unsigned long long, vh),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (overflow) atomicOr(g1.range_flag, 1);
+}
+
+static __global__ __launch_bounds__(256, 1) void gemm_small_mlp_kernel(GemmHArgs g1, GemmHArgs g2, int ntm, int gw, unsigned mper, unsigned mgw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    args_now_each(g1, g2, ntm, gw, mper, mgw);
+#ifdef JMID_SMALL_TRACE
+    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;
+    sm_trace_p = reinterpret_cast<unsigned long long*>(pin_uniform_rfl(reinterpret_cast<unsigned long long>(sm_trace_p)));
+#endif
+    SM_STAMP(0);
+    const int tid = threadIdx.x;
+    const int nwg = gridDim.x, b = blockIdx.x;       // the tile order of gemm_small_kernel for linear2's 64 x 64 tiles (ntn = 8)
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
+    const int s = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    const int per = ntm * gw, cg = fast_div(s, per, mper), rem = s - cg * per;
+    const int tm = fast_div(rem, gw, mgw), tn = cg * gw + (rem - tm * gw);
+    int m0_v = tm * 64, tn_v = tn;
+    asm volatile("" : "+v"(m0_v), "+v"(tn_v));       // (vector uses of the tile indices through an opaque copy: lnx_body)
+    mlp_hidden_block(g1, lds_raw, tm, 2 * tn, m0_v, 2 * tn_v, tid SM_TRACE_ARG);
+    __syncthreads();                                   // (the ring is primed again by the next K loop)
+    mlp_hidden_block(g1, lds_raw, tm, 2 * tn + 1, m0_v, 2 * tn_v + 1, tid SM_TRACE_ARG);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of the two blocks is out ...
+    __syncthreads();                                       // ... and the workgroup's (and the ring is free)
+    unsigned long long* flags = g2.ln_xchg + SM_LNX_STATS + (size_t)tm * 8;
+    if (tid == 0) __hip_atomic_store(flags + tn, (unsigned long long)g2.ln_epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 8 && tid != tn_v) {
+        int budget = SM_LNX_POLLS;
+        bool need = true;
+        while (need && budget > 0) {
+            need = (unsigned)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != g2.ln_epoch;
+            if (need) __builtin_amdgcn_s_sleep(1);
+            --budget;
+        }
+        if (need) atomicOr(g2.range_flag, 2);
+    }
+    __syncthreads();
+    lnx_body(g2, lds_raw, tm, tn, tid SM_TRACE_ARG);
+}
+
+#endif  // JMID_EXPERIMENTS
+
 template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
 __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags, unsigned mper, unsigned mgw) {
     using C = SmCfg<MODE, WC, TWO>;
@@ -597,31 +716,7 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
         // of the row statistics; then the exchange and the workgroup's own 64 columns (lnx_tail_mx)
         static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
         if constexpr (MODE == SM_MX && !TWO) {
-            // (the tile indices reach the prefetch through an opaque vector copy: with a visible vector use in front of the K loop hipcc
-            //  computes them in vector registers altogether, and the K loop's scalar-base copies fail to compile - "illegal VGPR to SGPR copy")
-            int m0_v = m0, c_v = tn;
-            asm volatile("" : "+v"(m0_v), "+v"(c_v));
-            if (g.cmb_O) lnx_combine(g, tm, tn, m0, tid);
-            LnxPre pre;
-            lnx_prefetch(g, c_v, m0_v, tid, pre);
-            acc[0][0] = small_kloop<MODE, WC, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
-            lnx_prefetch_landed(pre);
-            __syncthreads();                                   // everybody is done with the operand ring: it becomes the staging tile
-            float* stg = reinterpret_cast<float*>(lds_raw);
-            {
-                float* sr = stg + (wr * 32 + l31) * SM_STG_LD + wc * 32 + 4 * hi;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n0 + wc * 32 + 8 * q + 4 * hi);
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaf(acc[0][0][4 * q + e], kWInv, bv[e]);
-                    *reinterpret_cast<f32x4*>(sr + 8 * q) = o;
-                }
-            }
-            __syncthreads();
-            SM_STAMP(4);
-            lnx_tail_mx(g, pre, stg, stg + 64 * SM_STG_LD, tm, tn, m0, tid);
+            lnx_body(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
             SM_STAMP(5);
         }
         return;
@@ -807,8 +902,27 @@ inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t
 
 // does the out-projection's OUT_LNX launch also merge the partial outputs of a split-KV attention launch (lnx_combine)?  "small_cmb": 0 on, 2 off
 inline bool small_cmb_fits(int nsplit, int head_dim, int x2) {
-    return tune().small_cmb != 2 && nsplit > 1 && nsplit <= 8 && head_dim == 128 && x2;
+    return tune().small_cmb != 2 && tune().attn_h_variant != 1 && nsplit > 1 && nsplit <= 8 && head_dim == 128 && x2;      // (attn_h_variant 1: the register-staged kernel, which does not split)
 }
+
+#ifdef JMID_EXPERIMENTS
+// does the MLP of a layer (linear1 -> ReLU -> linear2 + residual + LayerNorm) run as ONE small launch?  Where linear2 takes OUT_LNX, with
+// ff = 2 d_model.  "small_mlp": 1 on (experiments flavour; measured slower), 0 / 2 off
+inline bool small_mlp_fits(int d_model, int ff) { return tune().small_mlp == 1 && d_model == GLN_BN && ff == 2 * GLN_BN; }
+
+inline hipError_t launch_gemm_small_mlp(const GemmHArgs& g1, const GemmHArgs& g2, hipStream_t st) {
+    using C = SmCfg<SM_MX, 2>;
+    const int ntm = (g2.M + 63) / 64, ntn = 8;
+    static DevSeen attr_seen;
+    if (auto once_ = first_use_on_device(attr_seen))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
+    const int pn = tune().small_pn > 0 ? (ntn % tune().small_pn == 0 ? tune().small_pn : 1) : small_pick_groups(g2, ntn, 3.0, 2.0);
+    const int gw = ntn / pn;
+    hipLaunchKernelGGL(gemm_small_mlp_kernel, dim3(ntm * ntn), dim3(256), C::LDS_BYTES, st, g1, g2, ntm, gw,
+                       fast_div_magic(ntm * gw, (unsigned long long)ntm * ntn), fast_div_magic(gw, (unsigned long long)ntm * ntn));
+    return hipGetLastError();
+}
+#endif  // JMID_EXPERIMENTS
 
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch with the statistics exchange (OUT_LNX)?  F16MX at d_model 512,
 // at most 256 tiles of 64 x 64 with nothing else in flight on the handle (the waiting workgroups need their partners resident), at

@@ -450,6 +450,9 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
         {"small_lanes", &Tuning::small_lanes, 0, 2},
+#ifdef JMID_EXPERIMENTS
+        {"small_mlp", &Tuning::small_mlp, 0, 2},               // 1: linear1 inside linear2's one-launch GEMM + LayerNorm (measured slower)
+#endif
         {"small_cmb", &Tuning::small_cmb, 0, 2},               // 2: attn_combine_kernel instead of the split-KV merge inside the out-projection's one-launch GEMM + LayerNorm
         {"small_lnx", &Tuning::small_lnx, 0, 2},               // the one-launch GEMM + LayerNorm with the statistics exchange: 0 two exchanges (bit-identical), 1 one exchange, 2 off (GEMM + add_ln2)
 #ifdef JMID_EXPERIMENTS

@@ -275,6 +275,24 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w1.hi; g.Wlo = w1.lo;
             set_w8(h, g, p + ".linear1.weight");
             g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
+#ifdef JMID_EXPERIMENTS
+            // one scene in F16MX: the whole MLP in ONE launch (gemm_small.hpp, gemm_small_mlp_kernel) where linear2 would take the
+            // one-launch GEMM + LayerNorm (experiment "small_mlp" = 1: bit-identical, measured slower)
+            const bool mlp_one = mxv2 && !ln_fused && !h->lnx_off && small_lnx_fits(M, ff) && small_mlp_fits(d, ff) && g.W8;
+            if (mlp_one) {
+                GemmHArgs g2 = g;
+                const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
+                g2.Ahi = sb.H1h; g2.Alo = sb.H1l; g2.Whi = w2.hi; g2.Wlo = w2.lo;
+                set_w8(h, g2, p + ".linear2.weight");
+                g2.bias = W(h, p + ".linear2.bias"); g2.C = sb.Y; g2.ldc = d; g2.N = d; g2.K = ff;
+                g2.cmb_O = nullptr;
+                g2.ln_gamma = W(h, p + ".norm2.weight"); g2.ln_beta = W(h, p + ".norm2.bias"); g2.ln_xh = sb.Xh; g2.ln_xl = nullptr;
+                g2.ln_xl8 = Xl8; g2.ln_xchg = sb.ln_xchg; g2.ln_eps = 1e-5f; g2.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
+                if (!g2.W8) return fail(h, JMID_EINVAL, "linear2 has no fp8 image");
+                if (int rc = run_gemm_mlp_small(h, KC_GEMM_FF2, g, g2)) return rc;
+                continue;
+            }
+#endif
             if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
             if (ln_fused && mxv2) {
                 GemmLn2Args g2{sb.H1h, h->w16[p + ".linear2.weight"].hi, h->w8[p + ".linear2.weight"].p, W(h, p + ".linear2.bias"),

@@ -431,6 +431,30 @@ def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
     assert ade(out[3], z["vel"]) <= ADE_GATE
 
 
+@needs_experiments
+@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w256_a7k9t24_s10.npz", "net_imid_w256_a5k20t12_s50.npz",
+                                  "net_jmid_w256_a2k3t4_s2.npz"])
+def test_one_scene_mlp_in_one_launch_is_bit_identical(case):
+    """One scene in F16MX: linear1 -> ReLU -> linear2 + residual + LayerNorm as ONE launch (gemm_small.hpp, gemm_small_mlp_kernel: every
+    workgroup two 64 x 64 blocks of the hidden rows, written through, a flag, then linear2's one-launch GEMM + LayerNorm on the complete
+    rows) against linear1's own launch followed by that launch: the same operations per element, the same bits - over whole denoise
+    loops, call after call on one handle, also when the rows end inside a 64-row tile (M = 24: one partial tile; M = 1512).
+    An experiment (knob small_mlp = 1, experiments flavour): measured slower - linear1 on 4-wave workgroups, two cold K loops in a row."""
+    z = np.load(os.path.join(GOLDEN, case))
+    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]), "exp")
+    eng.set_step(int(z["step"]), "ddim")
+    out = []
+    try:
+        for knob in (0, 1, 1, 1, 0):
+            eng.set_tuning("small_mlp", knob)
+            out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16mx", want_pos=False)[0][0])
+    finally:
+        eng.set_tuning("small_mlp", 0)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o, out[0])
+    assert ade(out[1], z["vel"]) <= ADE_GATE
+
+
 @pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w256_a7k9t24_s10.npz"])
 def test_one_scene_split_kv_merge_inside_the_out_projection_launch_is_bit_identical(case, precision):
@@ -649,7 +673,7 @@ def test_restructured_attention_kernels_equal_the_32_key_kernel(E, A, K, T, knob
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
                ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
-               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,))]
+               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (1, 2)), ("small_cmb", (2,))]
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)
