@@ -27,7 +27,8 @@ RNG contract (``rng_compat``): ``x_T`` is always the first draw of torch's CPU d
 (``MID/models/diffusion.py:499``).  The reference also draws one (unused, DDIM) ``randn_like(x_T)`` per reverse step
 (``:509``) on the device ``x_T`` was moved to: the CPU generator in a CPU-only run (what the golden captures are),
 the CUDA generator on a GPU host (``MID/mid.py:91``).  ``rng_compat="cpu"`` consumes those draws from the CPU
-generator, ``"cuda"`` from the device generator (the CPU generator then advances by ``x_T`` only), and the default
+generator, ``"cuda"`` from the device generator (the CPU generator then advances by ``x_T`` only; the device generator is
+moved by what the draws would consume without launching them, ``advance_cuda_generator``), and the default
 ``"auto"`` does what the reference itself would do on this host (``"cuda"`` iff ``torch.cuda.is_available()``).
 
 Differences from the reference that a caller can observe:
@@ -65,6 +66,32 @@ ERANGE_FALLBACKS = 0            # calls of this process that were repeated in "f
 SELF_CHECK_DOWNGRADES = 0       # instances whose opt-in precision was replaced by "f16x3" by the first-call self check
 # what HumanTrajectoryForecasterSim's keyword arguments default to (safe_interactive_crowdnav_amd.install(**defaults) edits it)
 DEFAULTS = {"device_id": 0, "precision": "f16x3", "rng_compat": "auto", "self_check": False, "device_topk": True}
+
+
+_PHILOX_STEP: Dict[Tuple[int, Tuple[int, ...]], int] = {}     # (device, shape) -> what one randn_like of that shape adds to the Philox offset
+
+
+def advance_cuda_generator(device_id: int, shape: Tuple[int, ...], n: int) -> None:
+    """Leave device ``device_id``'s default generator where ``n`` successive ``torch.randn_like(z)`` (z fp32 of ``shape`` on that
+    device) leave it - the reference's unused per-step draws (``MID/models/diffusion.py:509``) - without launching them: a CUDA
+    generator is (seed, Philox offset), and a draw of a given shape adds a fixed amount to the offset.  The first call for a
+    (device, shape) makes ONE real draw to learn that amount; 49 launches per cfg2 call (0.2 ms of host time) otherwise."""
+    if n <= 0:
+        return
+    gen = torch.cuda.default_generators[device_id] if len(torch.cuda.default_generators) > device_id else None
+    if gen is None:                               # (CUDA not initialised yet: the first tensor on the device does it)
+        torch.empty(1, device=f"cuda:{device_id}")
+        gen = torch.cuda.default_generators[device_id]
+    key = (int(device_id), tuple(int(v) for v in shape))
+    step = _PHILOX_STEP.get(key)
+    if step is None:
+        before = gen.get_offset()
+        torch.randn(key[1], device=f"cuda:{device_id}")
+        step = gen.get_offset() - before
+        _PHILOX_STEP[key] = step
+        n -= 1
+    if n > 0:
+        gen.set_offset(gen.get_offset() + n * step)
 
 
 def load_weights(model_path: str, dims: NetDims) -> JMIDWeights:
@@ -249,10 +276,12 @@ class HumanTrajectoryForecasterSim(ForecasterSimSuper):
         # reference (unused by DDIM) comes from the generator of the device the reference would run on
         x_T = torch.randn([K * A, H, 2])
         stride = int(100 / self.step_size)
-        z_like = x_T if self.rng_compat == "cpu" else torch.empty_like(x_T, device=f"cuda:{self.engine.device_id}")
-        for t in range(100, 0, -stride):
-            if t > 1:
-                torch.randn_like(z_like)
+        n_z = sum(1 for t in range(100, 0, -stride) if t > 1)
+        if self.rng_compat == "cpu":
+            for _ in range(n_z):
+                torch.randn_like(x_T)
+        else:
+            advance_cuda_generator(self.engine.device_id, tuple(x_T.shape), n_z)
         t1 = time.perf_counter()
         with self._engine_lock:               # the engine is shared between forecaster instances and not re-entrant
             if self.engine.step != self.step_size or self.engine.sampling != "ddim":

@@ -152,28 +152,34 @@ def build_scene(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float, ho
     ids_in_all = track_ids[in_mask]
     ids_out_all = track_ids[~in_mask]
 
-    def node_state(xy):                                                        # [F, 2] -> [F, 6]
-        v = derivative_of(xy, dt)                                              # both coordinates at once (element-wise: same values)
-        return np.concatenate([xy, v, derivative_of(v, dt)], axis=1)
-
-    # scene nodes in track-id order (robot first when it is in the cluster)
+    # scene nodes in track-id order (robot first when it is in the cluster); node state [pos, vel, acc] by first differences for all
+    # of them at once (element-wise, so the values derivative_of gives per coordinate)
     node_ids = list(ids_in_all)
-    states = [node_state(robot_xy if i == ROBOT_ID else human_xy[:, i]) for i in node_ids]
-    types = np.array([TYPE_VALUE_ROBOT if i == ROBOT_ID else TYPE_VALUE_PED for i in node_ids])
     n = len(node_ids)
-    S = np.stack(states, axis=0) if n else np.zeros((0, F, 6))                 # [n, F, 6]
+    pos_all = np.concatenate([robot_xy[:, None, :], human_xy], axis=1)         # [F, N+1, 2], robot first like track_ids
+
+    def deriv(a):                                                              # [n, F, 2], differences along the frames
+        if F < 2:
+            return np.zeros_like(a)
+        d = np.empty_like(a)
+        np.subtract(a[:, 1:], a[:, :-1], out=d[:, 1:])
+        d[:, 0] = d[:, 1]
+        return d / dt
+
+    P = np.ascontiguousarray(pos_all[:, in_mask].transpose(1, 0, 2))           # [n, F, 2]
+    V = deriv(P)
+    S = np.concatenate([P, V, deriv(V)], axis=2)                               # [n, F, 6]
+    types = np.where(ids_in_all == ROBOT_ID, TYPE_VALUE_ROBOT, TYPE_VALUE_PED)
 
     # constant-velocity forecasts for pedestrians outside the cluster (mid_sim_wrapper.py:413-429)
     cv = {}
-    for i in ids_out_all:
-        if i == ROBOT_ID:
-            continue
-        xy = human_xy[:, i]
-        vx, vy = derivative_of(xy[:, 0], dt), derivative_of(xy[:, 1], dt)
-        fc = np.zeros((horizon, 2))
-        fc[:, 0] = xy[-1, 0] + np.cumsum(np.tile(vx[-1] * dt, horizon))
-        fc[:, 1] = xy[-1, 1] + np.cumsum(np.tile(vy[-1] * dt, horizon))
-        cv[int(i)] = fc
+    out_peds = [int(i) for i in ids_out_all if i != ROBOT_ID]
+    if out_peds:
+        last = human_xy[-1, out_peds]                                          # [m, 2]
+        v_last = (last - human_xy[-2, out_peds]) / dt if F >= 2 else np.zeros_like(last)
+        fc_all = last[:, None, :] + np.cumsum(np.repeat((v_last * dt)[:, None, :], horizon, axis=1), axis=1)
+        for r, i in enumerate(out_peds):
+            cv[i] = fc_all[r]
 
     # temporal scene graph over the last 3 frames (scene.py:67-110, scene_graph.py:111-201)
     P3 = S[:, F - 3:F, 0:2].transpose(1, 0, 2)                                 # [3, n, 2]
@@ -181,35 +187,38 @@ def build_scene(human_xy: np.ndarray, robot_xy: np.ndarray, time_step: float, ho
     type_mat = np.tile(types[None, :], (n, 1)).astype(np.float64)
     np.fill_diagonal(type_mat, 0)
     adj3 = (d3 <= ATTENTION_RADIUS).astype(np.float64) * type_mat[None]
-    for t in range(3):
-        np.fill_diagonal(adj3[t], 0)
+    eye = np.eye(n, dtype=bool)
+    adj3[:, eye] = 0.0
     scaling = edge_scaling_last(adj3)                                          # [n, n]
     connected = scaling > 1e-2
 
-    ped_rows = [k for k, i in enumerate(node_ids) if i != ROBOT_ID]
+    ped_rows = np.nonzero(ids_in_all != ROBOT_ID)[0]
     A = len(ped_rows)
-    x = np.zeros((A, F, 6))
-    x_st = np.zeros((A, F, 6))
+    x = S[ped_rows]                                                            # [A, F, 6]
+    rel = np.zeros((A, 1, 6))
+    rel[:, 0, 0:2] = x[:, -1, 0:2]
+    x_st = (x - rel) / STATE_STD
     nbr_sum = np.zeros((A, 2, F, 6), dtype=np.float32)
     edge_mask = np.zeros((A, 2), dtype=np.float32)
     for r, k in enumerate(ped_rows):
-        xs = S[k]
-        x[r] = xs
-        rel = np.zeros(6)
-        rel[0:2] = xs[-1, 0:2]
-        x_st[r] = (xs - rel) / STATE_STD
         # edge values are NOT filtered by edge type (scene_graph.py:293-299): both types see the same sum
         ev = scaling[k, connected[k]].astype(np.float32)
-        em = np.float32(min(float(ev.sum(dtype=np.float32)), 1.0)) if ev.size else np.float32(0.0)
-        edge_mask[r, :] = em
-        for e, tv in enumerate((TYPE_VALUE_PED, TYPE_VALUE_ROBOT)):
-            acc = np.zeros((F, 6), dtype=np.float32)
-            for j in np.nonzero(connected[k] & (type_mat[k] == tv))[0]:
-                # neighbour state relative to the ego's WHOLE present state (preprocessing.py:531-550)
-                acc = acc + ((S[j] - xs[-1][None, :]) / STATE_STD).astype(np.float32)
-            nbr_sum[r, e] = acc
+        edge_mask[r, :] = np.float32(min(float(ev.sum(dtype=np.float32)), 1.0)) if ev.size else np.float32(0.0)
+    # neighbour state relative to the ego's WHOLE present state (preprocessing.py:531-550), summed per edge type in node order in
+    # float32: one pass over the neighbours j for all egos at once (a neighbour that is not connected adds +0.0, which leaves a
+    # float32 partial sum as it is - the sums start at +0.0 and never become -0.0)
+    if A and n:
+        conn = connected[ped_rows]                                             # [A, n]
+        tm = type_mat[ped_rows]
+        sel = np.stack([conn & (tm == TYPE_VALUE_PED), conn & (tm == TYPE_VALUE_ROBOT)], axis=1)   # [A, 2, n]
+        ego_now = x[:, -1, :]                                                  # [A, 6]
+        for j in range(n):
+            if not sel[:, :, j].any():
+                continue
+            term = ((S[j][None] - ego_now[:, None, :]) / STATE_STD).astype(np.float32)             # [A, F, 6]
+            nbr_sum += np.where(sel[:, :, j, None, None], term[:, None], np.float32(0.0))
     ids_in = np.array([i for i in node_ids if i != ROBOT_ID], dtype=np.int64)
-    ids_out = np.array([i for i in ids_out_all if i != ROBOT_ID], dtype=np.int64)
+    ids_out = np.array(out_peds, dtype=np.int64)
     return SceneBatch(ids_in=ids_in, ids_out=ids_out, x=x.astype(np.float32), x_st=x_st.astype(np.float32),
                       nbr_sum=nbr_sum, edge_mask=edge_mask, p0=x[:, -1, 0:2].astype(np.float32),
                       cv_forecasts=cv, robot_in_cluster=bool(in_mask[0]))

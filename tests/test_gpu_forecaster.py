@@ -110,6 +110,27 @@ def test_rng_compat_cuda_leaves_the_cpu_generator_after_x_T(tmp_path):
         HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="numpy")
 
 
+def test_device_generator_is_advanced_exactly_as_by_the_reference_draws():
+    """rng_compat="cuda": the reference's per-step z (MID/models/diffusion.py:509, unused by DDIM) are not launched; the device
+    generator's Philox offset is moved by what they would have consumed.  State and next draw must equal the real thing - on the
+    call that learns a shape's step (one real draw) and on the ones after it, for shapes of every launch geometry."""
+    from safe_interactive_crowdnav_amd import forecaster as F
+    for shape, n in (((100, 12, 2), 49), ((300, 8, 2), 1), ((7, 3, 2), 5), ((4096, 24, 2), 3), ((1, 1, 2), 2)):
+        F._PHILOX_STEP.pop((0, shape), None)
+        for attempt in ("learns", "knows"):
+            torch.cuda.manual_seed(1234)
+            z = torch.empty(shape, device="cuda:0")
+            for _ in range(n):
+                torch.randn_like(z)
+            state = torch.cuda.get_rng_state(0)
+            nxt = torch.randn(5, device="cuda:0")
+            torch.cuda.manual_seed(1234)
+            F.advance_cuda_generator(0, shape, n)
+            assert torch.equal(torch.cuda.get_rng_state(0), state), (shape, attempt)
+            assert torch.equal(torch.randn(5, device="cuda:0"), nxt), (shape, attempt)
+        assert (0, shape) in F._PHILOX_STEP
+
+
 def test_returned_arrays_are_fresh(tmp_path):
     z = np.load(os.path.join(GOLDEN, "wrapper_jmid_w32_spread50.npz"))
     env, ypath = write_configs(str(tmp_path), joint=True, ctx_dim=32, N=int(z["N"]), K=int(z["K"]),
