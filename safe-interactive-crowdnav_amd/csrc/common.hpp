@@ -153,6 +153,7 @@ struct Tuning {
     int small_mlp = 0;       // linear1 -> ReLU -> linear2 + residual + LayerNorm of a one-scene F16MX call in ONE launch (gemm_small.hpp, gemm_small_mlp_kernel; experiments flavour, measured slower): 1 on, 0 / 2 off (linear1's launch + the OUT_LNX launch)
     int small_cmb = 0;       // the split-KV merge of a one-scene attention launch inside the out-projection's OUT_LNX launch (gemm_small.hpp, lnx_combine): 0 on, 2 off (attn_combine_kernel)
     int small_lnx = 0;       // out_proj / linear2 + residual + LayerNorm of a small F16MX launch in ONE kernel, row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX): 0 on, two exchanges in the canonical summation order (bit-identical to the pair); 1 on, ONE exchange (0.2 ms per one-scene call faster, another summation order: diagnostics); 2 off (GEMM + add_ln2)
+    int small_lnx2 = 0;      // ... for launches of 33 ... 64 row tiles (two scenes' worth of tokens; the reference's shipped K = 100) with TWO workgroups per CU: 0 on, 2 off (GEMM + add_ln2 [+ attn_combine])
     int gemm_pn = 0;         // F16MX large-tile GEMMs: column groups of the XCD tile order (0 / 1 = N fastest over all N-tiles)
     int one_chunk = 1;       // set per call by run_network: the call is ONE chunk (OUT_LNX of gemm_small.hpp only then, whatever the lanes: a call's bits do not depend on its chunk plan)
     int small_now = 1;       // set per call by run_network: the small-launch kernels only while ONE chunk is in flight (with two lanes their

@@ -85,12 +85,17 @@ constexpr int SM_STG_LD = 68;                              // floats per row of 
 // flag, no counter); a workgroup waits for the seven other blocks of its rows only, which were dispatched next to it.  The partials
 // and the totals are formed in gemm_ln2_mx.hpp's canonical order (partial(c, h) by ONE thread over its 32 columns, P_c = partial(c, 0)
 // + partial(c, 1), total = ((P0 + P1) + ...) + P7), so the rows are bit-identical to the GEMM + add_ln2_kernel pair and to the
-// row-complete kernel of full launches.  The launch must fit the chip with one workgroup per CU (the waiting workgroups need their
-// partners resident: <= 256 tiles, nothing else in flight on the handle); the polls are BOUNDED - a workgroup that does not see a
+// row-complete kernel of full launches.  The launch must fit the chip (the waiting workgroups need their partners resident, nothing
+// else in flight on the handle): <= 256 tiles with one workgroup per CU, 257 ... 512 (33 ... 64 row tiles: two cfg2 scenes, the
+// reference's shipped N = 3, K = 100, H = 8) with TWO per CU on half the LDS each (SmCfg<SM_MX, 2, true>: two ring slots of k128
+// stages; the shipped point 0.728 -> 0.711 ms per call, 2 400 tokens x 50 steps 14.75 -> 14.24).  Either way every workgroup of
+// the launch is resident at once (the blocks of a row tile also sit at the same position of their XCDs' dispatch ranges, so a tile in
+// front of an incomplete one is complete and finishes).  The polls are BOUNDED all the same - a workgroup that does not see a
 // partner within ~10^5 polls sets bit 1 of the range flag and leaves, and the host drops the fused path for the handle.
 constexpr int SM_LNX_POLLS = 1 << 17;
-constexpr size_t SM_LNX_STATS = size_t(2) * 32 * 8 * 64;        // per step workspace: two statistics x 32 row tiles x 8 blocks x 64 rows ...
-constexpr size_t SM_LNX_GRANULES = SM_LNX_STATS + 32 * 8;       // ... + one flag per block of the A operand (lnx_combine)
+constexpr int SM_LNX_MAX_TILES = 64;                            // row tiles of a launch: 32 with one workgroup per CU, 33 ... 64 with two
+constexpr size_t SM_LNX_STATS = size_t(2) * SM_LNX_MAX_TILES * 8 * 64;        // per step workspace: two statistics x row tiles x 8 blocks x 64 rows ...
+constexpr size_t SM_LNX_GRANULES = SM_LNX_STATS + SM_LNX_MAX_TILES * 8;       // ... + one flag per block of the A operand (lnx_combine)
 
 __device__ __forceinline__ void lnx_publish(unsigned long long* slot, float v, unsigned tag) {
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -569,6 +574,7 @@ __device__ __forceinline__ void small_qk_staged_store(const GemmHArgs& g, const 
 // The OUT_LNX launch of one tile (tm, c): [split-KV merge] -> K loop (transposed: a lane owns token row l31 of its wave's block and
 // four runs of 4 consecutive columns) -> the fp32 rows (accumulator + bias: what the stand-alone GEMM hands add_ln2) staged in LDS, the
 // operand ring's place, in the ownership of the row statistics -> the exchange and the workgroup's own 64 columns (lnx_tail_mx).
+template <bool TWO = false>     // TWO: two workgroups per CU (257 ... 512 tiles: SmCfg<SM_MX, 2, true>, two ring slots of 40 KB)
 __device__ __forceinline__ void lnx_body(const GemmHArgs& g, unsigned char* lds_raw, int tm, int tn, int tid
 #ifdef JMID_SMALL_TRACE
                                          , unsigned long long* sm_trace_p
@@ -584,7 +590,7 @@ __device__ __forceinline__ void lnx_body(const GemmHArgs& g, unsigned char* lds_
     if (g.cmb_O) lnx_combine(g, tm, tn, m0, tid);
     LnxPre pre;
     lnx_prefetch(g, c_v, m0_v, tid, pre);
-    const f32x16 acc = small_kloop<SM_MX, 2, false, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
+    const f32x16 acc = small_kloop<SM_MX, 2, TWO, true>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
     lnx_prefetch_landed(pre);
     __syncthreads();                                   // everybody is done with the operand ring: it becomes the staging tile
     float* stg = reinterpret_cast<float*>(lds_raw);
@@ -715,8 +721,8 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
         // (accumulator + bias: what the stand-alone GEMM hands add_ln2) are staged in LDS - the operand ring's place - in the ownership
         // of the row statistics; then the exchange and the workgroup's own 64 columns (lnx_tail_mx)
         static_assert(WC == 2, "the LayerNorm tail is written for 256 threads");
-        if constexpr (MODE == SM_MX && !TWO) {
-            lnx_body(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
+        if constexpr (MODE == SM_MX) {
+            lnx_body<TWO>(g, lds_raw, tm, tn, tid SM_TRACE_ARG);
             SM_STAMP(5);
         }
         return;
@@ -892,7 +898,11 @@ inline int small_gemm_shape(const GemmHArgs& g) {
 template <int EPI, int OUT, int MODE>
 inline hipError_t launch_gemm_small_mode(const GemmHArgs& g, int wc, hipStream_t st) {
     if (wc == 2) return launch_gemm_small_cfg<EPI, OUT, MODE, 2>(g, st);
-    if constexpr (OUT == OUT_LNX) return hipErrorInvalidValue;       // (N = 512: always the 64-column shape)
+    if constexpr (OUT == OUT_LNX) {                                  // (N = 512: always the 64-column shape; 9 = two workgroups per CU)
+        if constexpr (MODE == SM_MX)
+            if (wc == 9) return launch_gemm_small_cfg<EPI, OUT, MODE, 2, true>(g, st);
+        return hipErrorInvalidValue;
+    }
     else {
         if constexpr (MODE != SM_X3)
             if (wc == 8) return launch_gemm_small_cfg<EPI, OUT, MODE, 4, true>(g, st);
@@ -928,10 +938,11 @@ inline hipError_t launch_gemm_small_mlp(const GemmHArgs& g1, const GemmHArgs& g2
 // at most 256 tiles of 64 x 64 with nothing else in flight on the handle (the waiting workgroups need their partners resident), at
 // most 32 row tiles (the exchange buffer), in calls of ONE chunk (a call's bits must not depend on its chunk plan or its lanes).  "small_lnx" knob: 0 on with two exchanges (the default: bit-identical to the pair), 1 on with
 // ONE exchange (diagnostics flavour), 2 off (GEMM + add_ln2).
-inline bool small_lnx_fits(int M, int K) {
+inline int small_lnx_fits(int M, int K) {       // 0 no; 2: one workgroup per CU (at most 32 row tiles); 9: two per CU (33 ... 64 row tiles, "small_lnx2" = 2 off)
     const long ntm = (M + 63) / 64;
-    return tune().gemm_small != 1 && tune().small_now == 1 && tune().one_chunk == 1 && tune().gemm_h_variant == 0 && tune().small_lnx != 2 && K % 128 == 0 &&
-           ntm * (GLN_BN / 64) <= 256 && ntm <= 32;
+    if (!(tune().gemm_small != 1 && tune().small_now == 1 && tune().one_chunk == 1 && tune().gemm_h_variant == 0 && tune().small_lnx != 2 && K % 128 == 0)) return 0;
+    if (ntm <= 32) return 2;
+    return ntm <= SM_LNX_MAX_TILES && tune().small_lnx2 != 2 ? 9 : 0;
 }
 
 template <int EPI, int OUT>

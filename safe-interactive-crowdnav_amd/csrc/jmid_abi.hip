@@ -455,6 +455,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 #endif
         {"small_cmb", &Tuning::small_cmb, 0, 2},               // 2: attn_combine_kernel instead of the split-KV merge inside the out-projection's one-launch GEMM + LayerNorm
         {"small_lnx", &Tuning::small_lnx, 0, 2},               // the one-launch GEMM + LayerNorm with the statistics exchange: 0 two exchanges (bit-identical), 1 one exchange, 2 off (GEMM + add_ln2)
+        {"small_lnx2", &Tuning::small_lnx2, 0, 2},             // the same at 33 ... 64 row tiles, two workgroups per CU: 0 on, 2 off
 #ifdef JMID_EXPERIMENTS
         {"small_out", &Tuning::small_out, 0, 2},
 #endif

@@ -31,7 +31,7 @@ inline int run_gemm_lnx_small(jmid_ctx* h, int cls, GemmHArgs& g) {
     g.ln_epoch = h->lnx_epoch;
     g.ln_one = tune().small_lnx == 1;
     ProfScope ps(h, cls);
-    HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LNX>(g, 2, h->stream)));
+    HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LNX>(g, small_lnx_fits(g.M, g.K), h->stream)));      // (2: one workgroup per CU, 9: two)
     return 0;
 }
 

@@ -278,7 +278,7 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
 #ifdef JMID_EXPERIMENTS
             // one scene in F16MX: the whole MLP in ONE launch (gemm_small.hpp, gemm_small_mlp_kernel) where linear2 would take the
             // one-launch GEMM + LayerNorm (experiment "small_mlp" = 1: bit-identical, measured slower)
-            const bool mlp_one = mxv2 && !ln_fused && !h->lnx_off && small_lnx_fits(M, ff) && small_mlp_fits(d, ff) && g.W8;
+            const bool mlp_one = mxv2 && !ln_fused && !h->lnx_off && small_lnx_fits(M, ff) == 2 && small_mlp_fits(d, ff) && g.W8;
             if (mlp_one) {
                 GemmHArgs g2 = g;
                 const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
@@ -447,7 +447,13 @@ std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
         // 512: 1142 -> 1086, 160: 356 -> 347, 104: 230 -> 224 (F16MX); F16X2 / F16X3 within 0.4 % either way (tools/chunk_fine.py).
         // The split-KV factor of a call does not depend on its chunk plan (run_network), so neither do the results.
         if (E <= c) {
-            c = (E + 1) / 2;
+            // ... unless the whole batch is at most 2 560 tokens in F16MX at d_model 512: as ONE chunk its out-projection / linear2 launches
+            // carry the LayerNorm and the split-KV merge (gemm_small.hpp, OUT_LNX - only while nothing else of the handle is in flight),
+            // nine launches less per denoise step: two cfg2 scenes (2 400 tokens) 14.45 -> 13.90 ms per call.  Three (3 600 tokens, 456
+            // workgroups of that kernel) are better off as 2 + 1 side by side: 16.42 against 16.90 (profiles/r05s_lnx_two_per_cu.log)
+            const bool lnx_call = h->mx && h->d == jmid::GLN_BN && !h->lnx_off && (long)E * tokens_per_episode <= 2560 &&
+                                  tune().small_lnx != 2 && tune().small_lnx2 != 2 && tune().gemm_small != 1 && tune().gemm_h_variant == 0;
+            c = lnx_call ? E : (E + 1) / 2;
         } else {
             int n = (E + c - 1) / c;
             if ((n & 1) && n < E) ++n;      // (never more chunks than episodes: c == 1 with an odd E stays at E chunks of one)

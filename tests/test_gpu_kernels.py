@@ -147,7 +147,8 @@ needs_experiments = pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="the 
                                        "(python safe-interactive-crowdnav_amd/build.py experiments)")
 
 
-@pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128), (1, 512)])
+@pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128), (1, 512),
+                                 (2049, 512), (2400, 512), (2400, 1024), (4096, 1024), (4001, 128)])      # (> 2048 rows: two workgroups per CU)
 def test_small_launch_gemm_with_statistics_exchange_equals_its_unfused_pair(M, K):
     """gemm_small_kernel<.., OUT_LNX> (one scene in F16MX: out_proj / linear2 + residual + LayerNorm in ONE launch - the eight
     workgroups of a 64-row tile exchange the row statistics as {value, launch tag} granules and normalise their own 64 columns)

@@ -405,6 +405,33 @@ def test_split_modes_hold_parity_when_attention_is_peaked():
     assert oerr["f16x2"] <= ADE_GATE and oerr["f16mx"] <= ADE_GATE, oerr
 
 
+@pytest.mark.parametrize("A,K,T,step", [(3, 100, 8, 2), (3, 100, 8, 50), (5, 35, 12, 10), (5, 68, 12, 4)])
+def test_layernorm_inside_the_gemm_launch_at_two_workgroups_per_cu_is_bit_identical(A, K, T, step):
+    """A scene of 2 049 ... 4 096 tokens in F16MX (the reference's shipped point: N = 3, K = 100, H = 8 = 2 400 tokens): the one-launch
+    GEMM + LayerNorm with the statistics exchange (and the split-KV merge in the out-projection's launch) runs with TWO workgroups per CU
+    (gemm_small.hpp, SmCfg<SM_MX, 2, true>: 33 ... 64 row tiles x 8 = up to 512 workgroups, all resident).  "small_lnx2" = 2 takes the
+    separate launches: the same bits, call after call on one handle, and within the gate of the oracle."""
+    eng, w = get_engine(256, 31, True)
+    eng.set_step(step, "ddim")
+    g = torch.Generator().manual_seed(A * 1000 + K)
+    ctx = torch.randn([1, A, 256], generator=g).cuda()
+    x_T = torch.randn([1, K * A, T, 2], generator=g).cuda()
+    assert 2048 < K * A * T <= 4096
+    out = []
+    try:
+        for knob in (2, 0, 0, 2, 0):
+            eng.set_tuning("small_lnx2", knob)
+            out.append(eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy())
+    finally:
+        eng.set_tuning("small_lnx2", 0)
+    for o in out[1:]:
+        np.testing.assert_array_equal(o, out[0])
+    if step <= 10:
+        with torch.no_grad():
+            ref = O.denoise(w.tensors, ctx.cpu(), x_T.cpu(), sample=K, step=step, joint=True).numpy()
+        assert ade(out[1], ref) <= ADE_GATE
+
+
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz"])
 def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
     """One scene in F16MX (d_model 512): out_proj / linear2 + residual + LayerNorm run as ONE small launch whose workgroups exchange
@@ -673,7 +700,7 @@ def test_restructured_attention_kernels_equal_the_32_key_kernel(E, A, K, T, knob
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
                ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
-               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (1, 2)), ("small_cmb", (2,))]
+               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (1, 2)), ("small_cmb", (2,)), ("small_lnx2", (2,))]
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)
