@@ -213,7 +213,7 @@ int64_t jmid_erange_count(jmid_handle_t h);
 /* ---- tuning / measurement ------------------------------------------------------------------ */
 /* Episodes processed together per pass of the 50-step loop (0 = automatic: a whole number of rounds of the attention
  * launch, a short ragged tail spread over the full chunks).  Results are bit-identical for every chunking of the same
- * call; the split-KV factor of the attention launches is a function of (E, A, K, T) only, so calls with different
+ * call; the split-KV factor of the attention launches is a function of (E, A, K, T) and the precision only, so calls with different
  * episode counts agree to rounding (ADE ~1e-7 m), not bit for bit, when head_dim is 128. */
 int jmid_set_chunk_episodes(jmid_handle_t h, int episodes);
 /* Run-time switches of a handle.  The production library knows ONE key:

@@ -449,7 +449,7 @@ std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
         if (E <= c) {
             // ... unless the whole batch is at most 2 560 tokens in F16MX at d_model 512: as ONE chunk its out-projection / linear2 launches
             // carry the LayerNorm and the split-KV merge (gemm_small.hpp, OUT_LNX - only while nothing else of the handle is in flight),
-            // nine launches less per denoise step: two cfg2 scenes (2 400 tokens) 14.45 -> 13.90 ms per call.  Three (3 600 tokens, 456
+            // nine launches less per denoise step: two cfg2 scenes (2 400 tokens) 14.45 -> 13.90 ms per call, 12.63 with the split-KV factor chosen for that launch (run_network).  Three (3 600 tokens, 456
             // workgroups of that kernel) are better off as 2 + 1 side by side: 16.42 against 16.90 (profiles/r05s_lnx_two_per_cu.log)
             const bool lnx_call = h->mx && h->d == jmid::GLN_BN && !h->lnx_off && (long)E * tokens_per_episode <= 2560 &&
                                   tune().small_lnx != 2 && tune().small_lnx2 != 2 && tune().gemm_small != 1 && tune().gemm_h_variant == 0;
@@ -532,7 +532,11 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         // sized for ONE launch of the default plan (two chunks in flight: a batch that fits one chunk runs as two halves) - a
         // function of the call's shape only, whatever the chunk size or number of lanes actually set
         const int c_auto = auto_chunk(h, E, S);
-        ns_call = attn_pick_nsplit(((S + 127) / 128) * h->nhead * (E >= 2 ? (c_auto + 1) / 2 : 1), S);
+        // (a batch of at most 2 560 tokens in F16MX is ONE launch by default - plan_chunks: two cfg2 scenes take 3 key ranges x 80 blocks,
+        //  13.43 ms per call, where the 6 x 80 of the halves' choice take 14.14-14.37; shape and mode only, no knob: the bits of a call
+        //  must not depend on one)
+        const bool one_launch = h->mx && h->d == jmid::GLN_BN && (long)E * S <= 2560;
+        ns_call = attn_pick_nsplit(((S + 127) / 128) * h->nhead * (E >= 2 ? (one_launch ? E : (c_auto + 1) / 2) : 1), S);
         if (tune().attn_nsplit > 0) ns_call = std::min(tune().attn_nsplit, (S + 31) / 32);
     }
     // ---- workspace
