@@ -259,6 +259,9 @@ int jmid_dbg_add_layernorm(jmid_handle_t h, int M, int d, float* X, const float*
 /* The chunk plan run_network would use for a call of E episodes of `tokens_per_episode` tokens (host logic only, no device):
  * writes at most `cap` chunk sizes to `sizes`, returns the number of chunks (or a negative JMID_E* code). */
 int jmid_dbg_plan_chunks(int net_kind, int nhead, int lanes, int chunk_episodes, int E, int tokens_per_episode, int* sizes, int cap);
+/* ... of a call in arithmetic mode `precision` (a JMID_PREC_F16MX batch of at most 2 560 tokens stays ONE chunk: its out-projection /
+ * linear2 launches then carry the LayerNorm and the split-KV merge; every other mode runs such a batch as two halves side by side). */
+int jmid_dbg_plan_chunks_mode(int net_kind, int nhead, int lanes, int chunk_episodes, int E, int tokens_per_episode, int precision, int* sizes, int cap);
 #endif /* JMID_DIAGNOSTICS */
 
 #pragma GCC visibility pop

@@ -63,6 +63,7 @@ DIAG_SIGNATURES = {
                                       C.c_void_p, C.c_int]),
     "jmid_dbg_add_layernorm": (C.c_int, [Handle, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "jmid_dbg_plan_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "jmid_dbg_plan_chunks_mode": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
 }
 
 

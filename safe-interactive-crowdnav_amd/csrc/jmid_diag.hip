@@ -19,6 +19,20 @@ int jmid_dbg_plan_chunks(int net_kind, int nhead, int lanes, int chunk_episodes,
     return (int)plan.size();
 }
 
+// ... in arithmetic mode `precision` (the plan of a small batch depends on it: at most 2 560 tokens stay ONE chunk in JMID_PREC_F16MX)
+int jmid_dbg_plan_chunks_mode(int net_kind, int nhead, int lanes, int chunk_episodes, int E, int tokens_per_episode, int precision, int* sizes, int cap) {
+    if (E <= 0 || tokens_per_episode <= 0 || nhead <= 0 || !sizes || cap <= 0) return JMID_EINVAL;
+    if (precision != JMID_PREC_F32 && precision != JMID_PREC_F16X3 && precision != JMID_PREC_F16X2 && precision != JMID_PREC_F16MX) return JMID_EINVAL;
+    jmid_ctx ctx;                      // (model dimensions at their defaults: d_model 512)
+    ctx.net_kind = net_kind; ctx.nhead = nhead; ctx.lanes = lanes; ctx.chunk_eps = chunk_episodes;
+    ctx.mx = precision == JMID_PREC_F16MX;
+    ctx.x2 = precision == JMID_PREC_F16X2 || ctx.mx;
+    TuneScope tune_scope(&ctx.tune);
+    const std::vector<int> plan = plan_chunks(&ctx, E, tokens_per_episode);
+    for (size_t i = 0; i < plan.size() && (int)i < cap; ++i) sizes[i] = plan[i];
+    return (int)plan.size();
+}
+
 int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const float* Wt, const float* bias, int relu,
                   int precision, float* C) {
     if (!h || !A || !Wt || !C) return JMID_EINVAL;

@@ -236,6 +236,22 @@ def test_chunk_plan_never_holds_an_empty_chunk():
     assert plan(256, 1200) == [43] * 4 + [42] * 2
     assert plan(3, 38400) == [1, 1, 1] and plan(5, 70000) == [1] * 5       # the advisor's case: c == 1, odd E
 
+    # a small batch by arithmetic mode: at most 2 560 tokens stay ONE chunk in F16MX (the LayerNorms ride in its GEMM launches, which only
+    # run while nothing else of the handle is in flight); every other mode, and anything larger, runs as two halves side by side
+    def plan_mode(E, tokens, prec, lanes=2):
+        n = lib.jmid_dbg_plan_chunks_mode(_lib.NET_JMID, 4, lanes, 0, E, tokens, prec, buf, len(buf))
+        assert 0 < n <= len(buf), n
+        return list(buf[:n])
+
+    assert plan_mode(2, 1200, _lib.PREC_F16MX) == [2] and plan_mode(2, 1280, _lib.PREC_F16MX) == [2]
+    assert plan_mode(2, 1281, _lib.PREC_F16MX) == [1, 1] and plan_mode(3, 1200, _lib.PREC_F16MX) == [2, 1]
+    assert plan_mode(4, 600, _lib.PREC_F16MX) == [4] and plan_mode(4, 1200, _lib.PREC_F16MX) == [2, 2]
+    for prec in (_lib.PREC_F32, _lib.PREC_F16X3, _lib.PREC_F16X2):
+        assert plan_mode(2, 1200, prec) == [1, 1] and plan_mode(4, 600, prec) == [2, 2]
+    assert plan_mode(2, 1200, _lib.PREC_F16MX, lanes=1) == [2] and plan_mode(256, 1200, _lib.PREC_F16MX) == [43] * 4 + [42] * 2
+    for E in (1, 2, 3, 5, 51, 256):                      # the mode-less entry point = a mode without the rule
+        assert plan(E, 1200) == plan_mode(E, 1200, _lib.PREC_F16X3)
+
 
 def test_module_level_get_most_likely_samples_has_the_reference_signature():
     """mid_sim_wrapper.get_most_likely_samples(forecasts, mid_model, num_ret_samples) -> torch tensors [A, k, H, 2], [A, k]."""
