@@ -10,10 +10,8 @@ LIB = os.path.join(CSRC, "libjmid_hip.so")
 # the diagnostics flavour: the same kernels + the jmid_dbg_* single-kernel entry points and the jmid_set_tuning experiment knobs
 # (-DJMID_DIAGNOSTICS).  tests/ and tools/ load it (tests/conftest.py sets JMID_LIB); the product never does.
 LIB_DIAG = os.path.join(CSRC, "libjmid_hip_diag.so")
-# the experiments flavour: the diagnostics flavour + the kernels that were built, measured slower and kept for the record
-# (-DJMID_EXPERIMENTS: attn_q64.hpp, attn_pp.hpp, attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp, attn_pp2.hpp, tail_f16x3.hpp, the small-launch GEMM + LayerNorm / output tails; docs/NOTEBOOK.md).
-# Not built by build(): `python safe-interactive-crowdnav_amd/build.py experiments`; its tests skip when it is absent.
-LIB_EXP = os.path.join(CSRC, "libjmid_hip_exp.so")
+# (The third flavour of rounds 4-5, -DJMID_EXPERIMENTS - seven attention / tail kernels that measured slower - was retired in round 6:
+# docs/NOTEBOOK.md and profiles/r05_*_check.log are the record; `git revert` of that one commit brings the kernels back.)
 # translation units of the host side (csrc/jmid_ctx.hpp says what each holds); every unit instantiates the kernels it launches
 SOURCES = ["jmid_abi.hip", "jmid_weights.hip", "jmid_planner.hip", "jmid_profile.hip", "jmid_diag.hip"]
 
@@ -41,12 +39,11 @@ def library_path() -> str:
     return os.environ.get("JMID_LIB") or LIB
 
 
-def build_library(force: bool = False, verbose: bool = False, diagnostics: bool = False, experiments: bool = False) -> str:
-    """Compile the HIP library in-tree (``diagnostics``: the -DJMID_DIAGNOSTICS flavour; ``experiments``: that + -DJMID_EXPERIMENTS).
+def build_library(force: bool = False, verbose: bool = False, diagnostics: bool = False) -> str:
+    """Compile the HIP library in-tree (``diagnostics``: the -DJMID_DIAGNOSTICS flavour).
     Returns the path of the .so."""
-    diagnostics = diagnostics or experiments
-    LIB = LIB_EXP if experiments else LIB_DIAG if diagnostics else globals()["LIB"]
-    flavour = "experiments" if experiments else "diagnostics" if diagnostics else "production"
+    LIB = LIB_DIAG if diagnostics else globals()["LIB"]
+    flavour = "diagnostics" if diagnostics else "production"
     # -ffp-contract=off: no implicit FMA contraction, so a value never depends on which template instance /
     # code path computed it (results are bit-identical across tile variants and chunkings); fmaf() is explicit.
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -59,7 +56,7 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
     # chunks in flight (docs/NOTEBOOK.md section 3).  Same IEEE arithmetic without them (bit-identical results), and 2 % faster.
     # (The host pass of the same command line warns that the feature is unknown to x86: harmless.)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-ffp-contract=off",
-             "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else []) + (["-DJMID_EXPERIMENTS"] if experiments else [])
+             "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"] + (["-DJMID_DIAGNOSTICS"] if diagnostics else [])
     stamp, digest = LIB + ".stamp", _source_digest(flags)
     force = force or os.environ.get("JMID_FORCE_BUILD", "0") not in ("", "0")
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
@@ -68,7 +65,7 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
             print(f"[build] {flavour}: reused {os.path.basename(LIB)} (sources + flags digest {digest[:12]} unchanged; "
                   "JMID_FORCE_BUILD=1 recompiles)")
         return LIB
-    objdir = os.path.join(CSRC, "obj_exp" if experiments else "obj_diag" if diagnostics else "obj")
+    objdir = os.path.join(CSRC, "obj_diag" if diagnostics else "obj")
     os.makedirs(objdir, exist_ok=True)
     # the units compile side by side (the planner - every GEMM / attention instantiation of the denoise loop - is the long one)
     jobs = []
@@ -102,8 +99,5 @@ def build_library(force: bool = False, verbose: bool = False, diagnostics: bool 
 
 if __name__ == "__main__":
     import sys
-    if "experiments" in sys.argv[1:]:
-        print(build_library(force="force" in sys.argv[1:], verbose=True, experiments=True))
-    else:
-        print(build_library(force=True, verbose=True))
-        print(build_library(force=True, verbose=True, diagnostics=True))
+    print(build_library(force=True, verbose=True))
+    print(build_library(force=True, verbose=True, diagnostics=True))

@@ -916,41 +916,8 @@ inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(256), tune().attn_one_wg ? 160 * 1024 : ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }
 
-#ifdef JMID_EXPERIMENTS
-// experiment (knob "attn_q64" = 1, -DJMID_EXPERIMENTS builds only): F16MX launches without a key split on the one-wave-per-SIMD kernel with two
-// query blocks per wave (attn_q64.hpp, included at the end of this file) - bit-identical, measured 7-14 % slower than the kernel below
-inline bool attn_q64_applies(const AttnHArgs& a, int nseq);
-inline hipError_t launch_attn_q64(const AttnHArgs& a_in, int nseq, hipStream_t st);
-#endif
-
-#ifdef JMID_EXPERIMENTS
-// experiment (knob "attn_pp" = 1): the 8-wave ping-pong form of the head_dim-128 kernel (attn_pp.hpp, included at the end of this
-// file; bit-identical, measured no faster - docs/NOTEBOOK.md section 10)
-inline bool attn_pp_applies(const AttnHArgs& a, int nseq);
-inline void launch_attn_pp(AttnHArgs a, int nseq, hipStream_t st);
-#endif
-
-#ifdef JMID_EXPERIMENTS
-// experiment (knob "attn_k64" = 1): F16MX / F16X2 launches without a key split on 64-key tiles - two softmax rounds per tile, their P.V
-// products behind one wait and one barrier (attn_k64.hpp, included at the end of this file; bit-identical, measured 0-4 % slower)
-inline bool attn_k64_applies(const AttnHArgs& a);
-inline void launch_attn_k64(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
-// experiment (knob "attn_sp" = 1): the same launches with P.V of tile t - 1 pipelined into the logits of tile t (attn_sp.hpp; bit-identical)
-inline bool attn_sp_applies(const AttnHArgs& a);
-inline void launch_attn_sp(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
-// ("attn_sp" = 2): ... and the softmax of tile t in the gaps of those matrix instructions (attn_sp2.hpp)
-inline bool attn_sp2_applies(const AttnHArgs& a);
-inline void launch_attn_sp2(const AttnHArgs& a, int nseq, int nqt, hipStream_t st);
-// ("attn_pp" = 3): the ping-pong rebuilt on attn_sp.hpp's matrix phase, copies three segments ahead by group 0 only (attn_pp2.hpp)
-inline bool attn_pp2_applies(const AttnHArgs& a);
-inline void launch_attn_pp2(AttnHArgs a, int nseq, hipStream_t st);
-#endif
-
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
     AttnHArgs a = a_in;
-#ifdef JMID_EXPERIMENTS
-    if (head_dim == 128 && tune().attn_h_variant != 1 && attn_q64_applies(a, nseq)) return launch_attn_q64(a, nseq, st);
-#endif
     if (head_dim == 128 && tune().attn_h_variant != 1) {
         const int nqt = (a.S + 127) / 128;
         const dim3 grid1(nqt * a.nhead * nseq * a.nsplit);
@@ -962,22 +929,6 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
         // the mode is a template parameter (a run-time flag in the key-tile loop costs F16X3 ~4 %).  F16X2 / F16MX: one fp16 plane
         // of P unless "attn_mx" = 1; F16MX with bf8 K images: the logits' correction terms as bf8 MFMAs
         const bool p1 = tune().attn_mx != 1;
-#ifdef JMID_EXPERIMENTS
-        if (attn_pp_applies(a, nseq)) {
-            launch_attn_pp(a, nseq, st);
-        } else
-#endif
-#ifdef JMID_EXPERIMENTS
-        if (attn_pp2_applies(a)) {
-            launch_attn_pp2(a, nseq, st);
-        } else if (attn_sp2_applies(a)) {
-            launch_attn_sp2(a, nseq, nqt, st);
-        } else if (attn_sp_applies(a)) {
-            launch_attn_sp(a, nseq, nqt, st);
-        } else if (attn_k64_applies(a)) {
-            launch_attn_k64(a, nseq, nqt, st);
-        } else
-#endif
         if (a.x2 && a.K8h) {
             if (p1 && tune().attn_pf != 2) launch_attn_dma<true, true, false, true, true>(a, grid1, nqt, st);
             else if (p1) launch_attn_dma<true, true, false, true>(a, grid1, nqt, st);
@@ -1009,11 +960,3 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 
 }  // namespace jmid
 
-#ifdef JMID_EXPERIMENTS
-#include "attn_k64.hpp"
-#include "attn_sp.hpp"
-#include "attn_sp2.hpp"
-#include "attn_pp2.hpp"
-#include "attn_pp.hpp"
-#include "attn_q64.hpp"
-#endif

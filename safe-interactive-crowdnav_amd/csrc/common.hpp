@@ -136,21 +136,14 @@ struct Tuning {
     int vt_stage = 0;        // 256x256 QKV kernel: V^T through LDS in full rows (0 / 1 on, 2 = direct 8-byte stores)
     int graph = 0;           // captured denoise loop (hipGraph) of one-chunk calls: 1 on, 0 / 2 off (default: not faster, see jmid_planner.hip)
     int attn_nsplit = 0;     // split-KV factor of the head_dim-128 attention launches: 0 auto, 1..16 forced
-    int tail_fuse = 0;       // tail of the net in one kernel (tail_f16x3.hpp, d_model 512): 1 on, 0 / 2 off (default: slower, see jmid_planner.hip)
-    int tail_rows = 0;       // its row tile: 0 auto, 32, 64
     int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
-    int attn_q64 = 0;        // experiment (diagnostics): 1 = F16MX attention launches without a key split on the one-wave-per-SIMD kernel (attn_q64.hpp: bit-identical, measured slower)
-    int attn_k64 = 0;        // head_dim-128 attention of F16MX / F16X2 without a key split on 64-key tiles (attn_k64.hpp, experiments flavour; bit-identical to the 32-key kernel, measured 0-4 % slower): 0 = automatic (= never), 1 = always, 2 = never
-    int attn_sp = 0;         // (experiments flavour) 1 = F16MX / F16X2 attention without a key split with P.V(t - 1) pipelined into the logits of tile t (attn_sp.hpp; bit-identical)
     int attn_one_wg = 0;     // (probe) 1 = the head_dim-128 LDS-DMA attention kernels request the CU's whole 160 KB of LDS: ONE workgroup per CU, one wave per SIMD
-    int attn_pp = 0;         // head_dim-128 attention as the 8-wave ping-pong kernel (attn_pp.hpp; bit-identical): 0 = automatic, 1 = always, 2 = never
     int h1_stage = 0;        // F16MX linear1 in the 256 x 256 / 128 x 256 shapes: 0 / 1 = tile out through LDS in whole lines (h1_staged_store), 2 = the element-wise epilogue
     int out_traj = 0;        // output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories, 1 = always, 2 = one wave per token
     int attn_mx = 0;         // head_dim 128: F16MX 0 = bf8 logit corrections + one fp16 plane of P, 1 = P_hi + P_lo (F16X2 too), 2 = F16X2's attention, 3 = as 0 with Q_lo as an fp16 plane (A/B; same bits)
     int mx_ln = 0;           // F16MX at d_model 512: 0 = second-generation GEMM + LayerNorm (gemm_ln2_mx.hpp: byte lo plane of the residual stream, two workgroups per CU), 2 = the first generation
     int attn_pf = 0;         // F16MX / F16X2 attention with one plane of P: 2 = fragment reads one step ahead instead of three (A/B; same bits)
     int gemm_small = 0;      // launches of at most one workgroup per CU (gemm_small.hpp): 0 = the deep-ring k64 kernel, 1 = the round-3 tile shapes, 2 = the deep-ring kernel only up to one workgroup per CU
-    int small_mlp = 0;       // linear1 -> ReLU -> linear2 + residual + LayerNorm of a one-scene F16MX call in ONE launch (gemm_small.hpp, gemm_small_mlp_kernel; experiments flavour, measured slower): 1 on, 0 / 2 off (linear1's launch + the OUT_LNX launch)
     int small_cmb = 0;       // the split-KV merge of a one-scene attention launch inside the out-projection's OUT_LNX launch (gemm_small.hpp, lnx_combine): 0 on, 2 off (attn_combine_kernel)
     int small_lnx = 0;       // out_proj / linear2 + residual + LayerNorm of a small F16MX launch in ONE kernel, row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX): 0 on, two exchanges in the canonical summation order (bit-identical to the pair); 1 on, ONE exchange (0.2 ms per one-scene call faster, another summation order: diagnostics); 2 off (GEMM + add_ln2)
     int small_lnx2 = 0;      // ... for launches of 33 ... 64 row tiles (two scenes' worth of tokens; the reference's shipped K = 100) with TWO workgroups per CU: 0 on, 2 off (GEMM + add_ln2 [+ attn_combine])
@@ -159,7 +152,6 @@ struct Tuning {
     int small_now = 1;       // set per call by run_network: the small-launch kernels only while ONE chunk is in flight (with two lanes their
                              // one-workgroup-per-CU launches collide: 4 episodes as 2 x 2 measured 4 % slower with them)
     int small_lanes = 0;     // experiment: the small-launch kernels with several chunks in flight too: 1 = all of them, 2 = only the two-workgroups-per-CU shape
-    int small_out = 0;       // concat4 + output layer + DDIM update + next embedding of a small launch in one kernel (gemm_small_out_kernel): 1 on (measured slower: 19 workgroups walk the output stage of 1200 tokens), 0 / 2 off
     int small_qk = 0;        // Q / K tiles of a small in_proj launch out through LDS in full rows: 0 / 1 on, 2 = the generic element-wise epilogue
     int small_pn = 0;        // its column groups per launch (two-dimensional XCD tile order): 0 = fewest Infinity-Cache bytes, 1 / 2 / 4 / 8 forced
     int attn_abl = 0;        // timing ablations (results are WRONG): only in builds with -DJMID_ABLATIONS

@@ -611,85 +611,6 @@ __device__ __forceinline__ void lnx_body(const GemmHArgs& g, unsigned char* lds_
     SM_STAMP(5);
 }
 
-#ifdef JMID_EXPERIMENTS
-// ---- linear1 -> ReLU -> linear2 + residual + LayerNorm of one scene in ONE launch (F16MX, d_model 512, ff = 1024).  The seam between the
-// two GEMMs is the one lnx_combine crosses: workgroup (tm, c) first computes the two 64 x 64 blocks 2 c, 2 c + 1 of the hidden rows
-// (linear1's K loop and epilogue: + bias, ReLU, the fp16 plane - the stand-alone launch's operations, the same bits), writes them
-// through, raises its flag, waits for the seven others of its row tile - the 1024 hidden columns of its 64 rows are complete then -
-// and runs linear2's OUT_LNX launch on them (lnx_body).  One launch and one kernel boundary less per layer; what it costs is linear1
-// on 4-wave workgroups with 64-column tiles (two K loops of 512 one after the other, each with its own cold ring) where the stand-alone
-// launch has 8 waves and 128-column tiles - and that is more than the launch saves: bit-identical at the first run, and MEASURED
-// SLOWER (one scene 11.23 against 10.70 ms per 50-step call, profiles/r05_lnx_mlp_single_scene.log).  Experiments flavour, knob
-// "small_mlp" = 1.
-__device__ __forceinline__ void mlp_hidden_block(const GemmHArgs& g1, unsigned char* lds_raw, int tm, int tn1, int m0_v, int tn1_v, int tid
-#ifdef JMID_SMALL_TRACE
-                                                 , unsigned long long* sm_trace_p
-#endif
-) {
-    const int lane = tid & 63, wid = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int wr = wid / 2, wc = wid % 2;
-    const f32x16 acc = small_kloop<SM_MX, 2, false, true>(g1, lds_raw, tm, tn1, tid SM_TRACE_ARG);
-    const int row = m0_v + wr * 32 + l31;
-    bool overflow = false;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int col = tn1_v * 64 + wc * 32 + 8 * q + 4 * hi;
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(g1.bias + col);
-        f16x4 vh;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float v = fmaf(acc[4 * q + e], kWInv, bv[e]);
-            v = v > 0.f ? v : 0.f;
-            half_t hh, ll;
-            split_f32(v, hh, ll);
-            overflow |= row < g1.M && !(fabsf(v) <= kHalfMax);
-            vh[e] = hh;
-        }
-        if (row < g1.M)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(g1.Chi + blk_index(row, col, g1.N)), __builtin_bit_cast(unsigned long long, vh),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (overflow) atomicOr(g1.range_flag, 1);
-}
-
-static __global__ __launch_bounds__(256, 1) void gemm_small_mlp_kernel(GemmHArgs g1, GemmHArgs g2, int ntm, int gw, unsigned mper, unsigned mgw) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    args_now_each(g1, g2, ntm, gw, mper, mgw);
-#ifdef JMID_SMALL_TRACE
-    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;
-    sm_trace_p = reinterpret_cast<unsigned long long*>(pin_uniform_rfl(reinterpret_cast<unsigned long long>(sm_trace_p)));
-#endif
-    SM_STAMP(0);
-    const int tid = threadIdx.x;
-    const int nwg = gridDim.x, b = blockIdx.x;       // the tile order of gemm_small_kernel for linear2's 64 x 64 tiles (ntn = 8)
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
-    const int s = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
-    const int per = ntm * gw, cg = fast_div(s, per, mper), rem = s - cg * per;
-    const int tm = fast_div(rem, gw, mgw), tn = cg * gw + (rem - tm * gw);
-    int m0_v = tm * 64, tn_v = tn;
-    asm volatile("" : "+v"(m0_v), "+v"(tn_v));       // (vector uses of the tile indices through an opaque copy: lnx_body)
-    mlp_hidden_block(g1, lds_raw, tm, 2 * tn, m0_v, 2 * tn_v, tid SM_TRACE_ARG);
-    __syncthreads();                                   // (the ring is primed again by the next K loop)
-    mlp_hidden_block(g1, lds_raw, tm, 2 * tn + 1, m0_v, 2 * tn_v + 1, tid SM_TRACE_ARG);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's part of the two blocks is out ...
-    __syncthreads();                                       // ... and the workgroup's (and the ring is free)
-    unsigned long long* flags = g2.ln_xchg + SM_LNX_STATS + (size_t)tm * 8;
-    if (tid == 0) __hip_atomic_store(flags + tn, (unsigned long long)g2.ln_epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 8 && tid != tn_v) {
-        int budget = SM_LNX_POLLS;
-        bool need = true;
-        while (need && budget > 0) {
-            need = (unsigned)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != g2.ln_epoch;
-            if (need) __builtin_amdgcn_s_sleep(1);
-            --budget;
-        }
-        if (need) atomicOr(g2.range_flag, 2);
-    }
-    __syncthreads();
-    lnx_body(g2, lds_raw, tm, tn, tid SM_TRACE_ARG);
-}
-
-#endif  // JMID_EXPERIMENTS
 
 template <int EPI, int OUT, int MODE, int WC, bool TWO = false>
 __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(GemmHArgs g, int ntm, int ntn, int gw, int flags, unsigned mper, unsigned mgw) {
@@ -757,92 +678,6 @@ __global__ __launch_bounds__(128 * WC, TWO ? WC : 1) void gemm_small_kernel(Gemm
 #endif
 }
 
-#ifdef JMID_EXPERIMENTS
-// concat4 (ConcatSquash 256 -> 128) + output layer + DDIM / DDPM update + the next step's embedding in ONE small launch: N = 128 is
-// one 64 x 128 tile, i.e. the workgroup owns complete Y4 rows - the only GEMM of the net whose consumer can follow in the same
-// workgroup without another workgroup's data.  The gated Y4 tile stays in LDS (the ring's place), then every wave walks its share
-// of the tile's tokens in pieces of tpw (out_ddim_piece: out_ddim_traj_kernel's body, the same expressions: the same bits as
-// concat4's launch + out_ddim_kernel).  One launch and one pass of Y4 through memory less per denoise step - and MEASURED SLOWER
-// (one scene 12.06 vs 11.55 ms per call in f16mx, 14.08 vs 13.61 in f16x3; the shipped 2-step point 0.766 vs 0.750): the output
-// stage of 1200 tokens lands on 19 workgroups whose waves each walk two pieces one after the other, every piece with its own
-// round trips for the hyper-net rows, x and the stores, where out_ddim_kernel spreads the same latencies over 1200 waves.
-// Opt-in ("small_out" = 1, diagnostics flavour); kept as the fourth data point on why row-complete fusions lose at M = 1200.
-constexpr int SM_Y4_LD = 132;        // floats per row of the Y4 tile in LDS (conflict-free 16-byte rows)
-template <int MODE, bool EMBED_NEXT>
-__global__ __launch_bounds__(512, 1) void gemm_small_out_kernel(GemmHArgs g, OutArgs oa, EmbedArgs nxt, int tpw) {
-    using C = SmCfg<MODE, 4>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    args_now_each(g, oa, nxt, tpw);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wr = wid / 4, wc = wid % 4;
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
-    const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;     // (XCD-contiguous row tiles, as everywhere)
-    const int m0 = tm * C::BM;
-#ifdef JMID_SMALL_TRACE
-    unsigned long long* sm_trace_p = g_small_trace + (size_t)blockIdx.x * 64;
-#endif
-    const f32x16 acc = small_kloop<MODE, 4, false, true>(g, lds_raw, tm, 0, tid SM_TRACE_ARG);
-    __syncthreads();                                       // everybody is done with the operand ring: it becomes the Y4 tile
-    float* y4 = reinterpret_cast<float*>(lds_raw);
-    {   // csl_swapped_epilogue<1, 1, EPI_CSL, OUT_F32>, into LDS: lane = token row l31 of its wave's block, four runs of 4 columns
-        const int r = wr * 32 + l31, m = m0 + r;
-        if (m < g.M) {
-            const float* hrow = g.hyp + (size_t)g.rmap.ea(m) * g.hyp_ld;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c0 = wc * 32 + 8 * q + 4 * hi;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + c0);
-                const f32x4 tg = *reinterpret_cast<const f32x4*>(g.thyp + g.goff + c0), tb = *reinterpret_cast<const f32x4*>(g.thyp + g.boff + c0);
-                const f32x4 hg = *reinterpret_cast<const f32x4*>(hrow + g.goff + c0), hb = *reinterpret_cast<const f32x4*>(hrow + g.boff + c0);
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = fmaf(acc[4 * q + e], kWInv, bv[e]);
-                    o[e] = fmaf(v, sigmoidf_(hg[e] + tg[e]), hb[e] + tb[e]);
-                }
-                *reinterpret_cast<f32x4*>(y4 + r * SM_Y4_LD + c0) = o;
-            }
-        }
-    }
-    __syncthreads();
-    // 64 / tpw pieces of tpw tokens (tpw divides T and 64: a piece lies inside one trajectory), dealt round-robin to the 8 waves
-    typedef const __attribute__((address_space(3))) float* lds_cfp;
-    for (int p = wid; p * tpw < C::BM; p += 8) {
-        const int mp = m0 + p * tpw;
-        if (mp >= g.M) break;
-        out_ddim_piece<EMBED_NEXT>(oa, nxt, mp, tpw, lane, (lds_cfp)(y4 + p * tpw * SM_Y4_LD), SM_Y4_LD);
-    }
-}
-
-// does the tail of a step run as concat3 + this kernel?  (opt-in; one chunk in flight, one workgroup per CU, d_low 128, d_model <= 512)
-inline bool small_out_fits(const GemmHArgs& g, int d_model) {
-    return tune().gemm_small != 1 && tune().gemm_h_variant == 0 && tune().small_now == 1 && tune().small_out == 1 && g.N == 128 &&
-           g.K % 128 == 0 && d_model <= 512 && (g.M + 63) / 64 <= 256;
-}
-template <int MODE>
-inline hipError_t launch_gemm_small_out_mode(const GemmHArgs& g, const OutArgs& oa, const EmbedArgs& nxt, bool embed_next, int T, hipStream_t st) {
-    using C = SmCfg<MODE, 4>;
-    int tpw = 1;
-    while (tpw < 8 && T % (2 * tpw) == 0) tpw *= 2;          // gcd(T, 8): divides T and the 64-row tile, at most one piece per wave
-    static DevSeen attr_seen;
-    if (auto once_ = first_use_on_device(attr_seen)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_out_kernel<MODE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_out_kernel<MODE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    }
-    static_assert(C::LDS_BYTES >= size_t(64) * SM_Y4_LD * 4, "the Y4 tile must fit the ring");
-    const dim3 grid((g.M + 63) / 64);
-    if (embed_next) hipLaunchKernelGGL((gemm_small_out_kernel<MODE, true>), grid, dim3(512), C::LDS_BYTES, st, g, oa, nxt, tpw);
-    else hipLaunchKernelGGL((gemm_small_out_kernel<MODE, false>), grid, dim3(512), C::LDS_BYTES, st, g, oa, nxt, tpw);
-    return hipGetLastError();
-}
-inline hipError_t launch_gemm_small_out(const GemmHArgs& g, const OutArgs& oa, const EmbedArgs& nxt, bool embed_next, int T, hipStream_t st) {
-    if (g.x2 && g.W8) return launch_gemm_small_out_mode<SM_MX>(g, oa, nxt, embed_next, T, st);
-    if (g.x2) return launch_gemm_small_out_mode<SM_X2>(g, oa, nxt, embed_next, T, st);
-    return launch_gemm_small_out_mode<SM_X3>(g, oa, nxt, embed_next, T, st);
-}
-#endif  // JMID_EXPERIMENTS
 
 // bytes all eight XCDs pull from the Infinity Cache with pn column groups: every XCD its column group's share of W and the A rows
 // of its part of the M range
@@ -915,24 +750,6 @@ inline bool small_cmb_fits(int nsplit, int head_dim, int x2) {
     return tune().small_cmb != 2 && tune().attn_h_variant != 1 && nsplit > 1 && nsplit <= 8 && head_dim == 128 && x2;      // (attn_h_variant 1: the register-staged kernel, which does not split)
 }
 
-#ifdef JMID_EXPERIMENTS
-// does the MLP of a layer (linear1 -> ReLU -> linear2 + residual + LayerNorm) run as ONE small launch?  Where linear2 takes OUT_LNX, with
-// ff = 2 d_model.  "small_mlp": 1 on (experiments flavour; measured slower), 0 / 2 off
-inline bool small_mlp_fits(int d_model, int ff) { return tune().small_mlp == 1 && d_model == GLN_BN && ff == 2 * GLN_BN; }
-
-inline hipError_t launch_gemm_small_mlp(const GemmHArgs& g1, const GemmHArgs& g2, hipStream_t st) {
-    using C = SmCfg<SM_MX, 2>;
-    const int ntm = (g2.M + 63) / 64, ntn = 8;
-    static DevSeen attr_seen;
-    if (auto once_ = first_use_on_device(attr_seen))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_small_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS_BYTES);
-    const int pn = tune().small_pn > 0 ? (ntn % tune().small_pn == 0 ? tune().small_pn : 1) : small_pick_groups(g2, ntn, 3.0, 2.0);
-    const int gw = ntn / pn;
-    hipLaunchKernelGGL(gemm_small_mlp_kernel, dim3(ntm * ntn), dim3(256), C::LDS_BYTES, st, g1, g2, ntm, gw,
-                       fast_div_magic(ntm * gw, (unsigned long long)ntm * ntn), fast_div_magic(gw, (unsigned long long)ntm * ntn));
-    return hipGetLastError();
-}
-#endif  // JMID_EXPERIMENTS
 
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch with the statistics exchange (OUT_LNX)?  F16MX at d_model 512,
 // at most 256 tiles of 64 x 64 with nothing else in flight on the handle (the waiting workgroups need their partners resident), at

@@ -429,9 +429,6 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"vt_stage", &Tuning::vt_stage, 0, 3},                 // V^T of the 256x256 QKV kernel through LDS: 0 / 1 on, 2 off
         {"graph", &Tuning::graph, 0, 2},                       // captured denoise loop of one-chunk calls: 1 on, 0 / 2 off
         {"attn_nsplit", &Tuning::attn_nsplit, 0, 16},
-#ifdef JMID_EXPERIMENTS
-        {"tail_fuse", &Tuning::tail_fuse, 0, 2},               // concat3 -> concat4 -> output -> update in one kernel: 1 on, 0 / 2 off
-#endif
         {"attn_mx", &Tuning::attn_mx, 0, 3},
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"attn_pf", &Tuning::attn_pf, 0, 2},
@@ -439,31 +436,14 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"h1_stage", &Tuning::h1_stage, 0, 2},
-#ifdef JMID_EXPERIMENTS
-        {"attn_q64", &Tuning::attn_q64, 0, 1},
-#endif
-#ifdef JMID_EXPERIMENTS
-        {"attn_pp", &Tuning::attn_pp, 0, 3},
-        {"attn_k64", &Tuning::attn_k64, 0, 2},
-        {"attn_sp", &Tuning::attn_sp, 0, 2},
-#endif
         {"gemm_small", &Tuning::gemm_small, 0, 2},             // 1: no deep-ring small-launch GEMM (the round-3 64 x 64 / 128 x 128 shapes)
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
         {"small_lanes", &Tuning::small_lanes, 0, 2},
-#ifdef JMID_EXPERIMENTS
-        {"small_mlp", &Tuning::small_mlp, 0, 2},               // 1: linear1 inside linear2's one-launch GEMM + LayerNorm (measured slower)
-#endif
         {"small_cmb", &Tuning::small_cmb, 0, 2},               // 2: attn_combine_kernel instead of the split-KV merge inside the out-projection's one-launch GEMM + LayerNorm
         {"small_lnx", &Tuning::small_lnx, 0, 2},               // the one-launch GEMM + LayerNorm with the statistics exchange: 0 two exchanges (bit-identical), 1 one exchange, 2 off (GEMM + add_ln2)
         {"small_lnx2", &Tuning::small_lnx2, 0, 2},             // the same at 33 ... 64 row tiles, two workgroups per CU: 0 on, 2 off
-#ifdef JMID_EXPERIMENTS
-        {"small_out", &Tuning::small_out, 0, 2},
-#endif
         {"small_qk", &Tuning::small_qk, 0, 2},
         {"small_pn", &Tuning::small_pn, 0, 8},                 // column groups of its XCD tile order: 0 auto
-#ifdef JMID_EXPERIMENTS
-        {"tail_rows", &Tuning::tail_rows, 0, 64},              // row tile of that kernel: 0 auto, 32, 64          // split-KV factor (head_dim 128): 0 auto, 1..16 forced
-#endif
 #ifdef JMID_ABLATIONS
         {"attn_abl", &Tuning::attn_abl, 0, 1 << 30},           // timing ablations: results are WRONG (tools/attn_abl.py)
         {"gemm_abl", &Tuning::gemm_abl, 0, 1 << 30},
@@ -478,8 +458,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 #ifdef JMID_DIAGNOSTICS
     for (const Knob& kn : knobs)
         if (k == kn.name) {
-            if (value < kn.lo || value > kn.hi || (k == "ln_rows" && value != 0 && value != 64 && value != 128) ||
-                (k == "tail_rows" && value != 0 && value != 32 && value != 64))
+            if (value < kn.lo || value > kn.hi || (k == "ln_rows" && value != 0 && value != 64 && value != 128))
                 return fail(h, JMID_EINVAL, k + " out of range");
             h->tune.*(kn.field) = value;
             drop_graphs(h);          // captured loops hold the kernel variants the old knobs selected

@@ -29,9 +29,6 @@
 #include "gemm_small.hpp"
 #include "gemm_f32.hpp"
 #include "kde.hpp"
-#ifdef JMID_EXPERIMENTS
-#include "tail_f16x3.hpp"      // fused tail of the net: measured slower (docs/NOTEBOOK.md); compiled with -DJMID_EXPERIMENTS only
-#endif
 
 using namespace jmid;
 

@@ -35,20 +35,6 @@ inline int run_gemm_lnx_small(jmid_ctx* h, int cls, GemmHArgs& g) {
     return 0;
 }
 
-#ifdef JMID_EXPERIMENTS
-// linear1 -> ReLU -> linear2 + residual + LayerNorm as ONE small launch (gemm_small.hpp, gemm_small_mlp_kernel): g1 linear1 as for its own
-// launch (OUT_SPLIT into the hidden plane), g2 linear2 as for run_gemm_lnx_small
-inline int run_gemm_mlp_small(jmid_ctx* h, int cls, GemmHArgs& g1, GemmHArgs& g2) {
-    g1.range_flag = g2.range_flag = h->range_flag;
-    g1.x2 = g2.x2 = h->x2;
-    if (++h->lnx_epoch == 0) h->lnx_epoch = 1;
-    g2.ln_epoch = h->lnx_epoch;
-    g2.ln_one = tune().small_lnx == 1;
-    ProfScope ps(h, cls);
-    HIPCHK(h, launch_gemm_small_mlp(g1, g2, h->stream));
-    return 0;
-}
-#endif
 
 // JMID_PREC_F16MX: hand the GEMM the fp8 image of this weight's lo plane (the kernels that have no fp8 path ignore it)
 inline void set_w8(jmid_ctx* h, GemmHArgs& g, const std::string& name) {

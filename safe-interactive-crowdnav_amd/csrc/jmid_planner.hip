@@ -109,8 +109,6 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
     // embed_done: the previous step's output kernel already embedded x for this step; next_step >= 0: this step's
     // output kernel does the same for step `next_step` (same chunk, same buffers)
     const bool split = precision != JMID_PREC_F32;
-    bool tail_fused = false, out_fused = false;
-    GemmHArgs g4{};
     const int R = Ec * K * A, M = R * T;
     const int d = h->d, ff = h->ff;
     const float* thyp = h->thyp + (size_t)step_idx * h->hl.total;
@@ -275,24 +273,6 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             g.Ahi = sb.Xh; g.Alo = sb.Xl; g.Whi = w1.hi; g.Wlo = w1.lo;
             set_w8(h, g, p + ".linear1.weight");
             g.bias = W(h, p + ".linear1.bias"); g.Chi = sb.H1h; g.Clo = sb.H1l; g.ldc = ff; g.N = ff; g.K = d;
-#ifdef JMID_EXPERIMENTS
-            // one scene in F16MX: the whole MLP in ONE launch (gemm_small.hpp, gemm_small_mlp_kernel) where linear2 would take the
-            // one-launch GEMM + LayerNorm (experiment "small_mlp" = 1: bit-identical, measured slower)
-            const bool mlp_one = mxv2 && !ln_fused && !h->lnx_off && small_lnx_fits(M, ff) == 2 && small_mlp_fits(d, ff) && g.W8;
-            if (mlp_one) {
-                GemmHArgs g2 = g;
-                const HalfPair& w2 = h->wsplit[p + ".linear2.weight"];
-                g2.Ahi = sb.H1h; g2.Alo = sb.H1l; g2.Whi = w2.hi; g2.Wlo = w2.lo;
-                set_w8(h, g2, p + ".linear2.weight");
-                g2.bias = W(h, p + ".linear2.bias"); g2.C = sb.Y; g2.ldc = d; g2.N = d; g2.K = ff;
-                g2.cmb_O = nullptr;
-                g2.ln_gamma = W(h, p + ".norm2.weight"); g2.ln_beta = W(h, p + ".norm2.bias"); g2.ln_xh = sb.Xh; g2.ln_xl = nullptr;
-                g2.ln_xl8 = Xl8; g2.ln_xchg = sb.ln_xchg; g2.ln_eps = 1e-5f; g2.ln_no_lo = mxv2 && l + 1 == h->tf_layer;
-                if (!g2.W8) return fail(h, JMID_EINVAL, "linear2 has no fp8 image");
-                if (int rc = run_gemm_mlp_small(h, KC_GEMM_FF2, g, g2)) return rc;
-                continue;
-            }
-#endif
             if (int rc = (run_gemm_h<EPI_BIAS_RELU, OUT_SPLIT>(h, KC_GEMM_FF1, g))) return rc;
             if (ln_fused && mxv2) {
                 GemmLn2Args g2{sb.H1h, h->w16[p + ".linear2.weight"].hi, h->w8[p + ".linear2.weight"].p, W(h, p + ".linear2.bias"),
@@ -330,14 +310,9 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
                 }
             }
         }
-        // concat3 -> concat4 -> output layer -> sampler update -> next embedding in ONE kernel (tail_f16x3.hpp; bit-identical
-        // to the three launches below it replaces) at the shipped width.  Opt-in: it saves two launches per step but runs
-        // four waves per CU, and measured slower than the three well-occupied kernels at every batch size (one scene
-        // 13.65 vs 13.23 ms per call, a 51-episode chunk +1.3 %; tools/single_scene_sweep.py tail_fuse=2,1)
-#ifdef JMID_EXPERIMENTS
-        tail_fused = d == TAIL_D && h->dmid == TAIL_DM && h->dlow == TAIL_DL && tune().tail_fuse == 1 && !h->mx;   // the fused kernel has no fp8-correction K loop
-#endif
-        if (!tail_fused) {
+        // concat3 -> concat4 as two launches, the output layer + sampler update + next embedding as a third (one fused kernel for all
+        // three was built in round 3 and measured slower at every batch size: docs/NOTEBOOK.md)
+        {
         GemmHArgs g{};
         g.rmap = rm; g.hyp = hyp_chunk; g.thyp = thyp; g.hyp_ld = h->hl.total; g.M = M;
         const HalfPair& w3 = h->wsplit["concat3._layer.weight"];
@@ -351,17 +326,12 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
         set_w8(h, g, "concat4._layer.weight");
         g.bias = W(h, "concat4._layer.bias"); g.C = sb.Y4; g.ldc = h->dlow; g.N = h->dlow; g.K = h->dmid;
         g.goff = h->hl.g4; g.boff = h->hl.b4;
-        // a small launch runs concat4 together with everything behind it (gemm_small_out_kernel, below)
         g.x2 = h->x2; g.range_flag = h->range_flag;
-#ifdef JMID_EXPERIMENTS
-        out_fused = small_out_fits(g, d);
-#endif
-        if (out_fused) g4 = g;
-        else if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
+        if (int rc = (run_gemm_h<EPI_CSL, OUT_F32>(h, KC_GEMM_TAIL, g))) return rc;
         }
     }
     {
-        ProfScope ps(h, tail_fused ? KC_GEMM_TAIL : KC_OUT_DDIM);
+        ProfScope ps(h, KC_OUT_DDIM);
         OutArgs oa{sb.Y4, W(h, "linear._layer.weight"), W(h, "linear._layer.bias"), hyp_chunk, thyp, x_chunk, e_out,
                    M, h->dlow, h->hl.total, h->hl.go, h->hl.bo,
                    h->c_e[step_idx], h->c_x[step_idx], h->n_x[step_idx], h->n_e[step_idx], rm,
@@ -373,22 +343,6 @@ int net_step(jmid_ctx* h, const StepBuffers& sb, int Ec, int A, int K, int T, in
             oa.c1 = h->p_c1[step_idx];
             oa.sigma = h->p_sigma[step_idx];
         }
-#ifdef JMID_EXPERIMENTS
-        if (out_fused) {
-            const bool en = next_step >= 0 && !e_out;
-            HIPCHK(h, launch_gemm_small_out(g4, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, T, h->stream));
-        } else if (tail_fused) {
-            const HalfPair& w3 = h->w16["concat3._layer.weight"];
-            const HalfPair& w4 = h->w16["concat4._layer.weight"];
-            TailArgs ta{sb.Xh, sb.Xl, w3.hi, w3.lo, w4.hi, w4.lo, W(h, "concat3._layer.bias"), W(h, "concat4._layer.bias"),
-                        hyp_chunk, thyp, h->hl.total, h->hl.g3, h->hl.b3, h->hl.g4, h->hl.b4, rm, M, h->range_flag};
-            const bool en = next_step >= 0 && !e_out;
-            // 32-row tiles while 64-row ones would leave CUs idle (a few scenes), 64-row tiles otherwise
-            const int rows = tune().tail_rows ? tune().tail_rows : (M < 64 * 256 ? 32 : 64);
-            HIPCHK(h, launch_tail(ta, oa, en ? embed_args(h->thyp + (size_t)next_step * h->hl.total) : EmbedArgs{}, en, rows,
-                                  h->x2 != 0, h->stream));
-        } else
-#endif
         if (d <= 512 && M % T == 0 && tune().out_traj != 2 && (tune().out_traj == 1 || M >= 4096 * 4)) {
             // one wave per trajectory (T tokens) - or per piece of one, the largest divisor of T that still leaves >= 4096 waves -
             // once there are enough tokens to fill the chip that way: one scene (100 trajectories) takes 14.0 instead of

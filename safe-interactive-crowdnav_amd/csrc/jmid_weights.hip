@@ -261,12 +261,6 @@ int jmid_finalize_weights(jmid_handle_t h) {
                 k16names.push_back(p + ".self_attn.out_proj.weight");
                 k16names.push_back(p + ".linear2.weight");
             }
-#ifdef JMID_EXPERIMENTS      // (the fused tail's k16 panels of concat3 / concat4)
-            if (h->dmid == TAIL_DM && h->dlow == TAIL_DL) {
-                k16names.push_back("concat3._layer.weight");
-                k16names.push_back("concat4._layer.weight");
-            }
-#endif
             {
                 for (const std::string& nm : k16names) {
                     const DevBuf& b = h->w[nm];

@@ -11,9 +11,6 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 # same kernels as the production libjmid_hip.so, which smoke(), bench.py and tests/test_gpu_production_lib.py run on
 PROD_LIB = os.path.join(REPO, "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
 DIAG_LIB = os.path.join(REPO, "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_diag.so")
-# the experiments flavour (kernels that measured slower, kept for the record: -DJMID_EXPERIMENTS) is built on request only
-# (`python safe-interactive-crowdnav_amd/build.py experiments`); the tests that drive those kernels skip without it
-EXP_LIB = os.path.join(REPO, "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_exp.so")
 os.environ.setdefault("JMID_LIB", DIAG_LIB)
 
 

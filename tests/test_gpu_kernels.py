@@ -142,9 +142,6 @@ def test_f16mx_fused_gemm_layernorm_gen2_matches_float64_and_its_unfused_pair(M,
     np.testing.assert_array_equal(fused, pair)
 
 
-EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_exp.so")
-needs_experiments = pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="the experiments flavour is not built "
-                                       "(python safe-interactive-crowdnav_amd/build.py experiments)")
 
 
 @pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128), (1, 512),
@@ -182,25 +179,3 @@ def test_small_launch_gemm_with_statistics_exchange_equals_its_unfused_pair(M, K
     ref = (v - v.mean(1, keepdims=True)) / np.sqrt(v.var(1, keepdims=True) + 1e-5) * g + t
     assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
 
-
-@needs_experiments
-@pytest.mark.parametrize("precision", ["f16mx", "f16x2", "f16x3"])
-@pytest.mark.parametrize("A,K,T,steps", [(5, 20, 12, 4), (3, 100, 8, 2), (2, 7, 6, 2), (1, 3, 5, 2)])
-def test_small_launch_tail_in_one_kernel_equals_its_unfused_pair(precision, A, K, T, steps):
-    """gemm_small_out_kernel (opt-in knob small_out = 1: concat4 + output layer + DDIM update + next embedding in ONE launch,
-    the gated Y4 tile in LDS) against the default chain (concat4's launch + out_ddim_kernel): every word of the velocities and
-    the positions, for pieces of 4 / 8 / 2 / 1 tokens (T = 12 / 8 / 6 / 5) and row counts that end inside a 64-row tile."""
-    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 2), joint=True, step=steps, lib_path=EXP_LIB)
-    try:
-        g = torch.Generator().manual_seed(A * 1000 + K)
-        ctx = torch.randn([1, A, 256], generator=g).cuda()
-        x_T = torch.randn([1, K * A, T, 2], generator=g).cuda()
-        p0 = torch.randn([1, A, 2], generator=g).cuda()
-        ref = [t.clone() for t in eng.denoise(x_T, ctx, p0, precision=precision)]
-        eng.set_tuning("small_out", 1)
-        got = eng.denoise(x_T, ctx, p0, precision=precision)
-        for a, b in zip(got, ref):
-            assert torch.equal(a, b)
-        assert eng.erange_count() == 0
-    finally:
-        eng.close()

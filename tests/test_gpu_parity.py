@@ -17,9 +17,6 @@ from safe_interactive_crowdnav_amd.engine import JmidEngine
 from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip_exp.so")
-needs_experiments = pytest.mark.skipif(not os.path.exists(EXP_LIB), reason="the experiments flavour is not built "
-                                       "(python safe-interactive-crowdnav_amd/build.py experiments)")
 PROD_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "safe-interactive-crowdnav_amd", "csrc", "libjmid_hip.so")
 ADE_GATE = 1e-4
 PRECISIONS = ["f32", "f16x3", "f16x2", "f16mx"]
@@ -42,7 +39,7 @@ def get_engine(ctx_dim, wseed, joint, flavour="diag"):
     key = (ctx_dim, wseed, joint, flavour)
     if key not in _ENGINES:
         w = JMIDWeights.from_seed(NetDims(ctx_dim=ctx_dim), wseed)
-        _ENGINES[key] = (JmidEngine(w, joint=joint, lib_path={"prod": PROD_LIB, "exp": EXP_LIB}.get(flavour)), w)
+        _ENGINES[key] = (JmidEngine(w, joint=joint, lib_path={"prod": PROD_LIB}.get(flavour)), w)
         assert _ENGINES[key][0]._lib.has_diagnostics == (flavour != "prod")
     return _ENGINES[key]
 
@@ -459,30 +456,6 @@ def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
     assert ade(out[3], z["vel"]) <= ADE_GATE
 
 
-@needs_experiments
-@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w256_a7k9t24_s10.npz", "net_imid_w256_a5k20t12_s50.npz",
-                                  "net_jmid_w256_a2k3t4_s2.npz"])
-def test_one_scene_mlp_in_one_launch_is_bit_identical(case):
-    """One scene in F16MX: linear1 -> ReLU -> linear2 + residual + LayerNorm as ONE launch (gemm_small.hpp, gemm_small_mlp_kernel: every
-    workgroup two 64 x 64 blocks of the hidden rows, written through, a flag, then linear2's one-launch GEMM + LayerNorm on the complete
-    rows) against linear1's own launch followed by that launch: the same operations per element, the same bits - over whole denoise
-    loops, call after call on one handle, also when the rows end inside a 64-row tile (M = 24: one partial tile; M = 1512).
-    An experiment (knob small_mlp = 1, experiments flavour): measured slower - linear1 on 4-wave workgroups, two cold K loops in a row."""
-    z = np.load(os.path.join(GOLDEN, case))
-    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]), "exp")
-    eng.set_step(int(z["step"]), "ddim")
-    out = []
-    try:
-        for knob in (0, 1, 1, 1, 0):
-            eng.set_tuning("small_mlp", knob)
-            out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16mx", want_pos=False)[0][0])
-    finally:
-        eng.set_tuning("small_mlp", 0)
-    for o in out[1:]:
-        np.testing.assert_array_equal(o, out[0])
-    assert ade(out[1], z["vel"]) <= ADE_GATE
-
-
 @pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_jmid_w256_a7k9t24_s10.npz"])
 def test_one_scene_split_kv_merge_inside_the_out_projection_launch_is_bit_identical(case, precision):
@@ -525,38 +498,6 @@ def test_output_kernel_with_fused_next_embedding_is_bit_identical(case, precisio
         eng.set_tuning("fuse_embed", 1)
         eng.set_step(int(z["step"]), "ddim")
     np.testing.assert_array_equal(out[0], out[1])
-
-
-@pytest.mark.parametrize("precision", SPLIT_MODES)
-@pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz",
-                                  "net_jmid_w256_a7k9t24_s10.npz", "ddpm_jmid_w256_a5k20t12_s10.npz"])
-@needs_experiments
-def test_fused_tail_kernel_is_bit_identical_to_the_three_launches(case, precision):
-    """tail_f16x3_kernel (concat3 -> concat4 -> output layer -> DDIM / DDPM update -> next embedding, intermediates in
-    LDS) against concat3 GEMM + concat4 GEMM + out_ddim_kernel: same arithmetic in the same order, for both row tiles,
-    for the sampling loop and for a single net evaluation (e_theta out, no update)."""
-    z = np.load(os.path.join(GOLDEN, case))
-    eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]), "exp")
-    ddpm = case.startswith("ddpm")
-    eng.set_step(int(z["step"]), "ddpm" if ddpm else "ddim")
-    kw = {"z": z["z"][:, None]} if ddpm else {}
-    out, e = {}, {}
-    try:
-        for fuse, rows in ((2, 0), (1, 32), (1, 64), (1, 0)):
-            eng.set_tuning("tail_fuse", fuse)
-            eng.set_tuning("tail_rows", rows)
-            out[(fuse, rows)] = eng.denoise(z["x_T"][None], z["ctx"][None], precision=precision, want_pos=False, **kw)[0][0]
-            if not ddpm:
-                e[(fuse, rows)] = eng.net_eval(z["x_T"][None], z["ctx"][None], step_idx=0, precision=precision)[0]
-    finally:
-        eng.set_tuning("tail_fuse", 0)
-        eng.set_tuning("tail_rows", 0)
-        eng.set_step(int(z["step"]), "ddim")
-    for k in ((1, 32), (1, 64), (1, 0)):
-        np.testing.assert_array_equal(out[k], out[(2, 0)])
-        if not ddpm:
-            np.testing.assert_array_equal(e[k], e[(2, 0)])
-    assert ade(out[(1, 0)], z["vel"]) <= ADE_GATE
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)
@@ -612,90 +553,6 @@ def test_linear1_tile_through_lds_is_bit_identical_to_the_elementwise_epilogue()
     with torch.no_grad():
         ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True)
     assert ade(out[(0, 0)][:2], ref.numpy()) <= ADE_GATE
-
-
-@pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (16, 3, 7, 5), (14, 2, 9, 7)])
-@needs_experiments
-def test_attention_q64_equals_the_two_wave_kernel(E, A, K, T):
-    """The one-wave-per-SIMD attention experiment (attn_q64.hpp, knob "attn_q64" = 1: two query blocks per wave, the softmax of tile t
-    in the gaps of the matrix instructions of tile t + 1) performs attn_f16x3_dma_kernel's operations in its order: bit-identical
-    outputs on S = 1200 (37.5 key tiles, the last wave of a sequence half empty), S = 105 and S = 126 (one 256-query workgroup per
-    sequence and head with idle waves, a partial last key tile) - nn.MultiheadAttention inside the encoder layers of
-    MID/models/diffusion.py:161-166."""
-    eng, w = get_engine(256, 23, True, "exp")
-    eng.set_step(4)
-    g = torch.Generator().manual_seed(13 + E)
-    ctx = torch.randn([E, A, 256], generator=g).cuda()
-    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
-    out = {}
-    try:
-        for v in (0, 1):
-            eng.set_tuning("attn_q64", v)
-            eng.set_tuning("attn_nsplit", 1)        # (the experiment has no key split: both arms unsplit)
-            out[v] = eng.denoise(x_T, ctx, precision="f16mx", want_pos=False)[0].cpu().numpy()
-    finally:
-        eng.set_tuning("attn_q64", 0)
-        eng.set_tuning("attn_nsplit", 0)
-    np.testing.assert_array_equal(out[1], out[0])
-    with torch.no_grad():
-        ref = O.denoise(w.tensors, ctx[:2].cpu(), x_T[:2].cpu(), sample=K, step=4, joint=True)
-    assert ade(out[0][:2], ref.numpy()) <= ADE_GATE
-
-
-@needs_experiments
-@pytest.mark.parametrize("precision", SPLIT_MODES)
-@pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (3, 3, 7, 5), (2, 25, 16, 12), (1, 5, 20, 12)])
-def test_attention_pingpong_equals_the_two_wave_kernel(E, A, K, T, precision):
-    """attn_pp_kernel (experiment, knob "attn_pp" = 1: 8-wave workgroups whose two halves alternate between a matrix-instruction segment
-    and a softmax / copy segment across s_barrier, three-stage K / V^T ring; csrc/attn_pp.hpp) issues attn_f16x3_dma_kernel's matrix
-    instructions per accumulator in its order: bit-identical outputs in every split mode, with and without a key split (one scene),
-    on S = 1200, 105, 4800 (dense) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
-    eng, w = get_engine(256, 23, True, "exp")
-    eng.set_step(4)
-    g = torch.Generator().manual_seed(17 + E)
-    ctx = torch.randn([E, A, 256], generator=g).cuda()
-    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
-    out = {}
-    try:
-        for v in (2, 1):
-            eng.set_tuning("attn_pp", v)
-            out[v] = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
-    finally:
-        eng.set_tuning("attn_pp", 0)
-    np.testing.assert_array_equal(out[1], out[2])
-    with torch.no_grad():
-        ref = O.denoise(w.tensors, ctx[:1].cpu(), x_T[:1].cpu(), sample=K, step=4, joint=True)
-    assert ade(out[1][:1], ref.numpy()) <= ADE_GATE
-
-
-@needs_experiments
-@pytest.mark.parametrize("precision", ["f16mx", "f16x2"])
-@pytest.mark.parametrize("knob,value", [("attn_k64", 1), ("attn_sp", 1), ("attn_sp", 2), ("attn_pp", 3)])
-@pytest.mark.parametrize("E,A,K,T", [(19, 5, 20, 12), (3, 3, 7, 5), (2, 25, 16, 12), (9, 5, 20, 11)])
-def test_restructured_attention_kernels_equal_the_32_key_kernel(E, A, K, T, knob, value, precision):
-    """Four experiments on the head-dim-128 attention of F16MX / F16X2 (csrc/attn_k64.hpp, attn_sp.hpp, attn_sp2.hpp, attn_pp2.hpp), each running the
-    shipped kernel's instructions per accumulator in its order: "attn_k64" = 1 - two softmax rounds per 64-key tile, their P.V products
-    behind one wait and one barrier; "attn_sp" = 1 - P.V of tile t - 1 between the logits' matrix instructions of tile t (three-stage
-    ring); "attn_sp" = 2 - the full in-wave pipeline: logits(t + 1) + P.V(t - 1) with the softmax of tile t cut into 17 atoms in their
-    gaps, two score accumulators, loop unrolled six times; "attn_pp" = 3 - the 8-wave ping-pong rebuilt on attn_sp's matrix phase, copies
-    three segments ahead by one of the two wave groups, four-stage rings.  Bit-identical outputs on S = 1200, 105, 4800 (dense) and 1100 (an odd
-    number of 32-key tiles) - the SDPA of nn.MultiheadAttention, MID/models/diffusion.py:161-166."""
-    eng, w = get_engine(256, 23, True, "exp")
-    eng.set_step(4)
-    g = torch.Generator().manual_seed(41 + E)
-    ctx = torch.randn([E, A, 256], generator=g).cuda()
-    x_T = torch.randn([E, K * A, T, 2], generator=g).cuda()
-    out = {}
-    try:
-        for v in (0, value):
-            eng.set_tuning(knob, v)
-            out[v] = eng.denoise(x_T, ctx, precision=precision, want_pos=False)[0].cpu().numpy()
-    finally:
-        eng.set_tuning(knob, 0)
-    np.testing.assert_array_equal(out[value], out[0])
-    with torch.no_grad():
-        ref = O.denoise(w.tensors, ctx[:1].cpu(), x_T[:1].cpu(), sample=K, step=4, joint=True)
-    assert ade(out[value][:1], ref.numpy()) <= ADE_GATE
 
 
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),

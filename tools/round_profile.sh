@@ -59,7 +59,6 @@ if [ -x build/concurrency_probe8 ]; then for c in 3 1 0; do timeout 300 ./build/
 # "before" half, build/concurrency_probe9_scaled: the same probe built with -DPROBE_SCALED_MFMA)
 if [ -x build/concurrency_probe9 ]; then (timeout 300 ./build/concurrency_probe9 40 | grep -v "hi plane\|tiles with"; if [ -x build/concurrency_probe9_scaled ]; then echo "--- the same with the SCALED instruction pair (v_mfma_ld_scale_b32 + v_mfma_scale_f32_32x32x64_f8f6f4)"; timeout 300 ./build/concurrency_probe9_scaled 40 | grep -v "hi plane\|tiles with"; fi) > $O/scaled_mfma_probe.log 2>&1; fi
 # round 5: the 8-wave ping-pong attention experiment against the shipped kernel (bitwise + time per launch, three operand sets; cycle stamps)
-if [ -x build/attn_pp_check ]; then (for m in 0 1 2; do echo "== operand set $m (0 = F16MX, 1 = F16X2, 2 = F16X3)"; timeout 120 ./build/attn_pp_check 51 1200 20 $m | grep -v amdgpu; done; if [ -x build/attn_pp_check_trace ]; then echo "== cycle stamps (F16MX)"; timeout 120 ./build/attn_pp_check_trace 51 1200 10 0 | grep -v amdgpu | grep -A7 "^trace"; AQ_TRACE_TWO_WAVE=1 timeout 120 ./build/attn_pp_check 51 1200 5 0 | grep -A8 "two-wave kernel, traced"; fi) > $O/attn_pp_check.log 2>&1; fi
 # where each arithmetic mode leaves the gate, incl. the two extreme cells (no JMID_ERANGE anywhere)
 timeout 900 python tools/robustness_sweep.py --out $O/robustness.json > $O/robustness.log 2>&1
 # lanes 1 / 2 / 3 on the default batch
