@@ -209,16 +209,30 @@ def compact_line(full, detail_path):
                                "modes": {m: t["ms_per_call"] for m, t in ss["modes"].items()}}
     if full.get("sweep_metrics"):
         out["sweep_episodes"] = full["sweep_metrics"]["episodes"]
+        out["rows_in_episode_order"] = full["sweep_metrics"].get("rows_in_episode_order")
+    if full.get("rank0_affinity"):
+        out["rank0_affinity"] = full["rank0_affinity"]
     if full.get("host_feed"):
         out["host_feed_ms"] = full["host_feed"]["ms"]
     out["detail"] = os.path.relpath(detail_path, REPO) if os.path.abspath(detail_path).startswith(REPO) else detail_path
     line = json.dumps(out, separators=(",", ":"))
-    for drop in ("single_scene", "hbm", "per_rank_ms_per_step"):          # never exceed the limit: shed the optional blocks
+    # never exceed the limit and never lose the line: shed the optional blocks one by one, then the notes inside the kept ones, and
+    # at the very end fall back to the contract keys alone (the driver parses this line; everything is in `detail` anyway)
+    for drop in ("single_scene", "hbm", "per_rank_ms_per_step", "rank0_affinity", "host_feed_ms", "gather_ms", "modes", "parity"):
         if len(line) <= COMPACT_LIMIT:
             break
         out.pop(drop, None)
         line = json.dumps(out, separators=(",", ":"))
-    assert len(line) <= COMPACT_LIMIT, len(line)
+    if len(line) > COMPACT_LIMIT:
+        for blk, keys in (("cpu_baseline", ("value", "unit", "cores", "kind", "sample")),
+                          ("roofline", ("bound", "achieved", "peak", "unit", "frac", "traffic"))):
+            if isinstance(out.get(blk), dict):
+                out[blk] = {k: (str(out[blk][k])[:120] if isinstance(out[blk][k], str) else out[blk][k]) for k in keys if k in out[blk]}
+        out["config"] = {"workload": str(out["config"].get("workload"))[:160], "precision": out["config"].get("precision")}
+        line = json.dumps(out, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:
+        line = json.dumps({k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                               "scaling", "vs_baseline", "detail") if k in out}, separators=(",", ":"))
     json.loads(line)
     return line
 
@@ -247,6 +261,68 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rcs = [p.wait() for p in procs]
     return max((abs(rc) for rc in rcs), default=0)
+
+
+def _cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist) -> sorted list of ints."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(out)
+
+
+def rank_cpu_share(allowed, local_rank, local_world, numa_of_rank=None, cpus_of_node=None):
+    """The host cores of one rank of a multi-rank launch: with NUMA information (``numa_of_rank[r]`` = node of rank r's GPU,
+    ``cpus_of_node[n]`` = that node's cores) the ranks whose GPUs hang off one node split THAT node's allowed cores evenly, in rank
+    order; without it (or when a node has fewer allowed cores than ranks) the allowed cores are split into ``local_world`` contiguous
+    shares.  Never empty, never outside ``allowed``; shares of different ranks are disjoint whenever there are enough cores."""
+    allowed = sorted(allowed)
+
+    def split(cores, k, n):
+        base, rem = divmod(len(cores), n)
+        lo = k * base + min(k, rem)
+        return cores[lo: lo + base + (1 if k < rem else 0)]
+
+    if numa_of_rank and cpus_of_node and numa_of_rank[local_rank] is not None and numa_of_rank[local_rank] >= 0:
+        node = numa_of_rank[local_rank]
+        peers = [r for r in range(local_world) if numa_of_rank[r] == node]
+        cores = [c for c in cpus_of_node.get(node, []) if c in set(allowed)]
+        if len(cores) >= len(peers):
+            return split(cores, peers.index(local_rank), len(peers))
+    if len(allowed) >= local_world:
+        return split(allowed, local_rank, local_world)
+    return allowed
+
+
+def pin_rank(local_rank, local_world, dev_of_rank):
+    """Per-rank CPU placement of a multi-rank launch (the driver's `torch.distributed.run` gives every rank the whole machine): this
+    process - its launch loop, its 512 `torch.randn` calls per step, torch's intra-op threads - is confined to its share of the cores,
+    on the NUMA node of its GPU when sysfs says which (/sys/bus/pci/devices/<bdf>/numa_node).  Returns what was done, for the JSON."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    numa, nodes = [None] * local_world, {}
+    try:
+        for r in range(local_world):
+            p = torch.cuda.get_device_properties(dev_of_rank(r))
+            bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+            with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
+                numa[r] = int(fh.read().strip())
+        for n in {v for v in numa if v is not None and v >= 0}:
+            with open(f"/sys/devices/system/node/node{n}/cpulist") as fh:
+                nodes[n] = _cpulist(fh.read())
+    except (OSError, AttributeError, ValueError):
+        numa, nodes = None, None
+    allowed = sorted(os.sched_getaffinity(0))
+    share = rank_cpu_share(allowed, local_rank, local_world, numa, nodes)
+    try:
+        os.sched_setaffinity(0, share)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(len(share), 8)))
+    return {"cores": len(share), "first": share[0], "last": share[-1], "numa_node": numa[local_rank] if numa else None}
 
 
 def cpu_worker(job):
@@ -418,6 +494,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev_id = local_rank if args.device < 0 else args.device
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    affinity = pin_rank(local_rank, local_world, (lambda r: r) if args.device < 0 else (lambda r: args.device))
     torch.cuda.set_device(dev_id)
     dev = torch.device("cuda", dev_id)
     dist = None
@@ -567,6 +645,9 @@ def main():
             rank_ms = [1e3 * float(v.item()) / args.steps for v in every]
         # the sweep's ONE collective: the per-episode metric rows of the last step, gathered to rank 0 after the timed steps
         #  and timed on its own - it is off the data path and says nothing about the kernels
+        # (a fifth column, added outside the timed steps: the GLOBAL index of the episode a row belongs to, so that rank 0 can see that
+        #  the gathered rows are in episode order)
+        met = torch.cat([met, torch.arange(ep_lo, ep_lo + met.shape[0], device=met.device, dtype=met.dtype)[:, None]], dim=1)
         tg = time.perf_counter()
         allm = gather_metrics(met, total_eps, force=args.force_dist)
         gather_ms = 1e3 * (time.perf_counter() - tg)
@@ -628,7 +709,8 @@ def main():
         if rank == 0:
             res["sweep_metrics"] = {"episodes": int(allm.shape[0]), "mean_ADE_m": float(np.nanmean(allm[:, 0])),
                                     "mean_minADE_m": float(np.nanmean(allm[:, 1])),
-                                    "mean_FDE_m": float(np.nanmean(allm[:, 2]))}
+                                    "mean_FDE_m": float(np.nanmean(allm[:, 2])),
+                                    "rows_in_episode_order": bool(np.array_equal(allm[:, -1], np.arange(allm.shape[0], dtype=allm.dtype)))}
         return res, pos
 
     log(f"inputs resident: E={E} A={A} K={K} H={H} modes={modes} world={world} backend={args.dist_backend}")
@@ -684,6 +766,7 @@ def main():
         "value": head["value"], "unit": "traj/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": scaling,
         "ranks_seen": head["ranks_seen"], "per_rank_ms_per_step": head["per_rank_ms_per_step"], "gather_ms": head["gather_ms"],
+        "rank0_affinity": affinity,
         "vs_baseline": None, "dtype": head["dtype"], "data": "synthetic",
         "config": {"workload": (f"{args.workload}: {E} episodes/GPU" if scaling == "weak" else
                                 f"cfg5-style strong scaling: {total_eps} episodes in total, block-partitioned over {world} GPU(s) "

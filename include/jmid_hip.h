@@ -65,8 +65,8 @@ enum { JMID_MEM_HOST = 0, JMID_MEM_DEVICE = 1 };
  *                     take the same path (bf8 images of K from the QKV GEMM, of Q made in the kernel), and P.V is one MFMA per
  *                     product: P_hi . V_hi with P rounded to nearest - the one rounding every other activation of the mode gets.
  *                     ~20 % more trajectories per second than F16X2.
- *                     Bit-identical across chunk plans like the other modes.  What bench.py quotes; an explicit opt-in of the Python
- *                     class (precision="f16mx"), whose default is JMID_PREC_F16X3.
+ *                     Bit-identical across chunk plans like the other modes.  What bench.py quotes, and since round 6 the default of
+ *                     the Python class (together with its first-call self check against JMID_PREC_F16X3).
  *   JMID_PREC_F16     single fp16 MFMA (11 bits; does NOT meet the 1e-4 ADE gate, reported only; not built) */
 enum { JMID_PREC_F32 = 0, JMID_PREC_F16X3 = 1, JMID_PREC_F16 = 2, JMID_PREC_F16X2 = 3, JMID_PREC_F16MX = 4 };
 
@@ -76,7 +76,11 @@ enum {
     JMID_ENOWEIGHT = -2,  /* a required weight has not been loaded */
     JMID_EHIP = -3,       /* HIP runtime error */
     JMID_ENOMEM = -4,
-    JMID_ERANGE = -5      /* F16X3/F16X2/F16MX: an operand left the fp16 range; rerun with JMID_PREC_F32 */
+    JMID_ERANGE = -5,     /* F16X3/F16X2/F16MX: an operand left the fp16 range; rerun with JMID_PREC_F32 */
+    JMID_ETIMEOUT = -6    /* a workgroup of a one-launch GEMM + LayerNorm (small F16MX calls) gave up waiting for its partner workgroups -
+                             not all of the launch was resident on the GPU (another process or stream held compute units).  Nothing to do
+                             with the arithmetic: the outputs are undefined, the handle runs the unfused kernels from now on (same bits,
+                             ~0.6 ms more per 50-step one-scene call); repeat the call in the SAME precision.  Counted: jmid_timeout_count */
 };
 
 /* Library / build identification (also the cheap "does it load" probe). */
@@ -209,6 +213,9 @@ int64_t jmid_graph_replays(jmid_handle_t h);
  * throughout, MID/models/diffusion.py:478-541, so the result is unchanged and only the latency differs); -1 for a null handle.
  * A deployment with trained weights reads this to see how often the slow path fires. */
 int64_t jmid_erange_count(jmid_handle_t h);
+/* Number of calls on this handle that ended with JMID_ETIMEOUT (at most one per handle in practice: the first one switches the handle
+ * to the unfused kernels for good); -1 for a null handle. */
+int64_t jmid_timeout_count(jmid_handle_t h);
 
 /* ---- tuning / measurement ------------------------------------------------------------------ */
 /* Episodes processed together per pass of the 50-step loop (0 = automatic: a whole number of rounds of the attention

@@ -15,7 +15,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 PREC_F32, PREC_F16X3, PREC_F16, PREC_F16X2, PREC_F16MX = 0, 1, 2, 3, 4
 PRECISIONS = {"f32": PREC_F32, "f16x3": PREC_F16X3, "f16": PREC_F16, "f16x2": PREC_F16X2, "f16mx": PREC_F16MX}
 
-ERR_NAMES = {-1: "JMID_EINVAL", -2: "JMID_ENOWEIGHT", -3: "JMID_EHIP", -4: "JMID_ENOMEM", -5: "JMID_ERANGE"}
+ERR_NAMES = {-1: "JMID_EINVAL", -2: "JMID_ENOWEIGHT", -3: "JMID_EHIP", -4: "JMID_ENOMEM", -5: "JMID_ERANGE", -6: "JMID_ETIMEOUT"}
 
 # name -> (restype, argtypes): every symbol declared in include/jmid_hip.h
 SIGNATURES = {
@@ -46,6 +46,7 @@ SIGNATURES = {
     "jmid_set_caller_stream": (C.c_int, [Handle, C.c_void_p]),
     "jmid_graph_replays": (C.c_int64, [Handle]),
     "jmid_erange_count": (C.c_int64, [Handle]),
+    "jmid_timeout_count": (C.c_int64, [Handle]),
     "jmid_profile_enable": (C.c_int, [Handle, C.c_uint32]),
     "jmid_profile_reset": (C.c_int, [Handle]),
     "jmid_profile_get": (C.c_int, [Handle, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

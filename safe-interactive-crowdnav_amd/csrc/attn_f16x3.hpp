@@ -31,6 +31,11 @@ __device__ __forceinline__ unsigned int pk_f16_rne(float a, float b) {
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_{a, b}, f16x2));
 }
+// acc + lo(pair) + hi(pair) of a packed fp16 pair, in fp32: ONE v_dot2_f32_f16 against {1, 1}
+__device__ __forceinline__ float dot2_ones(unsigned int pair, float acc) {
+    typedef __fp16 fp16x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(fp16x2_, pair), __builtin_bit_cast(fp16x2_, 0x3C003C00u), acc, false);
+}
 // p[0..7] -> hi fragment and unscaled lo fragment (8 fp16 each)
 __device__ __forceinline__ void split8(const float* p, f16x8& hi, f16x8& lo) {
     u32x4 h, l;
@@ -91,6 +96,8 @@ struct AttnHArgs {
     unsigned mq = 0, ms = 0, mh = 0;
     int nseq = 0;
     int skip_combine = 0;        // split-KV launches: the partial outputs are merged by the consumer (gemm_small.hpp, lnx_combine), not by attn_combine_kernel
+    int prio = 0;                // static s_setprio 1 for half of the workgroups (two share a CU, one wave of each per SIMD): 0 none, 1 = odd
+                                 // workgroups of an XCD's sequence, 2 = every second group of 32 of that sequence (the second to land on each CU)
 };
 
 
@@ -303,7 +310,20 @@ constexpr size_t ATT_DMA_LDS = size_t(2) * ATT_STAGE * sizeof(half_t);
 // 1.164e-5 m with or without the P_lo term.
 // (PIPE, a software-pipelined key-tile loop - the softmax of tile t in the shadow of the QK^T MFMAs of tile t + 1 - measured 1.7 %
 // slower in round 2 and was removed in round 3; the template parameter is kept so that kernel names stay comparable across profiles.)
-template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false, bool PF = false>
+// SM (round 6) - the softmax of a key tile with the vector instructions that are not exponentials, conversions or the row sum taken out of
+// the common path (the SQ's counters put 120 vector instructions beside 19 matrix instructions per wave and key tile, and the wave pair of
+// a SIMD is bound by their issue slots - docs/NOTEBOOK.md section 10):
+//   * the reference maximum m enters the logits through the ACCUMULATOR: the first matrix instruction of a tile takes C = -m (sixteen
+//     registers that change only when m moves), so s - m leaves the matrix pipe and the sixteen subtractions are gone;
+//   * no tile maximum on the common path: p = 2^(s - m) is formed optimistically and the ROW SUM of the tile says whether m was too
+//     low (sum > ATT_SM_THR = 2^14, or not finite: some p is about to leave the fp16 range) - only then (and in a wave's first tile) the wave
+//     takes the slow path: tile maximum, m moves there, O and l rescaled, p formed again.  m is any earlier tile maximum of the row, as
+//     with the lazy maximum of SM = 0; O / l is the same softmax;
+//   * P1 (F16X2 / F16MX): the row sum is taken from the PACKED fp16 P that multiplies V (v_dot2_f32_f16 against {1, 1}: eight
+//     instructions instead of sixteen, and l normalises exactly the P that was used).
+// SM = 0: the round 2-5 form (tile maximum, lazy reference maximum, subtraction, fp32 row sum); diagnostics A/B ("attn_sm" = 2).
+constexpr float ATT_SM_THR = 16384.0f;      // the largest P stays below 2^14 (fp16 holds 2^16); every P keeps fp16's relative precision whatever its size
+template <bool TRACE, bool X2 = false, bool MX = false, bool PIPE = false, bool P1 = false, bool PF = false, int SM = 1>
 __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int nqt, int abl, unsigned long long* trace) {
     constexpr int HD = 128, KT = 32, NT = 4, NKS = 8;
     args_now_each(a, nqt, abl, trace);
@@ -324,6 +344,9 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     const int nwg = gridDim.x, b = blockIdx.x;
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = b % 8;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
+    if (a.prio) {
+        if (a.prio == 1 ? ((b >> 3) & 1) : ((b >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
+    }
     const int sh0 = fast_div(swz, nqt, a.mq), qt = swz - sh0 * nqt;
     const int sh = fast_div(sh0, a.nsplit, a.ms), split = sh0 - sh * a.nsplit;
     const int seq = fast_div(sh, a.nhead, a.mh), h = sh - seq * a.nhead;
@@ -413,7 +436,10 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
     for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[n][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;   // running max in log2 units (Q is pre-scaled by log2(e)/sqrt(hd))
+    float m_run = SM ? 0.f : -INFINITY, l_run = 0.f;   // running max in log2 units (Q is pre-scaled by log2(e)/sqrt(hd))
+    f32x16 negm;                             // SM: -m_run in all sixteen registers, the C operand of a tile's first matrix instruction
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
 
     // DMA sources.  K rounds 0-3: plane = i>>1, row = 16*(i&1) + tid/16, stored chunk tid&15.
     //               V rounds 4-7: plane = (i-4)>>1, row = 64*(i&1) + tid/4, stored chunk tid&3.
@@ -522,8 +548,12 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
         const half_t* Vl = Vh + ATT_VPLANE;
 
         f32x16 sm;
+        if (SM) {
+            sm = negm;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sm[r] = 0.f;
+        }
         constexpr int PFD = 3;        // PF: fragment reads PFD steps ahead (4: no better)
         // ATT_ISSUE_AT (tools/attn_issue_probe.hip only; 0 = what ships): where the copies of tile kt + 1 go out.  0: one per QK^T step, behind
         // that step's matrix instruction.  1: all of them between the last QK^T instruction and the softmax.  2: the same, after ALL eight V^T
@@ -637,6 +667,69 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             for (int i = 0; i < PFD; ++i) vpre[i] = *reinterpret_cast<const f16x8*>(Vh + (i & 3) * 1024 + vbase[i >> 2]);
         }
         ATT_STAMP(4)
+        f16x8 ph[2], pl[2];
+        if (SM) {
+            if (kt == ntiles_all - 1) {              // only the last tile can hold keys past S
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kt * KT + frag_row(r, hi) >= S) sm[r] = -INFINITY;
+            }
+            // sm holds s - m_run.  P = 2^(sm - delta) as the fragments of P.V, psum = the tile's row sum over both lane halves
+            float psum;
+            auto soft = [&](const float delta, auto shifted_c) {
+                constexpr bool SHIFTED = decltype(shifted_c)::value;
+                float p[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(SHIFTED ? sm[r] - delta : sm[r]);
+                float ps = 0.f;
+                if (P1) {       // one fp16 plane of P, rounded to nearest; the row sum of exactly those values
+#pragma unroll
+                    for (int mf = 0; mf < 2; ++mf) {
+                        u32x4 hq;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            hq[i] = pk_f16_rne(p[8 * mf + 2 * i], p[8 * mf + 2 * i + 1]);
+                            ps = dot2_ones(hq[i], ps);
+                        }
+                        ph[mf] = __builtin_bit_cast(f16x8, hq);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ps += p[r];
+                    split8(p, ph[0], pl[0]);
+                    split8(p + 8, ph[1], pl[1]);
+                }
+                float x0, x1;
+                half_swap(ps, x0, x1);
+                psum = x0 + x1;
+            };
+            const bool first = kt == kt_begin;       // (uniform) a wave's first tile: m_run is still the placeholder 0
+            soft(0.f, std::false_type{});
+            if (first || __any(!(psum <= ATT_SM_THR))) {
+                // slow path (a wave's first tile; afterwards only when a row's logits outgrow its reference maximum by 9 ... 14 in log2 units):
+                // the reference maximum of the rows concerned moves to this tile's maximum
+                float tmax = sm[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sm[r]);
+                {
+                    float x0, x1;
+                    half_swap(tmax, x0, x1);
+                    tmax = fmaxf(x0, x1);
+                }
+                const float delta = (first || !(psum <= ATT_SM_THR)) ? tmax : 0.f;       // m_new - m_run
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
+                l_run *= alpha;
+                m_run += delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+                soft(delta, std::true_type{});
+            }
+            l_run += psum;
+        } else {
         if (!(abl & 2)) {
         if (kt == ntiles_all - 1) {              // only the last tile can hold keys past S
 #pragma unroll
@@ -675,7 +768,6 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
         }
         }
-        f16x8 ph[2], pl[2];
         if (P1) {       // one fp16 plane of P, rounded to nearest
 #pragma unroll
             for (int mf = 0; mf < 2; ++mf) {
@@ -690,6 +782,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
             for (int r = 0; r < 16; ++r) pv[r] = sm[r];
             split8(pv, ph[0], pl[0]);
             split8(pv + 8, ph[1], pl[1]);
+        }
         }
         ATT_STAMP(5)
         if (PF && P1 && X2) {
@@ -907,10 +1000,13 @@ inline int attn_pick_nsplit(int base_blocks, int S) {
 
 
 // one instantiation of the LDS-DMA kernel: its dynamic-LDS attribute once per device, then the launch
-template <bool X2, bool MX, bool PIPE, bool P1, bool PF = false>
+template <bool X2, bool MX, bool PIPE, bool P1, bool PF = false, int SM = 1>
 inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t st) {
+#ifdef JMID_DIAGNOSTICS
+    if (SM == 1 && tune().attn_sm == 2) return launch_attn_dma<X2, MX, PIPE, P1, PF, 0>(a, grid, nqt, st);      // A/B: the round 2-5 softmax
+#endif
     static DevSeen seen;
-    const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1, PF>;
+    const auto kern = &attn_f16x3_dma_kernel<false, X2, MX, PIPE, P1, PF, SM>;
     if (auto once_ = first_use_on_device(seen))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, grid, dim3(256), tune().attn_one_wg ? 160 * 1024 : ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
@@ -926,6 +1022,7 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
         a.ms = fast_div_magic(a.nsplit, x_max);
         a.mh = fast_div_magic(a.nhead, x_max);
         a.nseq = nseq;
+        a.prio = tune().attn_prio;
         // the mode is a template parameter (a run-time flag in the key-tile loop costs F16X3 ~4 %).  F16X2 / F16MX: one fp16 plane
         // of P unless "attn_mx" = 1; F16MX with bf8 K images: the logits' correction terms as bf8 MFMAs
         const bool p1 = tune().attn_mx != 1;

@@ -137,6 +137,8 @@ struct Tuning {
     int graph = 0;           // captured denoise loop (hipGraph) of one-chunk calls: 1 on, 0 / 2 off (default: not faster, see jmid_planner.hip)
     int attn_nsplit = 0;     // split-KV factor of the head_dim-128 attention launches: 0 auto, 1..16 forced
     int csl_swap = 0;        // F16MX: 0 = transposed product + row-wise epilogue for the ConcatSquash GEMMs, 3 = for linear1 too (slower), 2 = neither
+    int attn_sm = 0;         // head_dim-128 LDS-DMA attention: 0 = the round-6 softmax (reference maximum through the accumulator, no tile maximum on the common path, row sum from packed P), 2 = the round 2-5 form (diagnostics A/B; other bits, same softmax)
+    int attn_prio = 0;       // head_dim-128 LDS-DMA attention: static s_setprio 1 for half of the workgroups (AttnHArgs::prio): 0 off, 1 / 2 on
     int attn_one_wg = 0;     // (probe) 1 = the head_dim-128 LDS-DMA attention kernels request the CU's whole 160 KB of LDS: ONE workgroup per CU, one wave per SIMD
     int h1_stage = 0;        // F16MX linear1 in the 256 x 256 / 128 x 256 shapes: 0 / 1 = tile out through LDS in whole lines (h1_staged_store), 2 = the element-wise epilogue
     int out_traj = 0;        // output layer + DDIM update + next embedding: 0 = one wave per trajectory from 4096 trajectories, 1 = always, 2 = one wave per token
@@ -145,7 +147,10 @@ struct Tuning {
     int attn_pf = 0;         // F16MX / F16X2 attention with one plane of P: 2 = fragment reads one step ahead instead of three (A/B; same bits)
     int gemm_small = 0;      // launches of at most one workgroup per CU (gemm_small.hpp): 0 = the deep-ring k64 kernel, 1 = the round-3 tile shapes, 2 = the deep-ring kernel only up to one workgroup per CU
     int small_cmb = 0;       // the split-KV merge of a one-scene attention launch inside the out-projection's OUT_LNX launch (gemm_small.hpp, lnx_combine): 0 on, 2 off (attn_combine_kernel)
-    int small_lnx = 0;       // out_proj / linear2 + residual + LayerNorm of a small F16MX launch in ONE kernel, row statistics exchanged between the workgroups of a row tile (gemm_small.hpp, OUT_LNX): 0 on, two exchanges in the canonical summation order (bit-identical to the pair); 1 on, ONE exchange (0.2 ms per one-scene call faster, another summation order: diagnostics); 2 off (GEMM + add_ln2)
+    int small_lnx = 0;       // out_proj / linear2 + residual + LayerNorm of a small F16MX launch in ONE kernel, the row statistics (block sums + squared deviations from the block means: gemm_ln2_mx.hpp's canonical order) exchanged ONCE between the workgroups of a row tile (gemm_small.hpp, OUT_LNX): 0 on, 2 off (GEMM + add_ln2; the same bits)
+    int cus = 256;           // compute units of the handle's device (jmid_create): OUT_LNX launches only while every workgroup of the launch is resident (diagnostics: a test may lower it)
+    int lnx_polls = 0;       // diagnostics: poll budget of OUT_LNX's waits (0 = SM_LNX_POLLS)
+    int lnx_withhold = 0;    // diagnostics: 1 = one workgroup of an OUT_LNX launch never publishes its statistics (the give-up path under test)
     int small_lnx2 = 0;      // ... for launches of 33 ... 64 row tiles (two scenes' worth of tokens; the reference's shipped K = 100) with TWO workgroups per CU: 0 on, 2 off (GEMM + add_ln2 [+ attn_combine])
     int gemm_pn = 0;         // F16MX large-tile GEMMs: column groups of the XCD tile order (0 / 1 = N fastest over all N-tiles)
     int one_chunk = 1;       // set per call by run_network: the call is ONE chunk (OUT_LNX of gemm_small.hpp only then, whatever the lanes: a call's bits do not depend on its chunk plan)

@@ -126,7 +126,8 @@ struct GemmHArgs {
     // the row-statistics exchange of the workgroups of a row tile
     unsigned long long* ln_xchg;   // [2 kinds][ceil(M / 64)][8 column tiles][64 rows] granules {fp32 partial, launch tag}, zeroed once per call
     unsigned ln_epoch;             // this launch's tag: never 0, never repeated within a call
-    int ln_one;                    // one exchange (sum + squared deviations from the block's own mean, merged) instead of two in the canonical order
+    int ln_polls;                  // poll budget of a wait for a partner workgroup (0: gemm_small.hpp's SM_LNX_POLLS; tests shrink it)
+    int ln_withhold;               // diagnostics flavour: block 7 of row tile 0 never publishes its statistics (tests: the give-up path)
     // OUT_LNX of the attention out-projection after a split-KV attention launch: the merge of the partial outputs (attn_combine_kernel's
     // arithmetic) happens in THIS launch - every workgroup merges its 64 rows x 64 columns of the A operand, publishes a flag, waits
     // for the seven others of its row tile and only then starts its K loop

@@ -13,10 +13,18 @@
 //   * bf8(W_lo) of a k64 block is wave-private: in the 128-row shape it comes through the LDS-DMA ring like the fp16 operands
 //     (ordinary loads next to DMA copies make hipcc wait vmcnt(0) before the fp8 MFMAs: 121 -> 99 us per launch), in the 64-row
 //     shape - whose 66 KB budget has no room for it - straight into registers.
-// The row statistics are summed in a fixed order that both tile shapes and add_ln2_kernel (the unfused path for launches too
-// small to fill the chip) reproduce, so fused and unfused rows stay bit-identical and a chunk plan cannot change a result:
-//     partial(c, h) = sum over (j, p, e) in that order of v[64 c + 32 j + 16 p + 8 h + e]         c = 0..7, j, p, h = 0..1, e = 0..7
-//     total = ((((((P0 + P1) + P2) + P3) + P4) + P5) + P6) + P7,  Pc = partial(c, 0) + partial(c, 1)
+// The row statistics are formed in ONE fixed order that both tile shapes, add_ln2_kernel (the unfused path for launches too small to
+// fill the chip) and the one-launch GEMM + LayerNorm of small launches (gemm_small.hpp, OUT_LNX) reproduce, so all of them stay
+// bit-identical and a chunk plan cannot change a result.  Since round 6 that order is BLOCK-WISE - a 64-column block forms its part of
+// both statistics alone (mean AND squared deviations from its OWN mean, merged a la Chan et al.), so the batch kernels need one LDS
+// exchange instead of two and the small-launch kernel one exchange between workgroups instead of two:
+//     s(c, h) = sum over (j, p, e) in that order of v[64 c + 32 j + 16 p + 8 h + e]               c = 0..7, j, p, h = 0..1, e = 0..7
+//     S_c = s(c, 0) + s(c, 1),   mu_c = S_c / 64
+//     q(c, h) = sum in the same order of (v - mu_c)^2,   Q_c = q(c, 0) + q(c, 1)
+//     mean = (((((((S_0 + S_1) + S_2) + S_3) + S_4) + S_5) + S_6) + S_7) / 512
+//     dm   = sum over c = 0..7, in that order, of (mu_c - mean)^2
+//     var  = ((((((((Q_0 + Q_1) + Q_2) + Q_3) + Q_4) + Q_5) + Q_6) + Q_7) + 64 dm) / 512,   rstd = rsqrt(var + eps)
+// (Rounds 2-5 summed the squared deviations from the ROW mean: the same variance to fp32 accuracy, another summation order.)
 #pragma once
 #include "gemm_ln_f16x3.hpp"
 
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     // ---- epilogue, in the accumulators: register 8p + e of acc[i][j] is column 32 WN wc + 32 j + 16 p + 8 hi + e of row 32 i + l31.
     // Statistics in the canonical order of this file's header: a partial per 64-column block c (j = 2 c', 2 c' + 1) and lane half.
     constexpr int NC = WN / 2;            // 64-column blocks per wave
-    float mean[WM], rstd[WM];
+    float mean[WM], rstd[WM];      // (set in pass3)
     // one row block (a literal at every call site: every accumulator index is a compile-time constant).  The residual chunks of
     // a row (16 + 8 bytes each) are requested together: one memory round trip per row block.
     // The residual chunks of ALL row blocks are requested before the first is used: the K loop's operand registers are free here
@@ -321,8 +329,20 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
                     s += v;
                 }
             }
-            // both lane halves of a row write the same sum (a + b == b + a) to the same word: no divergent store
-            red[(wc * NC + c) * BM + i * 32 + l31] = s + __shfl_xor(s, 32, 64);
+            // the block's own mean, then its squared deviations from it: nothing of another wave is needed
+            const float S = s + __shfl_xor(s, 32, 64);
+            const float mc = S / 64.f;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 2 * c; j < 2 * c + 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float t = acc[i][j][e] - mc;
+                    q += t * t;
+                }
+            // both lane halves of a row write the same sums (a + b == b + a) to the same words: no divergent store
+            red[(wc * NC + c) * BM + i * 32 + l31] = S;
+            red[8 * BM + (wc * NC + c) * BM + i * 32 + l31] = q + __shfl_xor(q, 32, 64);
         }
     };
     auto row_total = [&](const float* r8p, int r) {      // the 8 partials of row r, summed in column order
@@ -331,28 +351,18 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
         for (int c = 2; c < 8; ++c) t += r8p[c * BM + r];
         return t;
     };
-    auto pass2 = [&](auto i_c) {
-        constexpr int i = decltype(i_c)::value;
-        const int r = i * 32 + l31;
-        mean[i] = row_total(red, r) / (float)d;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float q = 0.f;
-#pragma unroll
-            for (int j = 2 * c; j < 2 * c + 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float t = acc[i][j][e] - mean[i];
-                    q += t * t;
-                }
-            red[8 * BM + (wc * NC + c) * BM + r] = q + __shfl_xor(q, 32, 64);
-        }
-    };
     unsigned amax16 = 0;
     auto pass3 = [&](auto i_c) {
         constexpr int i = decltype(i_c)::value;
         const int r = i * 32 + l31, row = m0 + r;
-        rstd[i] = rsqrtf(row_total(red + 8 * BM, r) / (float)d + g.eps);
+        mean[i] = row_total(red, r) / (float)d;
+        float dm = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float t = red[c * BM + r] / 64.f - mean[i];
+            dm += t * t;
+        }
+        rstd[i] = rsqrtf((row_total(red + 8 * BM, r) + 64.f * dm) / (float)d + g.eps);
         unsigned am = 0;
 #pragma unroll
         for (int j = 0; j < WN; ++j)
@@ -393,9 +403,6 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     __builtin_amdgcn_sched_barrier(0);
     pass1(I1{});
     if constexpr (WM == 4) { pass1(I2{}); pass1(I3{}); }
-    __syncthreads();
-    pass2(I0{}); pass2(I1{});
-    if constexpr (WM == 4) { pass2(I2{}); pass2(I3{}); }
     __syncthreads();
     pass3(I0{}); pass3(I1{});
     if constexpr (WM == 4) { pass3(I2{}); pass3(I3{}); }
@@ -463,21 +470,30 @@ static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, con
         }
     }
     const int base = lane & ~15;
-    auto row_total = [&](float part) {      // partial(c, 0) + partial(c, 1), then the 8 blocks in column order
-        part += __shfl_xor(part, 1, 64);
-        float t = __shfl(part, base, 64) + __shfl(part, base + 2, 64);
+    auto row_total = [&](float blk) {      // the 8 blocks' values (lanes base + 2 k of this row) in column order
+        float t = __shfl(blk, base, 64) + __shfl(blk, base + 2, 64);
 #pragma unroll
-        for (int k = 2; k < 8; ++k) t += __shfl(part, base + 2 * k, 64);
+        for (int k = 2; k < 8; ++k) t += __shfl(blk, base + 2 * k, 64);
         return t;
     };
-    const float mean = row_total(s) / (float)d;
+    // this file's canonical order: the block's sum S_c and its squared deviations from its OWN mean, then the merge over the 8 blocks
+    const float S = s + __shfl_xor(s, 1, 64);
+    const float mc = S / 64.f;
     float q = 0.f;
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
-        const float t = v[e] - mean;
+        const float t = v[e] - mc;
         q += t * t;
     }
-    const float rstd = rsqrtf(row_total(q) / (float)d + eps);
+    const float Q = q + __shfl_xor(q, 1, 64);
+    const float mean = row_total(S) / (float)d;
+    float dm = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float t = __shfl(S, base + 2 * k, 64) / 64.f - mean;
+        dm += t * t;
+    }
+    const float rstd = rsqrtf((row_total(Q) + 64.f * dm) / (float)d + eps);
     bool overflow = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

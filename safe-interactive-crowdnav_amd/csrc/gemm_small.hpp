@@ -100,34 +100,37 @@ constexpr size_t SM_LNX_GRANULES = SM_LNX_STATS + SM_LNX_MAX_TILES * 8;       //
 __device__ __forceinline__ void lnx_publish(unsigned long long* slot, float v, unsigned tag) {
     __hip_atomic_store(slot, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the seven other blocks' partials of this workgroup's 64 rows -> red[row * 8 + block]; thread t polls blocks 2 (t & 3), + 1 of row t >> 2.
-// TWO_STATS: the granules of both statistics in one sweep (slots_q / red + 512 next to slots_s / red)
-template <bool TWO_STATS>
+// the seven other blocks' partials of this workgroup's 64 rows -> red[row * 8 + block] (sums) and red[512 + row * 8 + block] (squared
+// deviations), the granules of both statistics in one sweep; thread t polls blocks 2 (t & 3), + 1 of row t >> 2.  `polls`: the budget
+// (0 = SM_LNX_POLLS); every 256 unsuccessful polls a thread looks at the range flag and leaves when a workgroup of this call has
+// already given up (bit 1): the first timeout of a call costs the whole budget, the launches behind it next to nothing.
+__device__ __forceinline__ bool lnx_timed_out(const int* range_flag) {
+    return (__hip_atomic_load(range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
+}
 __device__ __forceinline__ bool lnx_gather(const unsigned long long* slots_s, const unsigned long long* slots_q, float* red, int own,
-                                           unsigned tag, int tid) {
+                                           unsigned tag, int tid, int polls, const int* range_flag) {
     const int r = tid >> 2, k = tid & 3;
     const unsigned long long* p0 = slots_s + (2 * k) * 64 + r;
     const unsigned long long* p1 = p0 + 64;
     const unsigned long long* q0 = slots_q + (2 * k) * 64 + r;
     const unsigned long long* q1 = q0 + 64;
     float* d0 = red + r * 8 + 2 * k;
-    bool n0 = 2 * k != own, n1 = 2 * k + 1 != own, m0 = TWO_STATS && n0, m1 = TWO_STATS && n1;
-    int budget = SM_LNX_POLLS;
+    bool n0 = 2 * k != own, n1 = 2 * k + 1 != own, m0 = n0, m1 = n1;
+    int budget = polls > 0 ? polls : SM_LNX_POLLS;
     while ((n0 || n1 || m0 || m1) && budget > 0) {
         unsigned long long g0 = 0, g1 = 0, h0 = 0, h1 = 0;
         if (n0) g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n1) g1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (TWO_STATS) {
-            if (m0) h0 = __hip_atomic_load(q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (m1) h1 = __hip_atomic_load(q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (m0) h0 = __hip_atomic_load(q0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (m1) h1 = __hip_atomic_load(q1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (n0 && (unsigned)(g0 >> 32) == tag) { d0[0] = __uint_as_float((unsigned)g0); n0 = false; }
         if (n1 && (unsigned)(g1 >> 32) == tag) { d0[1] = __uint_as_float((unsigned)g1); n1 = false; }
-        if (TWO_STATS) {
-            if (m0 && (unsigned)(h0 >> 32) == tag) { d0[512] = __uint_as_float((unsigned)h0); m0 = false; }
-            if (m1 && (unsigned)(h1 >> 32) == tag) { d0[513] = __uint_as_float((unsigned)h1); m1 = false; }
+        if (m0 && (unsigned)(h0 >> 32) == tag) { d0[512] = __uint_as_float((unsigned)h0); m0 = false; }
+        if (m1 && (unsigned)(h1 >> 32) == tag) { d0[513] = __uint_as_float((unsigned)h1); m1 = false; }
+        if (n0 || n1 || m0 || m1) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((budget & 255) == 0 && lnx_timed_out(range_flag)) break;
         }
-        if (n0 || n1 || m0 || m1) __builtin_amdgcn_s_sleep(1);
         --budget;
     }
     return !(n0 || n1 || m0 || m1);
@@ -194,11 +197,14 @@ __device__ __forceinline__ void lnx_combine(const GemmHArgs& g, int tm, int c, i
     unsigned long long* flags = g.ln_xchg + SM_LNX_STATS + (size_t)tm * 8;
     if (tid == 0) __hip_atomic_store(flags + c, (unsigned long long)g.ln_epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 8 && tid != c) {
-        int budget = SM_LNX_POLLS;
+        int budget = g.ln_polls > 0 ? g.ln_polls : SM_LNX_POLLS;
         bool need = true;
         while (need && budget > 0) {
             need = (unsigned)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != g.ln_epoch;
-            if (need) __builtin_amdgcn_s_sleep(1);
+            if (need) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((budget & 255) == 0 && lnx_timed_out(g.range_flag)) break;
+            }
             --budget;
         }
         if (need) atomicOr(g.range_flag, 2);               // a partner never showed up: the call is repeated without this kernel
@@ -239,15 +245,14 @@ __device__ __forceinline__ void lnx_prefetch_landed(LnxPre& pre) {
 }
 
 // stg: the workgroup's staged tile [64][SM_STG_LD] (accumulator + bias); red: [2][64][8] floats behind it
-// !ONE (what ships): two exchanges, the canonical order, bit-identical to the pair.  ONE ("small_lnx" = 1, diagnostics flavour): a single
-// exchange - every block publishes its sum P_c AND the squared deviations from ITS OWN mean, and the row variance is merged from the
-// eight (count, mean, M2) triples (Chan et al.): as accurate as the two-pass form and one memory round trip less per LayerNorm (one
-// scene 10.47 against 10.67 ms per call), but NOT the canonical summation order: the rows differ from add_ln2_kernel's in the last
-// bits, which 50 steps of F16MX carry to 1e-5 m - and every knob / chunk-plan / graph-replay test of tests/ compares bits.
+// ONE exchange: every block publishes its sum S_c AND the squared deviations Q_c from ITS OWN mean, and the row variance is merged from
+// the eight (count, mean, M2) triples (Chan et al.) - gemm_ln2_mx.hpp's canonical order since round 6 (its header), which the batch
+// kernels and add_ln2_kernel form the same way: the rows are bit-identical to theirs.  (Round 5 shipped TWO exchanges - sums, then squared
+// deviations from the row mean, the canonical order of that round - and kept this form as a diagnostics knob: one memory round trip less
+// per LayerNorm, one scene 10.47 against 10.67 ms per call.)
 __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pre, const float* stg, float* red, int tm, int c, int m0, int tid) {
     constexpr int d = GLN_BN;
-    const bool ONE = g.ln_one != 0;                    // (uniform: a kernel argument)
-    const bool owner = tid < 128;                      // waves 0 and 1: thread (row, h) owns the 32 columns of partial(c, h)
+    const bool owner = tid < 128;                      // waves 0 and 1: thread (row, h) owns the 32 columns of s(c, h)
     const int row = (tid >> 1) & 63, h = tid & 1;
     const int grow = m0 + row;
     const int ntm = (g.M + 63) / 64;
@@ -271,29 +276,29 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
             }
         }
         s += __shfl_xor(s, 1, 64);
-        if (ONE) {
-            const float mc = s / 64.f;
-            float q = 0.f;
+        const float mc = s / 64.f;
+        float q = 0.f;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                const float t = v[e] - mc;
-                q += t * t;
-            }
-            q += __shfl_xor(q, 1, 64);
-            if (h == 0) {
+        for (int e = 0; e < 32; ++e) {
+            const float t = v[e] - mc;
+            q += t * t;
+        }
+        q += __shfl_xor(q, 1, 64);
+#ifdef JMID_DIAGNOSTICS
+        const bool withheld = g.ln_withhold && tm == 0 && c == 7;      // (tests: a partner that never shows up)
+#else
+        constexpr bool withheld = false;
+#endif
+        if (h == 0) {
+            if (!withheld) {
                 lnx_publish(slots_s + c * 64 + row, s, g.ln_epoch);
                 lnx_publish(slots_q + c * 64 + row, q, g.ln_epoch);
-                red[row * 8 + c] = s;
-                red[512 + row * 8 + c] = q;
             }
-        } else if (h == 0) {
-            lnx_publish(slots_s + c * 64 + row, s, g.ln_epoch);
             red[row * 8 + c] = s;
+            red[512 + row * 8 + c] = q;
         }
     }
-    bool ok;
-    if (ONE) ok = lnx_gather<true>(slots_s, slots_q, red, c, g.ln_epoch, tid);
-    else ok = lnx_gather<false>(slots_s, slots_q, red, c, g.ln_epoch, tid);
+    const bool ok = lnx_gather(slots_s, slots_q, red, c, g.ln_epoch, tid, g.ln_polls, g.range_flag);
     __syncthreads();
     auto row_total = [&](const float* r8p) {
         float t = r8p[0] + r8p[1];
@@ -304,32 +309,13 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
     float mean = 0.f, rstd = 0.f;
     if (owner) {
         mean = row_total(red + row * 8) / (float)d;
-        if (ONE) {
-            float dm = 0.f;
+        float dm = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float t = red[row * 8 + k] / 64.f - mean;
-                dm += t * t;
-            }
-            rstd = rsqrtf((row_total(red + 512 + row * 8) + 64.f * dm) / (float)d + g.ln_eps);
-        } else {
-            float q = 0.f;
-#pragma unroll
-            for (int e = 0; e < 32; ++e) {
-                const float t = v[e] - mean;
-                q += t * t;
-            }
-            q += __shfl_xor(q, 1, 64);
-            if (h == 0) {
-                lnx_publish(slots_q + c * 64 + row, q, g.ln_epoch);
-                red[512 + row * 8 + c] = q;
-            }
+        for (int k = 0; k < 8; ++k) {
+            const float t = red[row * 8 + k] / 64.f - mean;
+            dm += t * t;
         }
-    }
-    if (!ONE) {
-        ok &= lnx_gather<false>(slots_q, slots_q, red + 512, c, g.ln_epoch, tid);
-        __syncthreads();
-        if (owner) rstd = rsqrtf(row_total(red + 512 + row * 8) / (float)d + g.ln_eps);
+        rstd = rsqrtf((row_total(red + 512 + row * 8) + 64.f * dm) / (float)d + g.ln_eps);
     }
     if (!ok) atomicOr(g.range_flag, 2);                // a partner never showed up: the call is repeated without this kernel
     if (!owner) return;
@@ -381,6 +367,7 @@ __device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char*
     //  v_readfirstlane for its LDS destination, on a wave that is alone on its SIMD and issues ~one instruction per five cycles)
     const int wid_s = __builtin_amdgcn_readfirstlane(wid);
     unsigned lane_off = (unsigned)lane * 16u;
+    const bool a_merged = g.cmb_O != nullptr;      // (uniform: a kernel argument)
     const char* src[C::NR];
     auto plane_src = [&](const void* base, int tile, auto rows_c, int q) {
         constexpr int ROWS = decltype(rows_c)::value, SUB = ROWS * 64;
@@ -422,8 +409,15 @@ __device__ __forceinline__ f32x16 small_kloop(const GemmHArgs& g, unsigned char*
         for (int r = 0; r < C::NR; ++r) {
             const bool is8 = MX && r >= I8;
             const unsigned long long u = pin_uniform(reinterpret_cast<unsigned long long>(src[r] + (is8 ? (size_t)st_idx * KB * w8_kstride : (size_t)st_idx * KB * 16384)));
-            __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
-                                             (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 0);
+            // the A plane another workgroup of THIS launch has just merged (lnx_combine: sc1 write-through stores, then a flag): read it
+            // with sc1 copies - the producer / consumer pair MI355X_MICROARCH.md lists as valid without an acquire fence (a fence is
+            // ~1.7 us per launch) - instead of relying on no stale line of the plane having survived the kernel boundary
+            if (r < IAL && a_merged)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
+                                                 (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 16);
+            else
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) char*>(u) + lane_off,
+                                                 (__attribute__((address_space(3))) void*)(st + dst_of(r)), 16, 0, 0);
         }
     };
     const int rowA = wr * 32 + l31, rowW = wc * 32 + l31;
@@ -752,14 +746,16 @@ inline bool small_cmb_fits(int nsplit, int head_dim, int x2) {
 
 
 // does out_proj / linear2 + residual + LayerNorm run as ONE small launch with the statistics exchange (OUT_LNX)?  F16MX at d_model 512,
-// at most 256 tiles of 64 x 64 with nothing else in flight on the handle (the waiting workgroups need their partners resident), at
-// most 32 row tiles (the exchange buffer), in calls of ONE chunk (a call's bits must not depend on its chunk plan or its lanes).  "small_lnx" knob: 0 on with two exchanges (the default: bit-identical to the pair), 1 on with
-// ONE exchange (diagnostics flavour), 2 off (GEMM + add_ln2).
-inline int small_lnx_fits(int M, int K) {       // 0 no; 2: one workgroup per CU (at most 32 row tiles); 9: two per CU (33 ... 64 row tiles, "small_lnx2" = 2 off)
+// nothing else in flight on the handle, calls of ONE chunk (a call's bits must not depend on its chunk plan or its lanes), and EVERY
+// workgroup of the launch resident at once - the waiting workgroups need their partners: 8 workgroups per 64-row tile against the
+// device's compute units (Tuning::cus, from hipDeviceProp_t::multiProcessorCount at jmid_create - a partitioned or smaller device
+// takes the unfused pair), one per CU, or two per CU on half the LDS each, and at most SM_LNX_MAX_TILES row tiles (the exchange
+// buffer).  "small_lnx" = 2: off (GEMM + add_ln2, the same bits).
+inline int small_lnx_fits(int M, int K) {       // 0 no; 2: one workgroup per CU; 9: two per CU ("small_lnx2" = 2 off)
     const long ntm = (M + 63) / 64;
     if (!(tune().gemm_small != 1 && tune().small_now == 1 && tune().one_chunk == 1 && tune().gemm_h_variant == 0 && tune().small_lnx != 2 && K % 128 == 0)) return 0;
-    if (ntm <= 32) return 2;
-    return ntm <= SM_LNX_MAX_TILES && tune().small_lnx2 != 2 ? 9 : 0;
+    if (ntm * 8 <= tune().cus && ntm <= SM_LNX_MAX_TILES) return 2;
+    return ntm * 8 <= 2L * tune().cus && ntm <= SM_LNX_MAX_TILES && tune().small_lnx2 != 2 ? 9 : 0;
 }
 
 template <int EPI, int OUT>

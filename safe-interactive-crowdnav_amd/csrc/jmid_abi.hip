@@ -103,6 +103,10 @@ int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, in
         delete h;
         return fail(nullptr, JMID_EHIP, "cannot create a HIP stream");
     }
+    // compute units of this device (or of its partition): the kernels whose workgroups wait for each other launch only when all of
+    // them are resident at once (gemm_small.hpp::small_lnx_fits)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) h->tune.cus = cus;
     *out = h;
     return JMID_OK;
 }
@@ -385,12 +389,8 @@ int jmid_predict(jmid_handle_t h, int E, int A, int K, int T, int k, const float
     float* pout = pin + in_floats;
     HIPCHK(h, hipMemcpyAsync(pout, dev + o_out, out_floats * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (flagged && *reinterpret_cast<const int*>(pout + (o_flag - o_out))) {
-        if (*reinterpret_cast<const int*>(pout + (o_flag - o_out)) & 2) { h->lnx_off = true; ++h->lnx_timeouts; }
-        ++h->erange_calls;
-        h->last_pos = nullptr;
-        return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
-    }
+    if (flagged && *reinterpret_cast<const int*>(pout + (o_flag - o_out)))
+        return jmid_host::flagged_call(h, *reinterpret_cast<const int*>(pout + (o_flag - o_out)));
     if (rank) {
         std::memcpy(sel, pout + (o_sel - o_out), n_sel * 4);
         std::memcpy(logw, pout + (o_lw - o_out), n_lw * 4);
@@ -433,6 +433,8 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"out_traj", &Tuning::out_traj, 0, 2},
         {"attn_pf", &Tuning::attn_pf, 0, 2},
         {"attn_one_wg", &Tuning::attn_one_wg, 0, 1},
+        {"attn_sm", &Tuning::attn_sm, 0, 2},
+        {"attn_prio", &Tuning::attn_prio, 0, 2},
         {"mx_ln", &Tuning::mx_ln, 0, 2},
         {"csl_swap", &Tuning::csl_swap, 0, 3},
         {"h1_stage", &Tuning::h1_stage, 0, 2},
@@ -440,7 +442,10 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"gemm_pn", &Tuning::gemm_pn, 0, 8},
         {"small_lanes", &Tuning::small_lanes, 0, 2},
         {"small_cmb", &Tuning::small_cmb, 0, 2},               // 2: attn_combine_kernel instead of the split-KV merge inside the out-projection's one-launch GEMM + LayerNorm
-        {"small_lnx", &Tuning::small_lnx, 0, 2},               // the one-launch GEMM + LayerNorm with the statistics exchange: 0 two exchanges (bit-identical), 1 one exchange, 2 off (GEMM + add_ln2)
+        {"small_lnx", &Tuning::small_lnx, 0, 2},               // the one-launch GEMM + LayerNorm with the statistics exchange: 0 on, 2 off (GEMM + add_ln2)
+        {"cus", &Tuning::cus, 0, 4096},                         // compute units OUT_LNX may count on (0 = ask the device again, as jmid_create did)
+        {"lnx_polls", &Tuning::lnx_polls, 0, 1 << 20},
+        {"lnx_withhold", &Tuning::lnx_withhold, 0, 1},
         {"small_lnx2", &Tuning::small_lnx2, 0, 2},             // the same at 33 ... 64 row tiles, two workgroups per CU: 0 on, 2 off
         {"small_qk", &Tuning::small_qk, 0, 2},
         {"small_pn", &Tuning::small_pn, 0, 8},                 // column groups of its XCD tile order: 0 auto
@@ -461,6 +466,10 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
             if (value < kn.lo || value > kn.hi || (k == "ln_rows" && value != 0 && value != 64 && value != 128))
                 return fail(h, JMID_EINVAL, k + " out of range");
             h->tune.*(kn.field) = value;
+            if (k == "cus" && value == 0) {
+                int cus = 0;
+                h->tune.cus = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0 ? cus : 256;
+            }
             drop_graphs(h);          // captured loops hold the kernel variants the old knobs selected
             return JMID_OK;
         }
@@ -471,6 +480,7 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
 int64_t jmid_graph_replays(jmid_handle_t h) { return h ? h->graph_replays : -1; }
 
 int64_t jmid_erange_count(jmid_handle_t h) { return h ? h->erange_calls : -1; }
+int64_t jmid_timeout_count(jmid_handle_t h) { return h ? h->lnx_timeouts : -1; }
 
 int jmid_set_caller_stream(jmid_handle_t h, void* stream) {
     if (!h) return JMID_EINVAL;

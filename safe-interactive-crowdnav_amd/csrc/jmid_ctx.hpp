@@ -105,7 +105,7 @@ struct jmid_ctx {
     int64_t erange_calls = 0;   // calls on this handle that ended with JMID_ERANGE (jmid_erange_count)
     unsigned lnx_epoch = 0;     // launch tag of the small-launch GEMM + LayerNorm with the statistics exchange (gemm_small.hpp, OUT_LNX)
     bool lnx_off = false;       // a workgroup of that kernel once gave up waiting for a partner (range flag bit 1): the handle stays on GEMM + add_ln2
-    int64_t lnx_timeouts = 0;
+    int64_t lnx_timeouts = 0;   // calls on this handle that ended with JMID_ETIMEOUT for that reason (jmid_timeout_count)
     int x2 = 0;          // the running call is JMID_PREC_F16X2 (set by the entry points, read by the launch helpers)
     int net_kind = 1, ctx_dim = 256, tf_layer = 3, nhead = 4, hist_len = 6;
     int d = 512, ff = 1024, dmid = 256, dlow = 128, H = 128;
@@ -223,6 +223,7 @@ int order_out(jmid_ctx* h, int mem);
 int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, const float* ctx, const float* p0, float dt,
                 int precision, int single_step, float* vel_out, float* pos_out, float* e_out, int mem,
                 const float* z_in = nullptr);
+int flagged_call(jmid_ctx* h, int flag);      // the status of a call whose range flag came back set (JMID_ETIMEOUT / JMID_ERANGE)
 int launch_episode_metrics(jmid_ctx* h, const float* pos, const float* gt, float* out, int E, int K, int A, int T);
 // jmid_profile.hip
 int prof_collect(jmid_ctx* h);

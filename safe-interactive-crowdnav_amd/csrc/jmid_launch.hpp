@@ -29,7 +29,10 @@ inline int run_gemm_lnx_small(jmid_ctx* h, int cls, GemmHArgs& g) {
     g.x2 = h->x2;
     if (++h->lnx_epoch == 0) h->lnx_epoch = 1;        // (0 is what the zeroed granules hold)
     g.ln_epoch = h->lnx_epoch;
-    g.ln_one = tune().small_lnx == 1;
+    g.ln_polls = tune().lnx_polls;
+    g.ln_withhold = tune().lnx_withhold;
+    // the kernel is written for the F16MX operand set (byte lo plane of the residual stream, bf8 image of W_lo) only
+    if (!(g.x2 && g.W8 && g.ln_xl8)) return fail(h, JMID_EINVAL, "one-launch GEMM + LayerNorm without the F16MX operand set");
     ProfScope ps(h, cls);
     HIPCHK(h, (launch_gemm_small<EPI_BIAS, OUT_LNX>(g, small_lnx_fits(g.M, g.K), h->stream)));      // (2: one workgroup per CU, 9: two)
     return 0;

@@ -406,6 +406,7 @@ std::vector<int> plan_chunks(const jmid_ctx* h, int E, int tokens_per_episode) {
             // nine launches less per denoise step: two cfg2 scenes (2 400 tokens) 14.45 -> 13.90 ms per call, 12.63 with the split-KV factor chosen for that launch (run_network).  Three (3 600 tokens, 456
             // workgroups of that kernel) are better off as 2 + 1 side by side: 16.42 against 16.90 (profiles/r05s_lnx_two_per_cu.log)
             const bool lnx_call = h->mx && h->d == jmid::GLN_BN && !h->lnx_off && (long)E * tokens_per_episode <= 2560 &&
+                                  ((long)E * tokens_per_episode + 63) / 64 * 8 <= 2L * tune().cus &&
                                   tune().small_lnx != 2 && tune().small_lnx2 != 2 && tune().gemm_small != 1 && tune().gemm_h_variant == 0;
             c = lnx_call ? E : (E + 1) / 2;
         } else {
@@ -674,16 +675,28 @@ int run_network(jmid_ctx* h, int E, int A, int K, int T, const float* x_in, cons
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (flag & 2) { h->lnx_off = true; ++h->lnx_timeouts; }     // (gemm_small.hpp, OUT_LNX: a workgroup gave up waiting; the caller's rerun takes GEMM + add_ln2)
-        if (flag) ++h->erange_calls;
-        if (flag) h->last_pos = nullptr;     // the integrated positions are poisoned too: jmid_topk(pos = NULL) must not rank them
-        if (flag) return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
+        if (flag) return flagged_call(h, flag);
     } else if (mem == JMID_MEM_HOST) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
     }
     return 0;
 }
 
+
+// A call whose range flag came back set.  Bit 1 (gemm_small.hpp, OUT_LNX): a workgroup gave up waiting for a partner - nothing to do with
+// the arithmetic: the handle drops that kernel for good and the caller repeats the call in the SAME precision (JMID_ETIMEOUT).  Otherwise
+// bit 0: an activation left the fp16 range (JMID_ERANGE: repeat in JMID_PREC_F32).  Either way the outputs are undefined.
+int flagged_call(jmid_ctx* h, int flag) {
+    h->last_pos = nullptr;     // the integrated positions are poisoned too: jmid_topk(pos = NULL) must not rank them
+    if (flag & 2) {
+        h->lnx_off = true;
+        ++h->lnx_timeouts;
+        return fail(h, JMID_ETIMEOUT, "a workgroup of a one-launch GEMM + LayerNorm gave up waiting for its partners (not all workgroups of the launch "
+                                      "were resident): this handle now runs the unfused kernels - repeat the call in the same precision");
+    }
+    ++h->erange_calls;
+    return fail(h, JMID_ERANGE, "an activation left the fp16 range in JMID_PREC_F16X3 / F16X2 / F16MX: rerun with JMID_PREC_F32");
+}
 
 int launch_episode_metrics(jmid_ctx* h, const float* pos, const float* gt, float* out, int E, int K, int A, int T) {
     ProfScope ps(h, KC_METRICS);

@@ -17,6 +17,7 @@ os.environ.setdefault("JMID_LIB", DIAG_LIB)
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "expects_erange: the test provokes JMID_ERANGE on purpose")
+    config.addinivalue_line("markers", "expects_timeout: the test provokes (or tolerates) JMID_ETIMEOUT on purpose")
 
 
 @pytest.fixture(scope="session")
@@ -33,8 +34,12 @@ def no_fp16_range_fallback(request):
         yield
         return
     from safe_interactive_crowdnav_amd import engine as EN, forecaster as FC
-    n0, f0 = len(EN.ERANGE_EVENTS), FC.ERANGE_FALLBACKS
+    n0, f0, t0 = len(EN.ERANGE_EVENTS), FC.ERANGE_FALLBACKS, len(EN.TIMEOUT_EVENTS)
     yield
     if request.node.get_closest_marker("expects_erange") is None:
         assert len(EN.ERANGE_EVENTS) == n0, EN.ERANGE_EVENTS[n0:]
         assert FC.ERANGE_FALLBACKS == f0
+    # ... and no workgroup of a one-launch GEMM + LayerNorm may ever give up waiting for its partners (JMID_ETIMEOUT: the engine retries
+    # and records it) unless the test withholds a partner or crowds the chip on purpose (marker ``expects_timeout``)
+    if request.node.get_closest_marker("expects_timeout") is None:
+        assert len(EN.TIMEOUT_EVENTS) == t0, EN.TIMEOUT_EVENTS[t0:]

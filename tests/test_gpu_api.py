@@ -1,5 +1,6 @@
 """C-ABI behaviour on the GPU: sweep metrics kernel, device-pointer encode, error codes, handle lifetime."""
 import ctypes as C
+import time
 
 import numpy as np
 import pytest
@@ -230,3 +231,100 @@ def test_predict_entry_equals_the_staged_calls(ctx_dim, precision, E, A, K, T, k
         assert ei.value.code == -1
     finally:
         e.close()
+
+
+def _one_scene(seed=5):
+    g = torch.Generator().manual_seed(seed)
+    A, K, T = 5, 20, 12
+    return (torch.randn([1, K * A, T, 2], generator=g).numpy(), torch.randn([1, A, 256], generator=g).numpy(),
+            torch.randn([1, A, 2], generator=g).numpy())
+
+
+@pytest.mark.expects_timeout
+def test_a_workgroup_that_gives_up_waiting_comes_back_as_timeout_and_the_retry_is_correct():
+    """The one-launch GEMM + LayerNorm of one-scene F16MX calls (gemm_small.hpp, OUT_LNX) waits for partner workgroups with BOUNDED polls.
+    Provoked here (diagnostics knobs: one workgroup never publishes its statistics, poll budget 2 000): the library returns
+    JMID_ETIMEOUT - not JMID_ERANGE: nothing left the fp16 range, no exact-fp32 rerun - counts it (jmid_timeout_count), drops the kernel
+    for this handle, and the engine's single retry in the SAME precision returns the bits of the unfused pair; later calls stay there."""
+    from safe_interactive_crowdnav_amd import engine as EN
+    x_T, ctx, p0 = _one_scene()
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 4), joint=True, step=10)
+    try:
+        eng.set_tuning("small_lnx", 2)
+        ref = eng.denoise(x_T, ctx, p0, precision="f16mx")                    # GEMM + add_ln2
+        eng.set_tuning("small_lnx", 0)
+        fused = eng.denoise(x_T, ctx, p0, precision="f16mx")                  # the one-launch form: same bits, nobody gives up
+        for a, b in zip(fused, ref):
+            np.testing.assert_array_equal(a, b)
+        assert eng.timeout_count() == 0
+        n0 = len(EN.TIMEOUT_EVENTS)
+        eng.set_tuning("lnx_withhold", 1)
+        eng.set_tuning("lnx_polls", 2000)
+        t0 = time.perf_counter()
+        got = eng.denoise(x_T, ctx, p0, precision="f16mx")                    # first attempt times out, the retry runs the pair
+        dt = time.perf_counter() - t0
+        assert len(EN.TIMEOUT_EVENTS) == n0 + 1 and "gave up waiting" in EN.TIMEOUT_EVENTS[-1][1]
+        assert eng.timeout_count() == 1 and eng.erange_count() == 0
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+        assert dt < 5.0, dt                                                    # the launches behind the first timeout leave early
+        again = eng.denoise(x_T, ctx, p0, precision="f16mx")                  # the handle stays on the pair: no second timeout
+        assert eng.timeout_count() == 1 and len(EN.TIMEOUT_EVENTS) == n0 + 1
+        for a, b in zip(again, ref):
+            np.testing.assert_array_equal(a, b)
+    finally:
+        eng.close()
+
+
+@pytest.mark.expects_timeout
+def test_timeout_is_reported_to_a_c_caller_with_its_own_status_code():
+    """Straight through the C ABI (no engine retry): JMID_ETIMEOUT = -6 with a message, the next call on the handle JMID_OK."""
+    import ctypes as C
+    from safe_interactive_crowdnav_amd import _lib
+    x_T, ctx, p0 = _one_scene(6)
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 4), joint=True, step=4)
+    try:
+        eng.set_tuning("lnx_withhold", 1)
+        eng.set_tuning("lnx_polls", 500)
+        vel = np.empty_like(x_T)
+        args = (eng._h, 1, 5, 20, 12, C.c_void_p(x_T.ctypes.data), C.c_void_p(ctx.ctypes.data), None, C.c_float(0.25),
+                _lib.PRECISIONS["f16mx"], C.c_void_p(vel.ctypes.data), None, _lib.MEM_HOST)
+        rc = eng._lib.jmid_denoise(*args)
+        assert rc == -6 and _lib.ERR_NAMES[rc] == "JMID_ETIMEOUT"
+        assert b"same precision" in eng._lib.jmid_last_error(eng._h)
+        assert eng._lib.jmid_timeout_count(eng._h) == 1 and eng._lib.jmid_erange_count(eng._h) == 0
+        assert eng._lib.jmid_denoise(*args) == 0 and np.isfinite(vel).all()
+    finally:
+        eng.close()
+
+
+@pytest.mark.expects_timeout
+def test_two_handles_each_on_one_scene_in_f16mx_from_two_threads():
+    """Two handles, BOTH on one cfg2 scene in F16MX, from two host threads at once: each launch of the one-launch GEMM + LayerNorm then
+    shares the chip with the other handle's, which is exactly when "all partner workgroups are resident" is not given by construction.
+    Either everything comes back with the bits of each handle alone, or a handle reports a timeout, retries and still returns those
+    bits - never garbage, never a hang."""
+    import threading
+    x_T, ctx, p0 = _one_scene(7)
+    engs = [JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 4), joint=True, step=50) for _ in range(2)]
+    try:
+        alone = [e.denoise(x_T, ctx, p0, precision="f16mx") for e in engs]
+        for a, b in zip(alone[0], alone[1]):
+            np.testing.assert_array_equal(a, b)
+        out = [[None] * 6 for _ in engs]
+        def run(i):
+            for r in range(6):
+                out[i][r] = engs[i].denoise(x_T, ctx, p0, precision="f16mx")
+        th = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+        [t.start() for t in th]
+        [t.join(timeout=120) for t in th]
+        assert not any(t.is_alive() for t in th)
+        for i in range(2):
+            for r in range(6):
+                for a, b in zip(out[i][r], alone[0]):
+                    np.testing.assert_array_equal(a, b)
+            assert engs[i].erange_count() == 0 and engs[i].timeout_count() in (0, 1)
+        print("timeouts per handle:", [e.timeout_count() for e in engs])
+    finally:
+        for e in engs:
+            e.close()

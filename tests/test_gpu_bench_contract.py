@@ -72,10 +72,11 @@ def test_bench_json_contract(tmp_path):
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert c["processes"] * c["threads_per_process"] == c["cores"] <= c["hardware_threads"]
-    # the headline is the throughput mode (an explicit opt-in of the drop-in class, whose own default is the fp32-class mode) ...
+    # the headline is the mode the drop-in class runs by default (round 6: "f16mx" with the first-call self check against "f16x3") ...
     import inspect
     assert inspect.signature(FC.HumanTrajectoryForecasterSim.__init__).parameters["precision"].default is None     # -> DEFAULTS
-    assert FC.DEFAULTS["precision"] == "f16x3"
+    assert FC.DEFAULTS["precision"] == "f16mx" and FC.DEFAULTS["self_check"] is True
+    assert j["config"]["precision"] == j["config"]["class_default_precision"]
     assert j["config"]["precision"] == "f16mx" and j["parity"]["precision"] == "f16mx"
     assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
     # ... and all split modes are measured the same way and reported under the same keys
@@ -160,6 +161,37 @@ def test_bench_strong_scaling_two_ranks_share_one_gpu_over_gloo():
     assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"] <= j["ms_per_step"] * 1.05 and j["gather_ms"] >= 0
     # whole-job rate: the FIXED total per step
     assert abs(j["value"] - 7 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+
+
+def test_bench_eight_ranks_share_one_gpu_strong_scaling_ragged_shards():
+    """8-rank readiness without an 8-GPU node: the driver's own launch line for N = 8 (`torch.distributed.run --nproc-per-node 8`)
+    with all eight ranks on the one GPU of the test box and host collectives over gloo: `--scaling strong` with a total that does NOT
+    divide by eight (61 episodes = 5 ranks x 8 + 3 ranks x 7, sweep.shard_range), ranks_seen == 8, eight per-rank step times, the
+    gathered rows in GLOBAL episode order (bench.py tags every row with its episode index before the gather), and every rank pinned to
+    its own share of the host cores (bench.pin_rank)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(PROD_ENV, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                          "--gpus", "8", "--steps", "1", "--warmup", "1", "--scaling", "strong", "--total-episodes", "61",
+                          "--dist-backend", "gloo", "--device", "0", "--modes", "f16mx", "--cpu-episodes", "0", "--no-profile"],
+                         capture_output=True, text=True, timeout=1200, cwd=REPO, env=env)
+    c = _one_json_line(out, full=False)
+    assert c["n_gpus"] == 8 and c["ranks_seen"] == 8 and c["scaling"] == "strong"
+    assert c["config"]["total_episodes"] == 61 and c["config"]["episodes_per_gpu"] == 8 and c["sweep_episodes"] == 61
+    assert c["rows_in_episode_order"] is True
+    j = _one_json_line(out)
+    pr = j["per_rank_ms_per_step"]
+    assert len(pr["all"]) == 8 and 0 < pr["min"] <= pr["max"] <= j["ms_per_step"] * 1.05
+    assert abs(j["value"] - 61 * 5 * 20 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
+    sm = j["sweep_metrics"]
+    assert sm["episodes"] == 61 and sm["rows_in_episode_order"] is True and sm["mean_ADE_m"] == sm["mean_ADE_m"]
+    aff = j["rank0_affinity"]
+    if aff is not None and len(os.sched_getaffinity(0)) >= 8:            # rank 0 holds an eighth of the cores this process may use
+        assert 1 <= aff["cores"] <= len(os.sched_getaffinity(0)) // 8 + 1
 
 
 def test_bench_launched_plainly_spawns_its_own_ranks():

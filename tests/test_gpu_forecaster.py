@@ -32,8 +32,11 @@ def test_predict_ret_best_matches_reference(case, flavour, tmp_path):
                                k_ret=k_ret, H=H, step=int(z["step"]), time_step=float(z["time_step"]))
     w = JMIDWeights.from_seed(NetDims(ctx_dim=int(z["ctx_dim"])), int(z["wseed"]))
     assert w.checksum() == str(z["wsum"])
-    # the captures are CPU-reference runs; flavour "prod" = the production libjmid_hip.so next to the session's diagnostics build
-    f = HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="cpu", lib_path=PROD_LIB if flavour == "prod" else None)
+    # the captures are CPU-reference runs; flavour "prod" = the production libjmid_hip.so next to the session's diagnostics build,
+    # constructed as the drop-in user constructs it (the class default: "f16mx" + self_check); "diag" = the fp32-class mode by name
+    f = HumanTrajectoryForecasterSim(env, ypath, weights=w, rng_compat="cpu", lib_path=PROD_LIB if flavour == "prod" else None,
+                                     precision=None if flavour == "prod" else "f16x3")
+    assert f.precision == ("f16mx" if flavour == "prod" else "f16x3") and f.self_check == (flavour == "prod")
     assert f.engine._lib.has_diagnostics == (flavour == "diag")
     assert f.num_hist_frames == int(z["past"])
     for r, h, t in zip(z["robot_xy"], z["human_xy"], z["stamps"]):

@@ -149,7 +149,40 @@ def test_f16mx_fused_gemm_layernorm_gen2_matches_float64_and_its_unfused_pair(M,
 def test_small_launch_gemm_with_statistics_exchange_equals_its_unfused_pair(M, K):
     """gemm_small_kernel<.., OUT_LNX> (one scene in F16MX: out_proj / linear2 + residual + LayerNorm in ONE launch - the eight
     workgroups of a 64-row tile exchange the row statistics as {value, launch tag} granules and normalise their own 64 columns)
-    against float64 and - in its two-exchange form - bit for bit against the GEMM + add_ln2 pair; repeated, so that a stale granule (the buffer is reused
+    against float64 and bit for bit against the GEMM + add_ln2 pair and the row-complete batch kernel; repeated, so that a stale granule (the buffer is reused
+    launch after launch, only the tag moves) or an unlucky arrival order would show - every word is compared."""
+    eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
+    try:
+        rng = np.random.default_rng(M + K)
+        A = rng.standard_normal((M, K)).astype(np.float32) * np.linspace(0.5, 1.5, M, dtype=np.float32)[:, None]
+        W = (rng.standard_normal((512, K)) / np.sqrt(K)).astype(np.float32) * np.linspace(1.5, 0.5, 512, dtype=np.float32)[:, None]
+        b, g, t = (rng.standard_normal(512).astype(np.float32) for _ in range(3))
+        X = rng.standard_normal((M, 512)).astype(np.float32) * 2.0
+        pair = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=0)
+        row_complete = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=1)
+        np.testing.assert_array_equal(row_complete, pair)
+        for _ in range(8):                       # ONE exchange of (block sum, squared deviations from the block mean): the canonical order
+            fused = eng.dbg_gemm_ln_mx(A, W, b, g, t, X, fused=3)
+            np.testing.assert_array_equal(fused, pair)
+    finally:
+        eng.close()
+    v = X.astype(np.float64) + A.astype(np.float64) @ W.astype(np.float64).T + b
+    ref = (v - v.mean(1, keepdims=True)) / np.sqrt(v.var(1, keepdims=True) + 1e-5) * g + t
+    bad = np.argwhere(np.abs(fused - ref) > 2e-2)
+    assert len(bad) == 0, (len(bad), bad[:10], np.unique(bad[:, 1] % 128)[:40])
+    # inputs enter as fp16 (A_hi, X as hi + bf8(lo)): 2^-11 relative per operand, outputs leave as hi + bf8(lo)
+    assert np.abs(fused - ref).max() <= 6e-3 * max(1.0, np.abs(ref).max())
+    np.testing.assert_array_equal(fused, pair)
+
+
+
+
+@pytest.mark.parametrize("M,K", [(64, 512), (300, 512), (1200, 512), (1200, 1024), (2048, 1024), (1999, 128), (1, 512),
+                                 (2049, 512), (2400, 512), (2400, 1024), (4096, 1024), (4001, 128)])      # (> 2048 rows: two workgroups per CU)
+def test_small_launch_gemm_with_statistics_exchange_equals_its_unfused_pair(M, K):
+    """gemm_small_kernel<.., OUT_LNX> (one scene in F16MX: out_proj / linear2 + residual + LayerNorm in ONE launch - the eight
+    workgroups of a 64-row tile exchange the row statistics as {value, launch tag} granules and normalise their own 64 columns)
+    against float64 and bit for bit against the GEMM + add_ln2 pair and the row-complete batch kernel; repeated, so that a stale granule (the buffer is reused
     launch after launch, only the tag moves) or an unlucky arrival order would show - every word is compared."""
     eng = JmidEngine(JMIDWeights.from_seed(NetDims(ctx_dim=256), 1), joint=True)
     try:

@@ -433,26 +433,25 @@ def test_layernorm_inside_the_gemm_launch_at_two_workgroups_per_cu_is_bit_identi
 @pytest.mark.parametrize("case", ["net_jmid_w256_a5k20t12_s50.npz", "net_imid_w256_a5k20t12_s50.npz"])
 def test_one_scene_layernorm_inside_the_gemm_launch_is_bit_identical(case):
     """One scene in F16MX (d_model 512): out_proj / linear2 + residual + LayerNorm run as ONE small launch whose workgroups exchange
-    the row statistics (gemm_small.hpp, OUT_LNX; six launches less per denoise step).  With two exchanges per LayerNorm (what ships) the same
-    bits as GEMM + add_ln2 over a whole 50-step loop; with one (a diagnostics knob) deterministic and within rounding of them; repeated on one handle (the exchange buffer is reused by every launch of every call); no workgroup ever gives up
-    waiting (that would come back as JMID_ERANGE and switch the handle to the pair)."""
+    the row statistics ONCE - block sums and squared deviations from the block means, the mode's canonical order since round 6
+    (gemm_small.hpp, OUT_LNX; six launches less per denoise step): the same bits as GEMM + add_ln2 over a whole 50-step loop, repeated on
+    one handle (the exchange buffer is reused by every launch of every call); no workgroup ever gives up waiting (that would come back
+    as JMID_ETIMEOUT, be retried by the engine and recorded)."""
+    from safe_interactive_crowdnav_amd import engine as EN
     z = np.load(os.path.join(GOLDEN, case))
     eng, _ = get_engine(int(z["ctx_dim"]), int(z["wseed"]), bool(z["joint"]))
     eng.set_step(int(z["step"]), "ddim")
     out = []
+    n0 = len(EN.TIMEOUT_EVENTS)
     try:
-        for knob in (2, 0, 0, 1, 1, 1):
+        for knob in (2, 0, 0, 2, 0):
             eng.set_tuning("small_lnx", knob)
             out.append(eng.denoise(z["x_T"][None], z["ctx"][None], precision="f16mx", want_pos=False)[0][0])
     finally:
         eng.set_tuning("small_lnx", 0)
-    np.testing.assert_array_equal(out[1], out[0])          # two exchanges per LayerNorm, the canonical summation order: the pair's bits
-    np.testing.assert_array_equal(out[2], out[0])
-    np.testing.assert_array_equal(out[4], out[3])          # the diagnostics variant with ONE exchange: deterministic ...
-    np.testing.assert_array_equal(out[5], out[3])
-    # ... last-bit differences of the row statistics - which 50 steps of a mode that rounds every activation to fp16 carry to ~1e-5 m,
-    # the distance between any two summation orders in this mode (f16mx against the oracle: 5e-6 ... 1.2e-5 m)
-    assert ade(out[3], out[0]) <= 3e-5, ade(out[3], out[0])
+    for o in out[1:]:
+        np.testing.assert_array_equal(o, out[0])
+    assert len(EN.TIMEOUT_EVENTS) == n0 and eng.timeout_count() == 0
     assert ade(out[3], z["vel"]) <= ADE_GATE
 
 
@@ -558,7 +557,7 @@ def test_linear1_tile_through_lds_is_bit_identical_to_the_elementwise_epilogue()
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
                ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
-               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (1, 2)), ("small_cmb", (2,)), ("small_lnx2", (2,))]
+               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (2,)), ("cus", (128, 64)), ("small_cmb", (2,)), ("small_lnx2", (2,))]
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)

@@ -6,8 +6,8 @@ Asserted (and quoted in INTEGRATION.md):
   * exact fp32 and f16x3 (the class default) stay within 1e-5 m of the fp64 truth in EVERY cell where f16x3 does not report
     JMID_ERANGE - and when it does, the class falls back to exact fp32 (forecaster.denoise_with_fallback);
   * the opt-in modes stay inside the 1e-4 m gate in the cells INTEGRATION.md lists as their envelope;
-  * ``self_check=True`` downgrades an opt-in mode to f16x3 in every cell where it is more than 2e-5 m from f16x3 on the call's
-    own inputs, and leaves it alone where it is within 1e-5 m.
+  * ``self_check=True`` (the class default since round 6) moves "f16mx" / "f16x2" to f16x3 in every cell where the mode is more than
+    ``self_check_tol`` (5e-5 m, half the gate) from f16x3 on the call's own inputs, and leaves it alone where it is within half of that.
 """
 import os
 import sys
@@ -90,8 +90,9 @@ def test_self_check_downgrades_exactly_where_the_mode_drifts(cell, tmp_path):
             with f._engine_lock:
                 out = f._self_check(x, c, p, d["pos"][mode][None])
         assert abs(f.self_check_delta - delta) <= 1e-7 + 1e-3 * delta       # the same quantity the sweep recorded
-        if delta > 2e-5:
+        assert f.self_check_tol == 5e-5
+        if delta > f.self_check_tol:
             assert f.precision == "f16x3" and not f.self_check, (cell, mode, delta)
             np.testing.assert_array_equal(out[0], d["pos"]["f16x3"])          # the call returns the f16x3 result
-        elif delta <= 1e-5:
+        elif delta <= 0.5 * f.self_check_tol:
             assert f.precision == mode, (cell, mode, delta)

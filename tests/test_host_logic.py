@@ -158,9 +158,10 @@ def test_install_aliases_the_reference_module(monkeypatch):
             monkeypatch.syspath_prepend("/root/reference")
             importlib.invalidate_caches()
         try:
-            mod = P.install(precision="f16mx", self_check=True)
+            assert FC.DEFAULTS["precision"] == "f16mx" and FC.DEFAULTS["self_check"] is True      # what bench.py quotes is what a drop-in user runs
+            mod = P.install(precision="f16x3", self_check=False)
             stood_in = list(P._STAND_INS)
-            assert mod is FC and FC.DEFAULTS["precision"] == "f16mx" and FC.DEFAULTS["self_check"] is True
+            assert mod is FC and FC.DEFAULTS["precision"] == "f16x3" and FC.DEFAULTS["self_check"] is False
             ns = {}
             exec("from sicnav_diffusion.JMID.mid_sim_wrapper import HumanTrajectoryForecasterSim", ns)     # the caller's line
             assert ns["HumanTrajectoryForecasterSim"] is FC.HumanTrajectoryForecasterSim
@@ -264,3 +265,41 @@ def test_module_level_get_most_likely_samples_has_the_reference_signature():
     # the device kernel's size limits (include/jmid_hip.h): beyond them the class falls back to the host twin
     assert topk_fits_device(32, 1024, 24) and not topk_fits_device(33, 100, 8) and not topk_fits_device(5, 1025, 8) \
         and not topk_fits_device(5, 100, 25)
+
+
+def test_rank_cpu_shares_are_disjoint_and_numa_local():
+    """bench.rank_cpu_share (the per-rank CPU placement of a multi-rank launch): contiguous disjoint shares of the allowed cores; with
+    NUMA information the ranks whose GPUs hang off one node split THAT node's cores; degenerate inputs never give an empty share."""
+    import bench
+    allowed = list(range(256))
+    sh = [bench.rank_cpu_share(allowed, r, 8) for r in range(8)]
+    assert all(len(x) == 32 for x in sh) and sorted(sum(sh, [])) == allowed
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    nodes = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    sh = [bench.rank_cpu_share(allowed, r, 8, numa, nodes) for r in range(8)]
+    assert sorted(sum(sh, [])) == allowed and all(set(sh[r]) <= set(nodes[numa[r]]) for r in range(8))
+    # a cpuset smaller than the node list (a container): only allowed cores are handed out
+    sh = [bench.rank_cpu_share(list(range(0, 16)), r, 8, numa, nodes) for r in range(8)]
+    assert all(len(x) >= 1 and set(x) <= set(range(16)) for x in sh)
+    assert bench.rank_cpu_share([3, 4], 5, 8) == [3, 4]                      # fewer cores than ranks: everybody gets them all
+    assert bench.rank_cpu_share(allowed, 2, 3, [None, None, None], {}) == allowed[171:256]
+    assert bench._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+
+
+def test_compact_bench_line_always_fits_and_always_parses():
+    """bench.compact_line never asserts and never loses the contract keys, however long the notes of the long result are (the driver
+    parses this one stdout line; round 4's 20 KB line was not parsed)."""
+    import json
+    import bench
+    full = {"metric": "m", "value": 1.0, "unit": "traj/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "x" * 3000, "data": "synthetic",
+            "config": {"workload_short": "w" * 3000, "episodes_per_gpu": 1, "total_episodes": 1, "humans": 5, "samples": 20, "horizon": 12,
+                       "denoise_steps": 50, "net": "jmid", "precision": "f16mx", "lanes": 2, "dist_backend": None},
+            "cpu_baseline": {"value": 1.0, "unit": "traj/s", "cores": 1, "kind": "port", "processes": 1, "threads_per_process": 1,
+                             "hardware_threads": 1, "host_physical_cores": 1, "sample_short": "s" * 3000, "cores_short": "c" * 3000},
+            "modes": {m: {"value": 1.0, "ms_per_step": 1.0} for m in ("f16mx", "f16x2", "f16x3")}}
+    line = bench.compact_line(full, "/tmp/detail.json")
+    assert len(line) <= bench.COMPACT_LIMIT
+    j = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline"):
+        assert k in j, k
