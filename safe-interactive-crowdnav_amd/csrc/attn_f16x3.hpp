@@ -1012,6 +1012,10 @@ inline void launch_attn_dma(const AttnHArgs& a, dim3 grid, int nqt, hipStream_t 
     hipLaunchKernelGGL(kern, grid, dim3(256), tune().attn_one_wg ? 160 * 1024 : ATT_DMA_LDS, st, a, nqt, PIPE ? 0 : attn_abl_bits(), (unsigned long long*)nullptr);
 }
 
+// (An 8-wave ping-pong form of this kernel - two wave groups per SIMD alternating between a matrix-instruction segment and the softmax across
+//  s_barrier - was built three times: rounds 4-5 with the ~100-instruction softmax, round 6 with the SM = 1 softmax, whose ~38 vector
+//  instructions fit inside the partner's matrix segment.  Bit-identical every time, and 7 % SLOWER than two free-running 4-wave workgroups
+//  per CU even then: profiles/r06_attn_pp_check.log, docs/NOTEBOOK.md section 11.  The kernel is not in the tree.)
 inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_dim, hipStream_t st) {
     AttnHArgs a = a_in;
     if (head_dim == 128 && tune().attn_h_variant != 1) {
@@ -1056,4 +1060,3 @@ inline hipError_t launch_attn_f16x3(const AttnHArgs& a_in, int nseq, int head_di
 }
 
 }  // namespace jmid
-

@@ -76,7 +76,7 @@ def test_bench_json_contract(tmp_path):
     import inspect
     assert inspect.signature(FC.HumanTrajectoryForecasterSim.__init__).parameters["precision"].default is None     # -> DEFAULTS
     assert FC.DEFAULTS["precision"] == "f16mx" and FC.DEFAULTS["self_check"] is True
-    assert j["config"]["precision"] == j["config"]["class_default_precision"]
+    assert _one_json_line(out, full=False)["config"]["class_default_precision"] == j["config"]["precision"] == "f16mx"
     assert j["config"]["precision"] == "f16mx" and j["parity"]["precision"] == "f16mx"
     assert j["parity"]["pass"] is True and j["parity"]["mean_ADE_vs_oracle_m"] <= 1e-4
     # ... and all split modes are measured the same way and reported under the same keys

@@ -557,7 +557,7 @@ def test_linear1_tile_through_lds_is_bit_identical_to_the_elementwise_epilogue()
 KNOB_VALUES = [("gemm_h_variant", (1, 2, 3, 4, 5, 6, 7, 8)), ("h1_stage", (2,)), ("ln_fuse", (1, 2)), ("ln_rows", (64, 128)), ("attn_h_variant", (1, 2)),
                ("vt_stage", (1, 2, 3)), ("no_vt_direct", (1,)), ("attn_nsplit", (1, 3)), ("csl_swap", (2, 3)),
                ("out_traj", (1, 2)), ("attn_mx", (1, 2, 3)), ("fuse_embed", (0,)), ("attn_pack", (0,)), ("lanes", (1, 3)),
-               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (2,)), ("cus", (128, 64)), ("small_cmb", (2,)), ("small_lnx2", (2,))]
+               ("bystander_lds", (100 * 1024,)), ("gemm_ng", (2,)), ("attn_pf", (2,)), ("attn_one_wg", (1,)), ("small_lnx", (2,)), ("cus", (128, 64)), ("attn_sm", (2,)), ("attn_prio", (1, 2)), ("small_cmb", (2,)), ("small_lnx2", (2,))]
 
 
 @pytest.mark.parametrize("precision", SPLIT_MODES)

@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Xclang -target-feature -Xclang -packed-fp32-ops -w \
 //         -DJMID_DIAGNOSTICS -I safe-interactive-crowdnav_amd/csrc -I include tools/attn_check.hip -o build/attn_check
 //   build/attn_check [nseq = 51] [S = 1200] [reps = 20] [mode: 0 = F16MX operands, 1 = F16X2, 2 = F16X3] [logit scale = 0.35] [nsplit = 1]
+//   TRACE=1 (mode 0, no key split): cycle stamps per phase of the key-tile loop, both softmax forms.
 //   ONE_WG=1 in the environment: ONE workgroup per CU (a wave alone on its SIMD).  DRIFT=x: the keys' scale grows by x per 32 keys
 //   (the reference maximum has to move late in the sequence: the slow path of "attn_sm" = 0).
 #include "attn_f16x3.hpp"
@@ -89,6 +90,42 @@ int main(int argc, char** argv) {
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double fl = 4.0 * nseq * (double)S * S * d;
         printf("%s: %.4f ms per launch  (%.0f TFLOP/s algorithmic)\n", names[v], ms / reps, fl / (ms / reps * 1e-3) * 1e-12);
+    }
+    if (getenv("TRACE") && mode == 0 && nsplit == 1) {
+        // cycle stamps per phase of the key-tile loop, per wave (the TRACE instantiation of the kernel; stamps perturb the schedule a little)
+        const int nqt = (S + 127) / 128, nblk = nqt * nhead * nseq;
+        unsigned long long* tr;
+        CK(hipMalloc(&tr, (size_t)nblk * 4 * 12 * 8));
+        const char* pn[7] = {"prologue", "wait vmcnt", "barrier", "issue DMA", "QK^T", "softmax + pack", "P.V"};
+        for (int v = 0; v < 2; ++v) {
+            CK(hipMemset(tr, 0, (size_t)nblk * 4 * 12 * 8));
+            AttnHArgs a{dQ, reinterpret_cast<half_t*>(dQ8), dK, nullptr, dV, nullptr, dO[v], nullptr, S, Spad, d, nhead, 1.f, flag, 1, dOpart, dML, 1, dK8h, dK8l, dQ8};
+            a.mq = fast_div_magic(nqt, nblk); a.ms = fast_div_magic(1, nblk); a.mh = fast_div_magic(nhead, nblk); a.nseq = nseq;
+            const size_t ldsb = getenv("ONE_WG") ? 160 * 1024 : ATT_DMA_LDS;
+            if (v == 0) {
+                auto k = &attn_f16x3_dma_kernel<true, true, true, false, true, true, 0>;
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(nblk), dim3(256), ldsb, st, a, nqt, 0, tr);
+            } else {
+                auto k = &attn_f16x3_dma_kernel<true, true, true, false, true, true, 1>;
+                CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k, dim3(nblk), dim3(256), ldsb, st, a, nqt, 0, tr);
+            }
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> t((size_t)nblk * 4 * 12);
+            CK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+            double sum[7] = {0}; size_t nw = 0;
+            for (size_t w = 0; w < (size_t)nblk * 4; ++w) {
+                if (!t[w * 12 + 4]) continue;      // idle waves (queries past S)
+                ++nw;
+                for (int i = 0; i < 7; ++i) sum[i] += (double)t[w * 12 + i];
+            }
+            const double tiles = (S + 31) / 32;
+            double tot = 0;
+            printf("%s, traced: %zu active waves; cycles per wave and key tile:", names[v], nw);
+            for (int i = 1; i < 7; ++i) { printf("  %s %.0f", pn[i], sum[i] / nw / tiles); tot += sum[i] / nw / tiles; }
+            printf("  total %.0f\n", tot);
+        }
     }
     // float64 reference on sampled rows
     std::vector<half_t> oh[2], ol[2];

@@ -1,7 +1,7 @@
 #!/bin/bash
 # SQ issue / wait counters of the big kernels over ONE whole predictor call on one 51-episode chunk (tools/step_only.py): what the
 # waves of attention and of the GEMMs spend their cycles on, from the hardware's own counters (the cycle stamps of
-# tools/attn_pp_check.hip say the same from inside the kernel).  One counter per rocprofv3 pass (--kernel-trace + --pmc only).
+# tools/attn_trace.hip say the same from inside the kernel).  One counter per rocprofv3 pass (--kernel-trace + --pmc only).
 #   JMID_PREC=f16mx tools/sq_counters.sh      -> gpurun_out/sq/sq_counters_<mode>.json
 export TMPDIR=/tmp
 export JMID_PREC=${JMID_PREC:-f16mx}
