@@ -393,6 +393,7 @@ def predict_batch(engine: JmidEngine, human_xy: np.ndarray, robot_xy: np.ndarray
     """
     E, F, N, _ = human_xy.shape
     K, k, H = int(num_samples), int(num_ret_samples), int(horizon)
+    precision = DEFAULTS["precision"] if precision is None else precision      # (no self check here: an engine-level call)
     b = SC.build_scenes_batched(human_xy, robot_xy, time_step, horizon=H)
     inc = b["in_cluster"]
     forecasts = np.zeros((E, N, k, H, 2), dtype=np.float64)
