@@ -126,7 +126,6 @@ __device__ __forceinline__ unsigned long long pin_uniform_rfl(unsigned long long
 struct Tuning {
     int fuse_embed = 1;      // the output kernel of step i embeds x for step i + 1
     int ln_fuse = 0;         // 0 auto, 1 always, 2 never: fused GEMM + residual + LayerNorm
-    int ln_stagger = 0;      // F16MX GEMM + LayerNorm of full launches: first-round workgroups of every second CU start n x ~3.9 us late (de-phasing experiment; 0 off)
     int ln_rows = 0;         // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
     int bystander_lds = 0;   // dynamic LDS the small row-wise kernels request although they use none
     int gemm_h_variant = 0;  // 0 auto, 1..6 force a tile variant of the split-fp16 GEMM (diagnostics: 7 = 128 x 256 two per CU, 8 = 256 x 256 with a three-stage ring)

@@ -70,7 +70,6 @@ struct GemmLn2Args {
     float eps;
     int* range_flag;
     int no_lo_out;                // the last LayerNorm of the net: nobody reads its lo plane
-    int stagger;                  // launch_gemm_ln2_cfg: the workgroups on every second CU start this many s_sleep 127 (~3.9 us each) late (0: off)
 };
 
 // Tile shapes: wave tile (32 WM) rows x (32 WN) columns = 128 accumulators either way; 16 / WN waves side by side cover the 512 columns.
@@ -111,12 +110,11 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     const int tm = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + b / 8;
     const int m0 = tm * BM;
     const int nk = g.K / 32, nsteps = g.K / 16;
-    // De-phasing: a launch is ~2 row tiles per CU, every CU alternating between an MFMA-bound K loop (HBM idle) and an HBM-bound epilogue
-    // (matrix pipes idle), all 256 of them in step.  The first-round workgroups of every second CU start late, so that one half of the
-    // chip is in its epilogue while the other half is in a K loop.
-    if (g.stagger && b < 256 && ((b >> 3) & 1)) {
-        for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    // (De-phasing experiment of round 6: a launch is ~2 row tiles per CU, every CU alternating between an MFMA-bound K loop and an HBM-bound
+    //  epilogue, all 256 in step.  Letting the first-round workgroups of every second CU start 4 ... 23 us late - so that half of the chip
+    //  is in an epilogue while the other half is in a K loop - made the launch no faster at any delay, and slower from 8 us on:
+    //  profiles/r06_gemm_ln2_stagger.log.  Two 64-row tiles in flight per CU - ln_rows = 64 - lose 8-12 % to the doubled W stream:
+    //  profiles/r06_gemm_ln2_rows_check.log.)
     // bias, gamma, beta of all 512 columns into LDS (6 KB): the epilogue reads them with LDS latency.  These are ordinary VMEM
     // loads: the ds_writes retire them before the DMA ring starts, so that vmcnt counts only the ring (+ the bf8(W_lo) loads).
     float* par = reinterpret_cast<float*>(lds_raw + C::RING_BYTES);
@@ -423,9 +421,7 @@ inline void launch_gemm_ln2_cfg(const GemmLn2Args& g, hipStream_t st) {
     if (auto once_ = first_use_on_device(seen))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ln2_mx_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)C::LDS_BYTES);
-    GemmLn2Args gs = g;
-    gs.stagger = tune().ln_stagger;
-    hipLaunchKernelGGL((gemm_ln2_mx_kernel<WM, WN>), dim3((g.M + C::BM - 1) / C::BM), dim3(C::NT), C::LDS_BYTES, st, gs);
+    hipLaunchKernelGGL((gemm_ln2_mx_kernel<WM, WN>), dim3((g.M + C::BM - 1) / C::BM), dim3(C::NT), C::LDS_BYTES, st, g);
 }
 inline hipError_t launch_gemm_ln2_mx(const GemmLn2Args& g, hipStream_t st) {
 #ifdef JMID_DIAGNOSTICS

@@ -421,7 +421,6 @@ int jmid_set_tuning(jmid_handle_t h, const char* key, int value) {
         {"attn_pack", &Tuning::attn_pack, 0, 1},               // 0: one short sequence per wave, 1: packed (iMID)
         {"fuse_embed", &Tuning::fuse_embed, 0, 1},             // 0: separate embed_kernel at the start of every step
         {"bystander_lds", &Tuning::bystander_lds, 0, 160 * 1024},   // unused dynamic LDS requested by row-wise kernels
-        {"ln_stagger", &Tuning::ln_stagger, 0, 16},
         {"ln_rows", &Tuning::ln_rows, 0, 128},                 // row tile of the fused GEMM + LayerNorm: 0 auto, 64, 128
         {"ln_fuse", &Tuning::ln_fuse, 0, 2},                   // 0 auto (M >= 7168 tokens), 1 always, 2 never
         {"no_vt_direct", &Tuning::no_vt_direct, 0, 1},         // 1: always V row-major + v_transpose_kernel

@@ -15,7 +15,6 @@ using namespace jmid;
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 61200, K = argc > 2 ? atoi(argv[2]) : 512, reps = argc > 3 ? atoi(argv[3]) : 20;
     std::vector<int> variants;
-    // (a variant 1000 + n: ln_rows = 128 with "ln_stagger" = n)
     { const char* v = argc > 4 ? argv[4] : "128,64"; for (const char* p = v; *p;) { variants.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p) ++p; } }
     const int d = 512;
     const size_t Mpad = ((size_t)M + 127) / 128 * 128 + 128;
@@ -47,7 +46,7 @@ int main(int argc, char** argv) {
     for (size_t v = 0; v < nv; ++v) { CK(hipMalloc(&dXh[v], Xh.size() * 2)); CK(hipMalloc(&dXl[v], Xl.size())); }
     for (int round = 0; round < 3; ++round)
         for (size_t v = 0; v < nv; ++v) {
-            Tuning tn; tn.ln_rows = variants[v] >= 1000 ? 128 : variants[v]; tn.ln_stagger = variants[v] >= 1000 ? variants[v] - 1000 : 0;      // 1000 + n: 128-row tiles, stagger n
+            Tuning tn; tn.ln_rows = variants[v];
             TuneScope ts(&tn);
             GemmLn2Args g{dA, dW, dW8, db, dg, dt, dXh[v], dXl[v], M, K, 1e-5f, flag, 0};
             // the result of ONE application to the pristine residual planes (kept for the comparison) ...

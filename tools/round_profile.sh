@@ -2,7 +2,7 @@
 # All measurements profiles/ holds for a round, in one GPU-box call (about 15 minutes).  Output: gpurun_out/$R/
 #   R=r02 tools/round_profile.sh ; then python tools/update_profiles.py r02
 export TMPDIR=/tmp
-R=${R:-r05}
+R=${R:-r06}
 O=gpurun_out/$R
 mkdir -p $O
 # PMC first: HBM bytes and MFMA busy per production kernel over one whole call, per mode; the summaries go into profiles/ of
@@ -61,6 +61,8 @@ if [ -x build/concurrency_probe9 ]; then (timeout 300 ./build/concurrency_probe9
 # round 5: the 8-wave ping-pong attention experiment against the shipped kernel (bitwise + time per launch, three operand sets; cycle stamps)
 # where each arithmetic mode leaves the gate, incl. the two extreme cells (no JMID_ERANGE anywhere)
 timeout 900 python tools/robustness_sweep.py --out $O/robustness.json > $O/robustness.log 2>&1
+# round 6: what the waves of the big kernels spend their cycles on (SQ counters, one per pass), after the softmax change
+JMID_PREC=f16mx tools/sq_counters.sh > $O/sq_counters.log 2>&1; cp gpurun_out/sq/sq_counters_f16mx.json $O/sq_counters_f16mx.json 2>/dev/null
 # lanes 1 / 2 / 3 on the default batch
 python tools/single_scene_sweep.py lanes=1,2,3 f16mx 256 2>/dev/null | grep ms > $O/lanes.log
 python tools/single_scene_sweep.py lanes=1,2,3 f16x2 256 2>/dev/null | grep ms >> $O/lanes.log

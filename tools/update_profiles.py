@@ -5,7 +5,7 @@ R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = f"gpurun_out/{R}", "profiles"
 names = ["bench_cfg3.json", "bench_cfg3_f32.json", "bench_cfg2.json", "bench_cfg4.json", "bench_cfg5_1gpu.json", "bench_cfg3_imid.json",
          "bench_cfg3_orca.json", "episode_sweep.log", "soak.log", "packed_fp32_probe.log", "scaled_mfma_probe.log", "lanes.log", "pmc_call_f16mx.json", "pmc_call_f16x2.json",
-         "pmc_call_f16x3.json", "shipped_profile.log", "small_pmc_f16mx_E1.txt", "small_launch_traces.log", "bench_strong_2ranks_1gpu.json", "bench_cfg3.line.json", "robustness.json"]
+         "pmc_call_f16x3.json", "shipped_profile.log", "small_pmc_f16mx_E1.txt", "small_launch_traces.log", "bench_strong_2ranks_1gpu.json", "bench_cfg3.line.json", "robustness.json", "sq_counters_f16mx.json"]
 for n in names:
     if os.path.exists(f"{src}/{n}"):
         shutil.copy(f"{src}/{n}", f"{dst}/{R}_{n}")
