@@ -49,23 +49,6 @@ __device__ __forceinline__ void split8(const float* p, f16x8& hi, f16x8& lo) {
     lo = __builtin_bit_cast(f16x8, l);
 }
 
-// The cross-half exchange of a row statistic (lane l <-> lane l ^ 32) as ONE vector instruction: v_permlane32_swap leaves {x[l % 32]} and
-// {x[l % 32 + 32]} in both halves of its two operands - no LDS round trip (ds_bpermute behind __shfl_xor) in the middle of the softmax.
-// max(a, b) and a + b of the pair are what max(x, shfl_xor(x, 32)) and x + shfl_xor(x, 32) give, bit for bit (both commutative).
-// (Inline assembly: hipcc folds the two results of __builtin_amdgcn_permlane32_swap into one register - max(a, b) became a and a + b
-//  became a + a.  The instruction needs two wait states after a vector write of its operands.)
-__device__ __forceinline__ void half_swap(float x, float& lo_half, float& hi_half) {
-#ifdef JMID_ATT_SHFL      // (A/B: the ds_bpermute form)
-    lo_half = x;
-    hi_half = __shfl_xor(x, 32, 64);
-#else
-    float a = x, b = x;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    lo_half = a;
-    hi_half = b;
-#endif
-}
-
 // The reference maximum of the online softmax is LAZY: it moves to the row's new tile maximum only when that exceeds it by more than
 // ATT_LAZY_TAU (log2 units), so P = 2^(s - m) can reach 2^8 - exact in fp32, far inside fp16 once rounded, and the row sum carries the
 // same factor: O / l is the same softmax.  The strict form max(m, tile max) rescales the O accumulators whenever ANY of a wave's 32

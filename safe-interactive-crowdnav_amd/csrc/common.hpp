@@ -235,6 +235,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The cross-half exchange of a row statistic (lane l <-> lane l ^ 32) as ONE vector instruction: v_permlane32_swap leaves {x[l % 32]} and
+// {x[l % 32 + 32]} in both halves of its two operands - no LDS round trip (ds_bpermute behind __shfl_xor) in the middle of the softmax.
+// max(a, b) and a + b of the pair are what max(x, shfl_xor(x, 32)) and x + shfl_xor(x, 32) give, bit for bit (both commutative).
+// (Inline assembly: hipcc folds the two results of __builtin_amdgcn_permlane32_swap into one register - max(a, b) became a and a + b
+//  became a + a.  The instruction needs two wait states after a vector write of its operands.)
+__device__ __forceinline__ void half_swap(float x, float& lo_half, float& hi_half) {
+#ifdef JMID_ATT_SHFL      // (A/B: the ds_bpermute form)
+    lo_half = x;
+    hi_half = __shfl_xor(x, 32, 64);
+#else
+    float a = x, b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    lo_half = a;
+    hi_half = b;
+#endif
+}
+
 // C/D fragment row of a 32x32 MFMA accumulator register (col = lane & 31)
 __device__ __forceinline__ int frag_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
 

@@ -24,6 +24,8 @@
 //     mean = (((((((S_0 + S_1) + S_2) + S_3) + S_4) + S_5) + S_6) + S_7) / 512
 //     dm   = sum over c = 0..7, in that order, of (mu_c - mean)^2
 //     var  = ((((((((Q_0 + Q_1) + Q_2) + Q_3) + Q_4) + Q_5) + Q_6) + Q_7) + 64 dm) / 512,   rstd = rsqrt(var + eps)
+//     (the squares accumulate as q = fma(t, t, q); the output is fma(fma(v, rstd, -mean rstd), gamma, beta): explicit fused operations,
+//      the same in every kernel - the build has -ffp-contract=off)
 // (Rounds 2-5 summed the squared deviations from the ROW mean: the same variance to fp32 accuracy, another summation order.)
 #pragma once
 #include "gemm_ln_f16x3.hpp"
@@ -335,7 +337,11 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
                 }
             }
             // the block's own mean, then its squared deviations from it: nothing of another wave is needed
-            const float S = s + __shfl_xor(s, 32, 64);
+            // (the cross-half exchange as v_permlane32_swap, not ds_bpermute: mc is needed right away, and an LDS round trip in this
+            //  dependency chain - four row blocks in a row - made the block-wise order 6 % SLOWER than the two-pass form it replaced)
+            float s0, s1;
+            half_swap(s, s0, s1);
+            const float S = s0 + s1;
             const float mc = S / 64.f;
             float q = 0.f;
 #pragma unroll
@@ -343,11 +349,13 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float t = acc[i][j][e] - mc;
-                    q += t * t;
+                    q = fmaf(t, t, q);
                 }
             // both lane halves of a row write the same sums (a + b == b + a) to the same words: no divergent store
             red[(wc * NC + c) * BM + i * 32 + l31] = S;
-            red[8 * BM + (wc * NC + c) * BM + i * 32 + l31] = q + __shfl_xor(q, 32, 64);
+            float q0, q1;
+            half_swap(q, q0, q1);
+            red[8 * BM + (wc * NC + c) * BM + i * 32 + l31] = q0 + q1;
         }
     };
     auto row_total = [&](const float* r8p, int r) {      // the 8 partials of row r, summed in column order
@@ -368,6 +376,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
             dm += t * t;
         }
         rstd[i] = rsqrtf((row_total(red + 8 * BM, r) + 64.f * dm) / (float)d + g.eps);
+        const float nmr = -mean[i] * rstd[i];      // (x - mean) rstd gamma + beta as two fused multiply-adds per element: fma(fma(x, rstd, -mean rstd), gamma, beta)
         unsigned am = 0;
 #pragma unroll
         for (int j = 0; j < WN; ++j)
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
                 float o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    o[e] = (acc[i][j][8 * p + e] - mean[i]) * rstd[i] * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+                    o[e] = fmaf(fmaf(acc[i][j][8 * p + e], rstd[i], nmr), e < 4 ? g0[e] : g1[e - 4], e < 4 ? t0[e] : t1[e - 4]);
                 const Split4 s0 = split_f32x4(o[0], o[1], o[2], o[3], am), s1 = split_f32x4(o[4], o[5], o[6], o[7], am);
                 if (row < g.M) {
                     *reinterpret_cast<__attribute__((address_space(1))) i32x4*>(xh_at(i, 2 * j + p)) = i32x4{s0.hi[0], s0.hi[1], s1.hi[0], s1.hi[1]};
@@ -407,10 +416,18 @@ __global__ __launch_bounds__(64 * (16 / WN), 2) void gemm_ln2_mx_kernel(GemmLn2A
     if constexpr (WM == 4) load1(I3{});
     __builtin_amdgcn_sched_barrier(0);
     pass1(I1{});
-    if constexpr (WM == 4) { pass1(I2{}); pass1(I3{}); }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (WM == 4) { pass1(I2{}); __builtin_amdgcn_sched_barrier(0); pass1(I3{}); }
     __syncthreads();
-    pass3(I0{}); pass3(I1{});
-    if constexpr (WM == 4) { pass3(I2{}); pass3(I3{}); }
+    pass3(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    pass3(I1{});
+    if constexpr (WM == 4) {
+        __builtin_amdgcn_sched_barrier(0);
+        pass3(I2{});
+        __builtin_amdgcn_sched_barrier(0);
+        pass3(I3{});
+    }
     if (split_range_exceeded(amax16)) atomicOr(g.range_flag, 1);
 }
 
@@ -488,7 +505,7 @@ static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, con
 #pragma unroll
     for (int e = 0; e < 32; ++e) {
         const float t = v[e] - mc;
-        q += t * t;
+        q = fmaf(t, t, q);
     }
     const float Q = q + __shfl_xor(q, 1, 64);
     const float mean = row_total(S) / (float)d;
@@ -499,6 +516,7 @@ static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, con
         dm += t * t;
     }
     const float rstd = rsqrtf((row_total(Q) + 64.f * dm) / (float)d + eps);
+    const float nmr = -mean * rstd;
     bool overflow = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -507,7 +525,7 @@ static __global__ __launch_bounds__(256) void add_ln2_kernel(const float* Y, con
         f16x8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float o = (v[u * 8 + e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+            const float o = fmaf(fmaf(v[u * 8 + e], rstd, nmr), e < 4 ? g0[e] : g1[e - 4], e < 4 ? t0[e] : t1[e - 4]);
             half_t hh, ll;
             split_f32(o, hh, ll);
             overflow |= !(fabsf(o) <= kHalfMax);

@@ -281,7 +281,7 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
             const float t = v[e] - mc;
-            q += t * t;
+            q = fmaf(t, t, q);
         }
         q += __shfl_xor(q, 1, 64);
 #ifdef JMID_DIAGNOSTICS
@@ -319,6 +319,7 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
     }
     if (!ok) atomicOr(g.range_flag, 2);                // a partner never showed up: the call is repeated without this kernel
     if (!owner) return;
+    const float nmr = -mean * rstd;
     bool overflow = false;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -327,7 +328,7 @@ __device__ __forceinline__ void lnx_tail_mx(const GemmHArgs& g, const LnxPre& pr
         f16x8 vh, vl;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float o = (v[u * 8 + e] - mean) * rstd * (e < 4 ? g0[e] : g1[e - 4]) + (e < 4 ? t0[e] : t1[e - 4]);
+            const float o = fmaf(fmaf(v[u * 8 + e], rstd, nmr), e < 4 ? g0[e] : g1[e - 4], e < 4 ? t0[e] : t1[e - 4]);
             half_t hh, ll;
             split_f32(o, hh, ll);
             overflow |= !(fabsf(o) <= kHalfMax);
