@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                     if (kt * KT + frag_row(r, hi) >= S) sm[r] = -INFINITY;
             }
             // sm holds s - m_run.  P = 2^(sm - delta) as the fragments of P.V, psum = the tile's row sum over both lane halves
-            float psum;
+            float psum = 0.f;
             auto soft = [&](const float delta, auto shifted_c) {
                 constexpr bool SHIFTED = decltype(shifted_c)::value;
                 float p[16];
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 psum = x0 + x1;
             };
             const bool first = kt == kt_begin;       // (uniform) a wave's first tile: m_run is still the placeholder 0
-            soft(0.f, std::false_type{});
+            if (!first) soft(0.f, std::false_type{});      // (a first tile goes straight to the slow path: with a key split a wave has ~6 tiles)
             if (first || __any(!(psum <= ATT_SM_THR))) {
                 // slow path (a wave's first tile; afterwards only when a row's logits outgrow its reference maximum by 9 ... 14 in log2 units):
                 // the reference maximum of the rows concerned moves to this tile's maximum
