@@ -102,7 +102,7 @@ __device__ __forceinline__ void lnx_publish(unsigned long long* slot, float v, u
 }
 // the seven other blocks' partials of this workgroup's 64 rows -> red[row * 8 + block] (sums) and red[512 + row * 8 + block] (squared
 // deviations), the granules of both statistics in one sweep; thread t polls blocks 2 (t & 3), + 1 of row t >> 2.  `polls`: the budget
-// (0 = SM_LNX_POLLS); every 256 unsuccessful polls a thread looks at the range flag and leaves when a workgroup of this call has
+// (0 = SM_LNX_POLLS); after every 256th unsuccessful poll a thread looks at the range flag and leaves when a workgroup of this call has
 // already given up (bit 1): the first timeout of a call costs the whole budget, the launches behind it next to nothing.
 __device__ __forceinline__ bool lnx_timed_out(const int* range_flag) {
     return (__hip_atomic_load(range_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 2) != 0;
@@ -116,7 +116,7 @@ __device__ __forceinline__ bool lnx_gather(const unsigned long long* slots_s, co
     const unsigned long long* q1 = q0 + 64;
     float* d0 = red + r * 8 + 2 * k;
     bool n0 = 2 * k != own, n1 = 2 * k + 1 != own, m0 = n0, m1 = n1;
-    int budget = polls > 0 ? polls : SM_LNX_POLLS;
+    int budget = polls > 0 ? polls : SM_LNX_POLLS, misses = 0;
     while ((n0 || n1 || m0 || m1) && budget > 0) {
         unsigned long long g0 = 0, g1 = 0, h0 = 0, h1 = 0;
         if (n0) g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -129,7 +129,7 @@ __device__ __forceinline__ bool lnx_gather(const unsigned long long* slots_s, co
         if (m1 && (unsigned)(h1 >> 32) == tag) { d0[513] = __uint_as_float((unsigned)h1); m1 = false; }
         if (n0 || n1 || m0 || m1) {
             __builtin_amdgcn_s_sleep(1);
-            if ((budget & 255) == 0 && lnx_timed_out(range_flag)) break;
+            if ((++misses & 255) == 0 && lnx_timed_out(range_flag)) break;      // (never on the first misses: the look costs a memory round trip)
         }
         --budget;
     }
@@ -197,13 +197,13 @@ __device__ __forceinline__ void lnx_combine(const GemmHArgs& g, int tm, int c, i
     unsigned long long* flags = g.ln_xchg + SM_LNX_STATS + (size_t)tm * 8;
     if (tid == 0) __hip_atomic_store(flags + c, (unsigned long long)g.ln_epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < 8 && tid != c) {
-        int budget = g.ln_polls > 0 ? g.ln_polls : SM_LNX_POLLS;
+        int budget = g.ln_polls > 0 ? g.ln_polls : SM_LNX_POLLS, misses = 0;
         bool need = true;
         while (need && budget > 0) {
             need = (unsigned)(__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != g.ln_epoch;
             if (need) {
                 __builtin_amdgcn_s_sleep(1);
-                if ((budget & 255) == 0 && lnx_timed_out(g.range_flag)) break;
+                if ((++misses & 255) == 0 && lnx_timed_out(g.range_flag)) break;
             }
             --budget;
         }
