@@ -92,12 +92,17 @@ int jmid_create(jmid_handle_t* out, int device_id, int net_kind, int ctx_dim, in
     h->H = ctx_dim / 2;
     h->hl = make_hyper_layout(h->d, h->dmid, h->dlow);
     register_shapes(h);
-    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreate(&h->stream) == hipSuccess &&
+    // NON-BLOCKING streams: a blocking stream is implicitly ordered against the legacy null stream, so once ANYTHING in the process
+    // (torch on its default stream, or this handle's own device-mode ordering events) has put work on the null stream, every launch on
+    // the handle's stream pays for that coupling - one cfg2 call went from 10.1 to 13.0 ms after a single device-mode call on the handle
+    // (tools/predict_probe.py).  The handle orders itself against the caller's stream EXPLICITLY (order_in / order_out: events), host-mode
+    // calls synchronise the stream before they return, and nothing in the library uses the null stream.
+    bool ok = hipSetDevice(device_id) == hipSuccess && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_out, hipEventDisableTiming) == hipSuccess;
     for (int l = 0; ok && l < jmid_ctx::kMaxLanes - 1; ++l)
-        ok = hipStreamCreate(&h->lane_stream[l]) == hipSuccess &&
+        ok = hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         delete h;

@@ -44,7 +44,7 @@ int jmid_dbg_gemm(jmid_handle_t h, int M, int N, int K, const float* A, const fl
     TuneScope tune_scope(&h->tune);
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
-        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
     }
     float *dA, *dW, *dB = nullptr, *dC;
     HIPCHK(h, hipMalloc((void**)&dA, (size_t)M * K * 4));
@@ -107,7 +107,7 @@ int jmid_dbg_attention(jmid_handle_t h, int nseq, int S, const float* QKV, int p
     TuneScope tune_scope(&h->tune);
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
-        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
     }
     const size_t Mt = (size_t)nseq * S;
     const int d = h->d, hd = h->d / h->nhead;
@@ -174,7 +174,7 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
     h->x2 = 1;
     if (!h->range_flag) {
         HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
-        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
     }
     std::vector<void*> tmp;
     auto dalloc = [&](size_t bytes, const void* host) -> void* {
@@ -182,7 +182,7 @@ int jmid_dbg_gemm_ln_mx(jmid_handle_t h, int M, int K, const float* A, const flo
         if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
         tmp.push_back(p);
         if (host) (void)hipMemcpy(p, host, bytes, hipMemcpyHostToDevice);
-        else (void)hipMemset(p, 0, bytes);
+        else (void)hipMemsetAsync(p, 0, bytes, h->stream);
         return p;
     };
     float* dA = (float*)dalloc((size_t)M * K * 4, A);

@@ -226,7 +226,7 @@ int jmid_finalize_weights(jmid_handle_t h) {
         if (!h->range_flag) {
             HIPCHK(h, hipMalloc((void**)&h->range_flag, sizeof(int)));
         }
-        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
         std::vector<std::string> names = {"concat3._layer.weight", "concat4._layer.weight"};
         for (int l = 0; l < h->tf_layer; ++l) {
             const std::string p = "transformer_encoder.layers." + std::to_string(l);
@@ -279,7 +279,7 @@ int jmid_finalize_weights(jmid_handle_t h) {
         int flag = 0;
         HIPCHK(h, hipMemcpy(&flag, h->range_flag, sizeof(int), hipMemcpyDeviceToHost));
         h->weights_in_half_range = flag == 0;
-        HIPCHK(h, hipMemset(h->range_flag, 0, sizeof(int)));
+        HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), h->stream));
     }
     h->finalized = true;
     return upload_time_table(h);
