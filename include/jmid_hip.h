@@ -15,7 +15,8 @@
  *   - buffers are caller-owned.  `mem` says where they live: JMID_MEM_HOST (the library
  *     copies through its stream) or JMID_MEM_DEVICE (device pointers on the handle's GPU,
  *     e.g. torch.Tensor.data_ptr(); no copies are made).
- *   - one HIP stream per handle; a handle is not re-entrant (the reference is a
+ *   - one HIP stream per handle, created hipStreamNonBlocking (no implicit ordering against the legacy null stream: other work of
+ *     the process on the default stream neither waits for nor delays the predictor); a handle is not re-entrant (the reference is a
  *     single-threaded caller; mid_sim_wrapper.py:174 only locks its history buffer).
  *   - JMID_MEM_DEVICE calls are stream-ordered against the CALLER's stream (jmid_set_caller_stream, default the
  *     legacy null stream): on entry the handle's stream waits for everything the caller enqueued on that stream,
