@@ -100,11 +100,14 @@ def test_two_engines_coexist():
     e2.close()
 
 
-def test_device_mode_calls_are_ordered_against_the_callers_stream():
+@pytest.mark.parametrize("which", ["side", "default"])
+def test_device_mode_calls_are_ordered_against_the_callers_stream(which):
     """JMID_MEM_DEVICE buffers are produced and consumed on the CALLER's stream (include/jmid_hip.h, Conventions): the
     library's private stream waits for what the caller enqueued before the call and the caller's stream waits for the
     call's last kernel.  Inputs that are still being computed on a non-default torch stream when the call is made, and
-    outputs consumed on that stream right after it, must give the synchronous answer."""
+    outputs consumed on that stream right after it, must give the synchronous answer.  "default": the same with torch's DEFAULT
+    stream (the legacy null stream) as the busy producer - the handle's streams are non-blocking streams since round 6, so nothing but
+    the library's own events orders them against it."""
     import torch
     from safe_interactive_crowdnav_amd.engine import JmidEngine
     from safe_interactive_crowdnav_amd.weights import JMIDWeights, NetDims
@@ -119,7 +122,7 @@ def test_device_mode_calls_are_ordered_against_the_callers_stream():
     torch.cuda.synchronize()
     ref_vel, ref_pos = eng.denoise(x0 * 2.0 - x0, ctx0 + 0.0, p0, precision="f32")     # default stream, synchronous reference
     eng.synchronize()
-    side = torch.cuda.Stream()
+    side = torch.cuda.Stream() if which == "side" else torch.cuda.default_stream()
     for _ in range(3):
         with torch.cuda.stream(side):
             for _ in range(8):                      # keep the side stream busy: the inputs below are produced behind this
