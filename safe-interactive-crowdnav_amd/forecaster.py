@@ -83,6 +83,11 @@ def advance_cuda_generator(device_id: int, shape: Tuple[int, ...], n: int) -> No
         torch.empty(1, device=f"cuda:{device_id}")
         gen = torch.cuda.default_generators[device_id]
     key = (int(device_id), tuple(int(v) for v in shape))
+    if not (hasattr(gen, "get_offset") and hasattr(gen, "set_offset")):
+        # an older torch (the reference pins 1.13.1) has no Philox-offset accessors: make the draws for real, as the reference does
+        for _ in range(n):
+            torch.randn(key[1], device=f"cuda:{device_id}")
+        return
     step = _PHILOX_STEP.get(key)
     if step is None:
         before = gen.get_offset()
