@@ -701,13 +701,16 @@ __global__ __launch_bounds__(256, 2) void attn_f16x3_dma_kernel(AttnHArgs a, int
                 }
                 const float delta = (first || !(psum <= ATT_SM_THR)) ? tmax : 0.f;       // m_new - m_run
                 // (a wave's first tile: O and l are still zero and delta is measured from the placeholder 0 - it may be -1 000 with
-                //  logits that large, 2^1000 = inf, and 0 x inf would poison the row: no rescale there)
-                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                //  logits that large, 2^1000 = inf, and 0 x inf would poison the row: no rescale there - and 64 multiplications of zeros
+                //  less in a tile that is a sixth of a wave's work when the key range is split)
+                if (!first) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-                for (int n = 0; n < NT; ++n)
+                    for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
-                l_run *= alpha;
+                        for (int r = 0; r < 16; ++r) ot[n][r] *= alpha;
+                    l_run *= alpha;
+                }
                 m_run += delta;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) negm[r] = -m_run;
